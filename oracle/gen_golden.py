@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE ONLY — generate golden vectors by running the real reference.
+
+Runs ONLY in the build container (needs /root/reference; no-op elsewhere).  It calls the
+reference's own public functions on seeded synthetic waypoints and stores inputs + outputs as small
+``.npz`` fixtures under ``tests/golden/``.  No reference source is copied: a fixture is data.
+
+    python oracle/gen_golden.py            # all small cases (~1 min)
+    python oracle/gen_golden.py --c2       # additionally the 256-waypoint x 1e6-sample case (~4 min)
+
+What is captured per case (all fp64; waypoints are fp32-representable so that the fp32 device path
+and the fp64 reference see identical inputs):
+  inputs : waypoints, constraints(6), dd, start/end velocity, per-node / action-point attributes
+  fit    : per-spline segment blocks (G,6,2), segment_lengths, parameters[-1]
+           (quintic_hermite_spline.py:30-138)
+  LUT    : lookup_table.distances / parameters / total_length (spline_manager.py:426-475)
+  tables : strided + head/tail entries of the curvature / heading tables (spline_manager.py:477-548)
+  grid   : for every distance sample of forward_backward_pass (motion_profile_generator.py:112-176)
+           the parameter t, curvature, heading, point, and the final velocities it returns
+  profile: (case c1 only) the 9-tuple of generate_motion_profile (motion_profile_generator.py:389)
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import refimport  # noqa: E402
+from vexautonomousplanner_amd.synth import (DEFAULT_CONSTRAINTS, DEFAULT_DD, END_VEL,  # noqa: E402
+                                             START_VEL, make_waypoints)
+
+OUT = os.path.join(ROOT, "tests", "golden")
+NODE_FIELDS = ("is_reverse_node", "turn", "wait_time", "stop", "max_velocity", "max_acceleration")
+
+
+def build_manager(sm_mod, wp, node_attrs=None, action_points=None):
+    W = len(wp)
+    nodes = []
+    for i in range(W):
+        kw = dict(node_attrs[i]) if node_attrs else {}
+        if "tangent" in kw and kw["tangent"] is not None:
+            kw["tangent"] = np.asarray(kw["tangent"], dtype=float)
+        nodes.append(refimport.Node(**kw))
+    aps = [refimport.ActionPoint(**a) for a in (action_points or [])]
+    mgr = sm_mod.QuinticHermiteSplineManager()
+    ok = mgr.build_path(np.array(wp, dtype=float), nodes, aps)
+    assert ok
+    return mgr
+
+
+def walk_grid(mgr, dd, max_keep=None):
+    """Re-walk the distance grid of forward_backward_pass with the reference's own accessors."""
+    total = mgr.get_total_arc_length()
+    ts, ks, hs, xs, ys = [], [], [], [], []
+    s = 0
+    while s < total:
+        t = mgr.distance_to_time(s)
+        ts.append(float(t))
+        ks.append(float(mgr.get_curvature(t)))
+        hs.append(float(mgr.get_heading(t)))
+        p = mgr.get_point_at_parameter(t)
+        xs.append(float(p[0]))
+        ys.append(float(p[1]))
+        s += dd
+    t = mgr.distance_to_time(total)
+    ts.append(float(t))
+    ks.append(float(mgr.get_curvature(t)))
+    hs.append(float(mgr.get_heading(t)))
+    p = mgr.get_point_at_parameter(t)
+    xs.append(float(p[0]))
+    ys.append(float(p[1]))
+    return (np.array(ts), np.array(ks), np.array(hs), np.array(xs), np.array(ys))
+
+
+def node_arrays(W, node_attrs):
+    out = {}
+    for f in NODE_FIELDS:
+        out["node_" + f] = np.array([float((node_attrs[i] if node_attrs else {}).get(f, 0))
+                                     for i in range(W)])
+    tan = np.full((W, 2), np.nan)
+    mag = np.full((W, 2), np.nan)
+    if node_attrs:
+        for i, a in enumerate(node_attrs):
+            if a.get("tangent") is not None:
+                tan[i] = a["tangent"]
+                mag[i] = (a["incoming_magnitude"], a["outgoing_magnitude"])
+    out["node_tangent"] = tan
+    out["node_magnitudes"] = mag
+    return out
+
+
+def run_case(mods, name, wp, dd=DEFAULT_DD, samples=None, node_attrs=None, action_points=None,
+             constraints=DEFAULT_CONSTRAINTS, full_profile=False, keep="all"):
+    sm_mod, _, mpg = mods
+    t0 = time.time()
+    wp = np.asarray(wp, dtype=np.float64)
+    W = len(wp)
+    mgr = build_manager(sm_mod, wp, node_attrs, action_points)
+    mgr.rebuild_tables()
+    total = mgr.get_total_arc_length()
+    if samples is not None:
+        # "fixed sample count" grid of this build: dd = L/(S-1.5) gives exactly S-1 loop samples
+        # (k*dd < L for k <= S-2 with half a step of margin) plus the appended end sample.
+        dd = float(total) / (samples - 1.5)
+    c = mpg.Constraints(*constraints)
+    vel = np.array(mpg.forward_backward_pass(mgr, c, dd), dtype=np.float64)
+    ts, ks, hs, xs, ys = walk_grid(mgr, dd)
+    assert len(vel) == len(ts), (len(vel), len(ts))
+    if samples is not None:
+        assert len(vel) == samples, (len(vel), samples)
+    d = {
+        "waypoints": wp,
+        "constraints": np.array(constraints, dtype=np.float64),
+        "dd": np.float64(dd),
+        "samples": np.int64(samples if samples is not None else 0),
+        "start_vel": np.float64(START_VEL),
+        "end_vel": np.float64(END_VEL),
+        "n_splines": np.int64(len(mgr.splines)),
+        "lut_distances": np.asarray(mgr.lookup_table.distances),
+        "lut_parameters": np.asarray(mgr.lookup_table.parameters),
+        "total_length": np.float64(total),
+        "n_samples": np.int64(len(vel)),
+    }
+    d.update(node_arrays(W, node_attrs))
+    if action_points:
+        d["ap_t"] = np.array([a["t"] for a in action_points], dtype=np.float64)
+        for f in ("stop", "wait_time", "max_velocity", "max_acceleration"):
+            d["ap_" + f] = np.array([float(a.get(f, 0)) for a in action_points])
+    for si, sp in enumerate(mgr.splines):
+        d[f"spline{si}_segments"] = np.array(sp.segments)
+        d[f"spline{si}_segment_lengths"] = np.array(sp.segment_lengths, dtype=np.float64)
+        d[f"spline{si}_param_last"] = np.float64(sp.parameters[-1])
+        d[f"spline{si}_n_points"] = np.int64(len(sp.control_points))
+    props = mgr._precomputed_properties
+    n_tab = len(props["parameters"])
+    idx = np.unique(np.concatenate([np.arange(0, min(16, n_tab)), np.arange(0, n_tab, 97),
+                                    np.arange(max(0, n_tab - 16), n_tab)]))
+    d["tab_n"] = np.int64(n_tab)
+    d["tab_idx"] = idx
+    d["tab_parameters"] = props["parameters"][idx]
+    d["tab_curvatures"] = props["curvatures"][idx]
+    d["tab_headings"] = props["headings"][idx]
+    if keep == "all":
+        sel = np.arange(len(vel))
+    else:  # large case: strided + windows
+        n = len(vel)
+        sel = np.unique(np.concatenate([np.arange(0, 512), np.arange(0, n, 997),
+                                        np.arange(n // 2, n // 2 + 4096), np.arange(n - 512, n)]))
+    d["grid_idx"] = sel
+    d["grid_t"] = ts[sel]
+    d["grid_curvature"] = ks[sel]
+    d["grid_heading"] = hs[sel]
+    d["grid_x"] = xs[sel]
+    d["grid_y"] = ys[sel]
+    d["grid_velocity"] = vel[sel]
+    d["velocity_sum"] = np.float64(np.sum(vel))
+    if full_profile:
+        mgr2 = build_manager(sm_mod, wp, node_attrs, action_points)
+        res = mpg.generate_motion_profile(mgr2, mpg.Constraints(*constraints))
+        names = ("times", "positions", "linear_vels", "accelerations", "headings", "angular_vels",
+                 "nodes_map", "actions_map")
+        for nm, arr in zip(names, res[:8]):
+            d["profile_" + nm] = np.array(arr, dtype=np.float64)
+        d["profile_coords"] = np.array([np.asarray(p, dtype=np.float64) for p in res[8]])
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **d)
+    print(f"{name}: W={W} N={len(vel)} L={total:.6f} dd={dd:.6g} "
+          f"{os.path.getsize(path) / 1024:.0f} KiB  {time.time() - t0:.1f}s", flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--c2", action="store_true", help="also run the 1e6-sample single-path case")
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    if not refimport.available():
+        print("reference tree absent: nothing to do")
+        return
+    mods = refimport.load()
+
+    def want(name):
+        return args.only is None or args.only in name
+
+    # plain-node paths at the reference's native grid (dd = 0.005 ft)
+    for W in (2, 5, 8, 32):
+        for seed in range(5):
+            name = f"plain_w{W}_s{seed}"
+            if want(name):
+                run_case(mods, name, make_waypoints(1, W, 100 + seed)[0],
+                         full_profile=(W in (5, 8) and seed == 0))
+    # config 1: single 8-waypoint path, default constraints, seed 1 (+ full time-domain profile)
+    if want("c1_w8"):
+        run_case(mods, "c1_w8", make_waypoints(1, 8, 1)[0], full_profile=True)
+    # fixed-sample-count grids (bench semantics): slices of config 3's batch (seed 3)
+    c3 = make_waypoints(8, 32, 3)
+    if want("c3_p0_S10000"):
+        run_case(mods, "c3_p0_S10000", c3[0], samples=10000)
+    for p in (1, 2, 3):
+        if want(f"c3_p{p}_S1024"):
+            run_case(mods, f"c3_p{p}_S1024", c3[p], samples=1024)
+    # config 5 slice: 8 waypoints, 1024 samples
+    c5 = make_waypoints(4, 8, 5)
+    for p in range(2):
+        if want(f"c5_p{p}_S1024"):
+            run_case(mods, f"c5_p{p}_S1024", c5[p], samples=1024)
+    # a 256-waypoint path on a moderate grid
+    c2wp = make_waypoints(1, 256, 2)[0]
+    if want("c2_w256_S20000"):
+        run_case(mods, "c2_w256_S20000", c2wp, samples=20000, keep="strided")
+    if args.c2 and want("c2_w256_S1000000"):
+        run_case(mods, "c2_w256_S1000000", c2wp, samples=1000000, keep="strided")
+
+    # ---- feature cases for SURVEY.md §8(f) "next" rows (node / action-point semantics) ----
+    wp8 = make_waypoints(1, 8, 11)[0]
+    if want("feat_stop"):
+        na = [{} for _ in range(8)]
+        na[3] = {"stop": True}
+        run_case(mods, "feat_stop", wp8, node_attrs=na, full_profile=True)
+    if want("feat_limits"):
+        na = [{} for _ in range(8)]
+        na[0] = {"max_velocity": 3.0, "max_acceleration": 5.0}
+        na[2] = {"max_velocity": 2.0}
+        na[4] = {"max_acceleration": 3.0}
+        na[5] = {"max_velocity": 3.5, "max_acceleration": 6.0}
+        run_case(mods, "feat_limits", wp8, node_attrs=na, full_profile=True)
+    if want("feat_tangent"):
+        na = [{} for _ in range(8)]
+        na[2] = {"tangent": [0.6, 0.8], "incoming_magnitude": 0.7, "outgoing_magnitude": 0.4}
+        na[5] = {"tangent": [-0.8, 0.6], "incoming_magnitude": 0.5, "outgoing_magnitude": 0.9}
+        run_case(mods, "feat_tangent", wp8, node_attrs=na, full_profile=True)
+    if want("feat_action"):
+        aps = [{"t": 1.4, "max_velocity": 2.5}, {"t": 3.3, "stop": True, "max_acceleration": 4.0},
+               {"t": 5.6, "wait_time": 0.2}]
+        run_case(mods, "feat_action", wp8, action_points=aps, full_profile=True)
+    if want("feat_reverse"):
+        na = [{} for _ in range(8)]
+        na[3] = {"is_reverse_node": True}
+        run_case(mods, "feat_reverse", wp8, node_attrs=na, full_profile=True)
+    if want("feat_turn"):
+        na = [{} for _ in range(8)]
+        na[4] = {"turn": 90}
+        run_case(mods, "feat_turn", wp8, node_attrs=na, full_profile=True)
+    if want("feat_wait"):
+        na = [{} for _ in range(8)]
+        na[0] = {"wait_time": 0.3}
+        na[3] = {"wait_time": 0.5}
+        run_case(mods, "feat_wait", wp8, node_attrs=na, full_profile=True)
+    if want("feat_mixed"):
+        na = [{} for _ in range(8)]
+        na[2] = {"is_reverse_node": True, "wait_time": 0.1}
+        na[4] = {"turn": -45, "max_velocity": 2.0}
+        na[6] = {"stop": True, "tangent": [1.0, 0.0], "incoming_magnitude": 0.5,
+                 "outgoing_magnitude": 0.5}
+        aps = [{"t": 0.5, "max_velocity": 1.5}, {"t": 5.2, "stop": True}]
+        run_case(mods, "feat_mixed", wp8, node_attrs=na, action_points=aps, full_profile=True)
+
+
+if __name__ == "__main__":
+    main()
