@@ -1,0 +1,161 @@
+/* vap.h — C-ABI of libvap.so: MI355X-native batched trajectory generator.
+ *
+ * Drop-in boundary for the quintic-Hermite spline + 2-D motion-profile hot path of
+ * RohitMovva/VexAutonomousPlanner.  The reference has no FFI of its own (it is pure Python); each
+ * entry point below names the reference function(s) it replaces (file:line under the reference's
+ * src/), and INTEGRATION.md shows the ctypes binding a maintainer adds on the reference side.
+ *
+ *   QHS = splines/quintic_hermite_spline.py      SM = splines/spline_manager.py
+ *   MPG = motion_profiling_v2/motion_profile_generator.py
+ *
+ * Conventions
+ *   - plain C types only; every buffer is caller-owned; the library keeps no pointer after a call.
+ *   - "d_" pointers are DEVICE (HBM) pointers valid on the context's device; "h_" pointers are host.
+ *   - all entry points return 0 (VAP_OK) or a negative vap_status; none of them throws.
+ *   - work is enqueued on the context's HIP stream (vap_ctx_set_stream); "_host" variants and
+ *     vap_ctx_synchronize block, the device-pointer variants do not.
+ *   - units: feet, seconds, radians.
+ *
+ * Precision (`vap_dtype`):
+ *   VAP_F32  fp32 inputs/outputs.  Parameter/index arithmetic, derivative evaluation and curvature
+ *            are carried in fp64 on the device (the reference's table/step-lookup quantisation and
+ *            its finite-difference angular-acceleration term are not reproducible to 1e-5 otherwise,
+ *            see DESIGN.md §Numerics); headings, the velocity recurrence and all stores are fp32.
+ *   VAP_F64  fp64 inputs/outputs, all arithmetic fp64.
+ */
+#ifndef VAP_H
+#define VAP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VAP_VERSION 100
+
+typedef enum {
+    VAP_OK = 0,
+    VAP_ERR_INVALID = -1,     /* bad argument (NULL, W < 2, S < 2, ...): reference returns False */
+    VAP_ERR_NO_DEVICE = -2,   /* no usable HIP device: the product never falls back to the CPU */
+    VAP_ERR_HIP = -3,         /* a HIP runtime call failed; vap_last_error() has the text */
+    VAP_ERR_UNFITTED = -4,    /* evaluator called before fit/build (reference: ValueError) */
+    VAP_ERR_CAPACITY = -5,    /* output capacity S too small for the requested grid */
+    VAP_ERR_UNSUPPORTED = -6
+} vap_status;
+
+typedef enum { VAP_F32 = 0, VAP_F64 = 1 } vap_dtype;
+
+/* MPG:14-21 Constraints dataclass, same field order. */
+typedef struct {
+    double max_vel, max_acc, max_dec, friction_coef, max_jerk, track_width;
+} vap_constraints;
+
+/* Per-path flag bits written to flags[b]. */
+#define VAP_FLAG_DEGENERATE 1u /* zero-length segment or non-finite value met during fit/LUT */
+#define VAP_FLAG_TRUNCATED 2u  /* grid needed more than S samples; the first S were produced */
+#define VAP_FLAG_NOCONVERGE 4u /* velocity relaxation hit its round limit (never expected) */
+
+/* Timing slots of vap_last_timing (milliseconds, HIP events on the context's stream). */
+enum { VAP_T_FIT = 0, VAP_T_LUT = 1, VAP_T_SAMPLE = 2, VAP_T_VELOCITY = 3, VAP_T_TOTAL = 4,
+       VAP_T_COUNT = 8 };
+
+#define VAP_LUT_SAMPLES 1000      /* SM:427 min_samples */
+#define VAP_SAMPLES_PER_NODE 1000 /* SM:477 samples_per_node */
+
+typedef struct vap_ctx vap_ctx;
+
+/* ---- context ------------------------------------------------------------------------------- */
+int vap_version(void);
+const char *vap_status_string(int status);
+/* Thread-local text of the last failure in this thread ("" if none). */
+const char *vap_last_error(void);
+/* Number of HIP devices visible (0 when there is none; never initialises a context). */
+int vap_device_count(void);
+/* One context = one device + one stream + its scratch arena.  Not thread-safe; one per thread. */
+int vap_ctx_create(int device, vap_ctx **out);
+int vap_ctx_destroy(vap_ctx *ctx);
+/* Run subsequent work on `hip_stream` (a hipStream_t, e.g. torch's current stream); NULL = the
+ * context's own stream. */
+int vap_ctx_set_stream(vap_ctx *ctx, void *hip_stream);
+int vap_ctx_synchronize(vap_ctx *ctx);
+/* Enable/disable per-stage hipEvent timing (replaces the reference's time.time() log lines,
+ * SM:587-594, MPG:398-411).  Off by default. */
+int vap_ctx_set_timing(vap_ctx *ctx, int enabled);
+int vap_last_timing(vap_ctx *ctx, float ms[VAP_T_COUNT]);
+
+/* ---- staged device API (plain-node paths: one spline of W control points per path) ----------
+ * Buffers, for a batch of B paths with W waypoints (G = W-1 segments) and sample capacity S:
+ *   waypoints  [B][W][2]                 dtype
+ *   segments   [B][G][6][2]   fp64       rows p0,p1,d0*L,d1*L,dd0*L^2,dd1*L^2 (QHS:92-122)
+ *   lut        [B][1000]      fp64       lookup_table.distances (SM:448-454); parameters are
+ *                                        j * param_last/999 (np.linspace) and are not stored
+ *   meta       [B][4]         fp64       {parameters[-1] (QHS:736), total_length, dd, n_samples}
+ *   x,y,heading,curvature,velocity [B][S] dtype
+ */
+
+/* QHS:30-138 fit + QHS:149-219 _compute_derivatives + QHS:719-736 _compute_parameters, batched;
+ * also SM:42-172 build_path for plain nodes.  d_tangent_in/out: optional [B][W][2] fp64 per-node
+ * tangent overrides (NaN = None; SM:65-77, QHS:102-115), or NULL. */
+int vap_fit(vap_ctx *ctx, vap_dtype dt, int B, int W, const void *d_waypoints,
+            const double *d_tangent_in, const double *d_tangent_out, double *d_segments,
+            double *d_meta, uint32_t *d_flags);
+
+/* SM:426-475 build_lookup_table.  Fills lut and meta[1] (= get_total_arc_length, SM:320-330). */
+int vap_build_lut(vap_ctx *ctx, int B, int W, const double *d_segments, double *d_lut,
+                  double *d_meta, uint32_t *d_flags);
+
+/* Distance grid + per-sample properties: MPG:112-176 (the sampling loop of forward_backward_pass)
+ * with SM:291-318 distance_to_time, SM:477-580 (the curvature/heading table entry the reference's
+ * step lookup selects, evaluated on demand — the 1000*W table is never materialised) and
+ * SM:204-215 get_point_at_parameter.
+ *   dd > 0 : reference grid, s_k = k*dd while s_k < L, plus the end sample; n_samples varies
+ *   dd <= 0: fixed grid of exactly S samples, dd_b = L_b / (S - 1.5)
+ * Writes meta[2], meta[3]; d_dtheta [B][S] (dtype) receives |heading[k+1]-heading[k]| for the
+ * velocity pass (scratch; may be NULL only if the velocity pass is not wanted). */
+int vap_sample(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd, const double *d_segments,
+               const double *d_lut, double *d_meta, void *d_x, void *d_y, void *d_heading,
+               void *d_curvature, void *d_dtheta, uint32_t *d_flags);
+
+/* MPG:188-316 forward + backward pass.  d_velocity receives the final velocities (MPG:316).
+ * d_vcap: optional [B][S] (dtype) per-sample initial velocities (MPG:121,127,153,172; NULL = the
+ * plain-node default max_vel with start/end velocities at the ends). */
+int vap_velocity_pass(vap_ctx *ctx, vap_dtype dt, int B, int S, const vap_constraints *c,
+                      double start_vel, double end_vel, const double *d_meta,
+                      const void *d_curvature, const void *d_dtheta, const void *d_vcap,
+                      void *d_velocity, uint32_t *d_flags);
+
+/* ---- fused hot path ------------------------------------------------------------------------ */
+
+/* rebuild_tables (SM:582-594) + forward_backward_pass (MPG:70-316) for B plain-node paths, inputs
+ * and outputs resident in HBM.  Any output pointer may be NULL except d_velocity.
+ * d_meta: optional [B][4] fp64 (see above); d_flags: optional [B]. */
+int vap_profile_batch(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd,
+                      const void *d_waypoints, const vap_constraints *c, double start_vel,
+                      double end_vel, void *d_x, void *d_y, void *d_heading, void *d_curvature,
+                      void *d_velocity, double *d_meta, uint32_t *d_flags);
+
+/* Same with host buffers (allocates device scratch in the context arena, copies in and out,
+ * synchronises).  This is what a single-path GUI call uses. */
+int vap_profile_batch_host(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd,
+                           const void *h_waypoints, const vap_constraints *c, double start_vel,
+                           double end_vel, void *h_x, void *h_y, void *h_heading,
+                           void *h_curvature, void *h_velocity, double *h_meta,
+                           uint32_t *h_flags);
+
+/* ---- scalar / vector evaluators on a fitted path (host buffers) -----------------------------
+ * SM:204-241 get_point / get_derivative / get_second_derivative _at_parameter for n parameters of
+ * path 0 of a (1,G,6,2) segment block held on the host.  order = 0,1,2.  out [n][2] fp64. */
+int vap_eval_host(vap_ctx *ctx, int W, const double *h_segments, double param_last, int order,
+                  int n, const double *h_t, double *h_out);
+
+/* SM:291-318 distance_to_time for n distances; SM:332-346 get_heading / get_curvature (table step
+ * lookup) for n parameters.  what: 0 = distance_to_time, 1 = curvature, 2 = heading. */
+int vap_lookup_host(vap_ctx *ctx, int W, const double *h_segments, double param_last,
+                    const double *h_lut, int what, int n, const double *h_in, double *h_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VAP_H */

@@ -1,0 +1,119 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle and the golden vectors.
+
+Tolerances (north_star: <= 1e-5 relative in fp32 vs the reference profile):
+  velocity   : |dv| <= 1e-5 * |v_ref|                (pure relative; v >= 0.01 everywhere)
+  curvature  : |dk| <= 1e-5 * max(|k_ref|, 1e-2)     (relative, floored at 0.01 rad/ft)
+  heading    : |dh| <= 1e-5 * pi                     (absolute: headings pass through 0)
+  x, y       : |dx| <= 1e-5 * max(|x_ref|, 1)        (feet)
+fp64 runs are held to 1e-9 on the same measures.
+"""
+import numpy as np
+import pytest
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def gens(torch_mod):
+    from vexautonomousplanner_amd.batch import BatchedTrajectoryGenerator
+    return {"f32": BatchedTrajectoryGenerator(0, "f32"), "f64": BatchedTrajectoryGenerator(0, "f64")}
+
+
+def check_fields(got, ref, tol, what=""):
+    v, rv = got["velocity"], ref["velocity"]
+    assert np.all(np.isfinite(v)), what
+    e_v = np.max(np.abs(v - rv) / np.abs(rv))
+    e_k = np.max(np.abs(got["curvature"] - ref["curvature"]) / np.maximum(np.abs(ref["curvature"]), 1e-2))
+    e_h = np.max(np.abs(got["heading"] - ref["heading"])) / np.pi
+    e_x = np.max(np.abs(got["x"] - ref["x"]) / np.maximum(np.abs(ref["x"]), 1.0))
+    e_y = np.max(np.abs(got["y"] - ref["y"]) / np.maximum(np.abs(ref["y"]), 1.0))
+    msg = f"{what}: v {e_v:.2e} k {e_k:.2e} h {e_h:.2e} x {e_x:.2e} y {e_y:.2e}"
+    print(msg)
+    assert e_v <= tol and e_k <= tol and e_h <= tol and e_x <= tol and e_y <= tol, msg
+    return e_v, e_k, e_h, e_x
+
+
+def run_gpu(torch, gen, wp64, **kw):
+    wp = torch.tensor(wp64, dtype=gen.tdtype, device=gen.device)
+    r = gen.profile(wp, **kw)
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy().astype(np.float64) if k != "flags" else v.cpu().numpy() for k, v in r.items()}
+
+
+GOLDEN_FIXED = [n for n in gu.names(("c3_", "c5_", "c2_w256_S20000"))]
+GOLDEN_DD = [n for n in gu.names(("plain_", "c1_"))]
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-5), ("f64", 1e-9)])
+@pytest.mark.parametrize("name", GOLDEN_FIXED)
+def test_fixed_grid_vs_reference_golden(torch_mod, gens, name, dtype, tol):
+    g = gu.load(name)
+    S = int(g["samples"])
+    r = run_gpu(torch_mod, gens[dtype], g["waypoints"][None], samples=S, constraints=g["constraints"])
+    assert r["flags"][0] == 0
+    assert abs(r["meta"][0, 1] - float(g["total_length"])) <= 1e-14 * float(g["total_length"])
+    assert r["meta"][0, 2] == pytest.approx(float(g["dd"]), rel=1e-14)
+    gi = g["grid_idx"]
+    got = {k: r[k][0][gi] for k in ("x", "y", "heading", "curvature", "velocity")}
+    ref = {"x": g["grid_x"], "y": g["grid_y"], "heading": g["grid_heading"],
+           "curvature": g["grid_curvature"], "velocity": g["grid_velocity"]}
+    check_fields(got, ref, tol, f"{name}/{dtype}")
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-5), ("f64", 1e-9)])
+@pytest.mark.parametrize("name", GOLDEN_DD)
+def test_reference_grid_vs_reference_golden(torch_mod, gens, name, dtype, tol):
+    g = gu.load(name)
+    N = int(g["n_samples"])
+    r = run_gpu(torch_mod, gens[dtype], g["waypoints"][None], dd=float(g["dd"]), capacity=N + 7,
+                constraints=g["constraints"])
+    assert r["flags"][0] == 0
+    assert int(r["meta"][0, 3]) == N
+    gi = g["grid_idx"]
+    got = {k: r[k][0][:N][gi] for k in ("x", "y", "heading", "curvature", "velocity")}
+    ref = {"x": g["grid_x"], "y": g["grid_y"], "heading": g["grid_heading"],
+           "curvature": g["grid_curvature"], "velocity": g["grid_velocity"]}
+    check_fields(got, ref, tol, f"{name}/{dtype}")
+    # the rows are zero-filled past n_samples
+    assert np.all(r["velocity"][0][N:] == 0)
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-5), ("f64", 1e-9)])
+@pytest.mark.parametrize("B,W,S,seed", [(64, 8, 1024, 5), (48, 32, 2000, 3), (3, 2, 300, 9), (5, 5, 257, 10)])
+def test_batch_vs_oracle(torch_mod, gens, B, W, S, seed, dtype, tol):
+    from oracle import oracle
+    from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
+    wp = make_waypoints(B, W, seed).astype(np.float64)
+    ref = oracle.profile_batch(wp, S, DEFAULT_CONSTRAINTS, n_threads=8)
+    r = run_gpu(torch_mod, gens[dtype], wp, samples=S)
+    assert np.all(r["flags"] == 0)
+    np.testing.assert_allclose(r["meta"][:, 1], ref["total_length"], rtol=1e-14)
+    check_fields(r, ref, tol, f"batch B={B} W={W} S={S}/{dtype}")
+
+
+def test_truncation_flag_and_capacity(torch_mod, gens):
+    g = gu.load("c1_w8")
+    N = int(g["n_samples"])
+    r = run_gpu(torch_mod, gens["f32"], g["waypoints"][None], dd=float(g["dd"]), capacity=N - 10)
+    assert r["flags"][0] & 2
+    assert int(r["meta"][0, 3]) == N - 10
+
+
+def test_invalid_arguments(torch_mod, gens):
+    from vexautonomousplanner_amd import _lib
+    gen = gens["f32"]
+    wp = torch_mod.zeros((1, 1, 2), dtype=gen.tdtype, device=gen.device)
+    with pytest.raises(_lib.VapError):
+        gen.profile(wp, samples=100)
+    wp = torch_mod.zeros((1, 4, 2), dtype=gen.tdtype, device=gen.device)
+    with pytest.raises(ValueError):
+        gen.profile(wp)

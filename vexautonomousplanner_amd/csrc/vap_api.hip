@@ -1,0 +1,398 @@
+// vap_api.hip — the C-ABI of libvap.so (declared in include/vap.h).
+//
+// Host-side runtime: context (device + stream + scratch arena + stage timers) and the entry points
+// that sequence the kernels of vap_kernels.hip.  There is deliberately no CPU implementation behind
+// any entry point: without a HIP device every call fails with VAP_ERR_NO_DEVICE.
+#include "../../include/vap.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "vap_kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int status, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return status;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(VAP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+struct Buffer {
+    void *ptr = nullptr;
+    size_t cap = 0;
+};
+
+}  // namespace
+
+struct vap_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    bool timing = false;
+    hipEvent_t ev[VAP_T_COUNT + 1] = {};
+    float ms[VAP_T_COUNT] = {};
+    // scratch arena (grow-only, reused across calls)
+    Buffer seg, power, lut, meta, dth, flags, io[8], small_in, small_out, small_seg, small_lut;
+
+    int ensure(Buffer &b, size_t bytes)
+    {
+        if (bytes <= b.cap) return VAP_OK;
+        if (b.ptr) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            HIP_TRY(hipFree(b.ptr));
+            b.ptr = nullptr;
+            b.cap = 0;
+        }
+        size_t want = bytes + bytes / 8 + 256;
+        HIP_TRY(hipMalloc(&b.ptr, want));
+        b.cap = want;
+        return VAP_OK;
+    }
+};
+
+#define VAP_TRY(expr)            \
+    do {                         \
+        int s_ = (expr);         \
+        if (s_ != VAP_OK) return s_; \
+    } while (0)
+
+namespace {
+
+struct StageTimer {
+    vap_ctx *c;
+    explicit StageTimer(vap_ctx *ctx) : c(ctx)
+    {
+        if (c->timing) (void)hipEventRecord(c->ev[0], c->stream);
+    }
+    void mark(int slot)
+    {
+        if (c->timing) (void)hipEventRecord(c->ev[slot + 1], c->stream);
+    }
+};
+
+int set_device(vap_ctx *ctx)
+{
+    if (!ctx) return fail(VAP_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return VAP_OK;
+}
+
+size_t esz(vap_dtype dt) { return dt == VAP_F64 ? 8 : 4; }
+
+int check_shape(int B, int W, int S)
+{
+    if (B < 1) return fail(VAP_ERR_INVALID, "batch must be >= 1 (got %d)", B);
+    if (W < 2) return fail(VAP_ERR_INVALID, "a path needs at least 2 waypoints (got %d)", W);  // SM:50-51
+    if (W > vap::kMaxWaypoints) return fail(VAP_ERR_UNSUPPORTED, "W=%d exceeds %d", W, vap::kMaxWaypoints);
+    if (S < 2) return fail(VAP_ERR_INVALID, "sample capacity must be >= 2 (got %d)", S);
+    return VAP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vap_version(void) { return VAP_VERSION; }
+
+const char *vap_status_string(int status)
+{
+    switch (status) {
+        case VAP_OK: return "ok";
+        case VAP_ERR_INVALID: return "invalid argument";
+        case VAP_ERR_NO_DEVICE: return "no HIP device";
+        case VAP_ERR_HIP: return "HIP runtime error";
+        case VAP_ERR_UNFITTED: return "path has not been fitted";
+        case VAP_ERR_CAPACITY: return "output capacity too small";
+        case VAP_ERR_UNSUPPORTED: return "unsupported size";
+        default: return "unknown status";
+    }
+}
+
+const char *vap_last_error(void) { return g_last_error.c_str(); }
+
+int vap_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int vap_ctx_create(int device, vap_ctx **out)
+{
+    if (!out) return fail(VAP_ERR_INVALID, "null out pointer");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1)
+        return fail(VAP_ERR_NO_DEVICE, "no HIP device visible: libvap has no CPU path");
+    if (device < 0 || device >= n) return fail(VAP_ERR_INVALID, "device %d out of range [0,%d)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    vap_ctx *c = new vap_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return fail(VAP_ERR_HIP, "hipStreamCreate failed");
+    }
+    c->stream = c->own_stream;
+    for (auto &e : c->ev) {
+        if (hipEventCreate(&e) != hipSuccess) {
+            delete c;
+            return fail(VAP_ERR_HIP, "hipEventCreate failed");
+        }
+    }
+    *out = c;
+    return VAP_OK;
+}
+
+int vap_ctx_destroy(vap_ctx *ctx)
+{
+    if (!ctx) return VAP_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    Buffer *bufs[] = {&ctx->seg, &ctx->power, &ctx->lut, &ctx->meta, &ctx->dth, &ctx->flags, &ctx->small_in,
+                      &ctx->small_out, &ctx->small_seg, &ctx->small_lut};
+    for (Buffer *b : bufs)
+        if (b->ptr) (void)hipFree(b->ptr);
+    for (Buffer &b : ctx->io)
+        if (b.ptr) (void)hipFree(b.ptr);
+    for (auto &e : ctx->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return VAP_OK;
+}
+
+int vap_ctx_set_stream(vap_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return fail(VAP_ERR_INVALID, "null context");
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return VAP_OK;
+}
+
+int vap_ctx_synchronize(vap_ctx *ctx)
+{
+    VAP_TRY(set_device(ctx));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return VAP_OK;
+}
+
+int vap_ctx_set_timing(vap_ctx *ctx, int enabled)
+{
+    if (!ctx) return fail(VAP_ERR_INVALID, "null context");
+    ctx->timing = enabled != 0;
+    return VAP_OK;
+}
+
+int vap_last_timing(vap_ctx *ctx, float ms[VAP_T_COUNT])
+{
+    VAP_TRY(set_device(ctx));
+    if (!ms) return fail(VAP_ERR_INVALID, "null output");
+    for (int i = 0; i < VAP_T_COUNT; i++) ms[i] = 0.f;
+    if (!ctx->timing) return VAP_OK;
+    HIP_TRY(hipEventSynchronize(ctx->ev[VAP_T_VELOCITY + 1]));
+    float total = 0.f;
+    for (int i = 0; i <= VAP_T_VELOCITY; i++) {
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, ctx->ev[i], ctx->ev[i + 1]));
+        ms[i] = t;
+        total += t;
+    }
+    ms[VAP_T_TOTAL] = total;
+    return VAP_OK;
+}
+
+int vap_fit(vap_ctx *ctx, vap_dtype dt, int B, int W, const void *d_waypoints, const double *d_tangent_in,
+            const double *d_tangent_out, double *d_segments, double *d_meta, uint32_t *d_flags)
+{
+    VAP_TRY(set_device(ctx));
+    VAP_TRY(check_shape(B, W, 2));
+    if (!d_waypoints || !d_segments || !d_meta) return fail(VAP_ERR_INVALID, "null buffer");
+    HIP_TRY(vap::launch_fit(ctx->stream, dt == VAP_F64, B, W, d_waypoints, d_tangent_in, d_tangent_out,
+                            d_segments, nullptr, d_meta, d_flags));
+    return VAP_OK;
+}
+
+int vap_build_lut(vap_ctx *ctx, int B, int W, const double *d_segments, double *d_lut, double *d_meta,
+                  uint32_t *d_flags)
+{
+    VAP_TRY(set_device(ctx));
+    VAP_TRY(check_shape(B, W, 2));
+    if (!d_segments || !d_lut || !d_meta) return fail(VAP_ERR_INVALID, "null buffer");
+    HIP_TRY(vap::launch_lut(ctx->stream, B, W, d_segments, d_lut, d_meta, d_flags));
+    return VAP_OK;
+}
+
+int vap_sample(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd, const double *d_segments,
+               const double *d_lut, double *d_meta, void *d_x, void *d_y, void *d_heading, void *d_curvature,
+               void *d_dtheta, uint32_t *d_flags)
+{
+    VAP_TRY(set_device(ctx));
+    VAP_TRY(check_shape(B, W, S));
+    if (!d_segments || !d_lut || !d_meta) return fail(VAP_ERR_INVALID, "null buffer");
+    const size_t n_seg = (size_t)B * (W - 1);
+    VAP_TRY(ctx->ensure(ctx->power, n_seg * 12 * sizeof(double)));
+    HIP_TRY(vap::launch_power(ctx->stream, (int)n_seg, d_segments, (double *)ctx->power.ptr));
+    HIP_TRY(vap::launch_grid(ctx->stream, B, S, dd, d_meta, d_flags));
+    HIP_TRY(vap::launch_sample(ctx->stream, dt == VAP_F64, B, W, S, (const double *)ctx->power.ptr, d_lut, d_meta,
+                               d_x, d_y, d_heading, d_curvature, d_dtheta));
+    return VAP_OK;
+}
+
+int vap_velocity_pass(vap_ctx *ctx, vap_dtype dt, int B, int S, const vap_constraints *c, double start_vel,
+                      double end_vel, const double *d_meta, const void *d_curvature, const void *d_dtheta,
+                      const void *d_vcap, void *d_velocity, uint32_t *d_flags)
+{
+    (void)d_flags;
+    VAP_TRY(set_device(ctx));
+    VAP_TRY(check_shape(B, 2, S));
+    if (!c || !d_meta || !d_curvature || !d_dtheta || !d_velocity) return fail(VAP_ERR_INVALID, "null buffer");
+    const double cc[6] = {c->max_vel, c->max_acc, c->max_dec, c->friction_coef, c->max_jerk, c->track_width};
+    HIP_TRY(vap::launch_velocity_seq(ctx->stream, dt == VAP_F64, B, S, cc, start_vel, end_vel, d_meta, d_curvature,
+                                     d_dtheta, d_vcap, d_velocity));
+    return VAP_OK;
+}
+
+int vap_profile_batch(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd, const void *d_waypoints,
+                      const vap_constraints *c, double start_vel, double end_vel, void *d_x, void *d_y,
+                      void *d_heading, void *d_curvature, void *d_velocity, double *d_meta, uint32_t *d_flags)
+{
+    VAP_TRY(set_device(ctx));
+    VAP_TRY(check_shape(B, W, S));
+    if (!d_waypoints || !c || !d_velocity) return fail(VAP_ERR_INVALID, "null buffer");
+    const bool f64 = dt == VAP_F64;
+    const size_t n_seg = (size_t)B * (W - 1), n_pts = (size_t)B * S;
+    VAP_TRY(ctx->ensure(ctx->seg, n_seg * 12 * sizeof(double)));
+    VAP_TRY(ctx->ensure(ctx->power, n_seg * 12 * sizeof(double)));
+    VAP_TRY(ctx->ensure(ctx->lut, (size_t)B * VAP_LUT_SAMPLES * sizeof(double)));
+    VAP_TRY(ctx->ensure(ctx->dth, n_pts * esz(dt)));
+    double *meta = d_meta;
+    if (!meta) {
+        VAP_TRY(ctx->ensure(ctx->meta, (size_t)B * 4 * sizeof(double)));
+        meta = (double *)ctx->meta.ptr;
+    }
+    uint32_t *flags = d_flags;
+    if (!flags) {
+        VAP_TRY(ctx->ensure(ctx->flags, (size_t)B * sizeof(uint32_t)));
+        flags = (uint32_t *)ctx->flags.ptr;
+    }
+    void *curv = d_curvature;
+    if (!curv) {
+        VAP_TRY(ctx->ensure(ctx->io[7], n_pts * esz(dt)));
+        curv = ctx->io[7].ptr;
+    }
+    const double cc[6] = {c->max_vel, c->max_acc, c->max_dec, c->friction_coef, c->max_jerk, c->track_width};
+    StageTimer tm(ctx);
+    HIP_TRY(vap::launch_fit(ctx->stream, f64, B, W, d_waypoints, nullptr, nullptr, (double *)ctx->seg.ptr,
+                            (double *)ctx->power.ptr, meta, flags));
+    tm.mark(VAP_T_FIT);
+    HIP_TRY(vap::launch_lut(ctx->stream, B, W, (const double *)ctx->seg.ptr, (double *)ctx->lut.ptr, meta, flags));
+    HIP_TRY(vap::launch_grid(ctx->stream, B, S, dd, meta, flags));
+    tm.mark(VAP_T_LUT);
+    HIP_TRY(vap::launch_sample(ctx->stream, f64, B, W, S, (const double *)ctx->power.ptr,
+                               (const double *)ctx->lut.ptr, meta, d_x, d_y, d_heading, curv, ctx->dth.ptr));
+    tm.mark(VAP_T_SAMPLE);
+    HIP_TRY(vap::launch_velocity_seq(ctx->stream, f64, B, S, cc, start_vel, end_vel, meta, curv, ctx->dth.ptr,
+                                     nullptr, d_velocity));
+    tm.mark(VAP_T_VELOCITY);
+    return VAP_OK;
+}
+
+int vap_profile_batch_host(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd, const void *h_waypoints,
+                           const vap_constraints *c, double start_vel, double end_vel, void *h_x, void *h_y,
+                           void *h_heading, void *h_curvature, void *h_velocity, double *h_meta,
+                           uint32_t *h_flags)
+{
+    VAP_TRY(set_device(ctx));
+    VAP_TRY(check_shape(B, W, S));
+    if (!h_waypoints || !c || !h_velocity) return fail(VAP_ERR_INVALID, "null buffer");
+    const size_t n_pts = (size_t)B * S, e = esz(dt);
+    VAP_TRY(ctx->ensure(ctx->io[0], (size_t)B * W * 2 * e));
+    void *houts[5] = {h_x, h_y, h_heading, h_curvature, h_velocity};
+    void *douts[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < 5; i++) {
+        if (!houts[i]) continue;
+        VAP_TRY(ctx->ensure(ctx->io[1 + i], n_pts * e));
+        douts[i] = ctx->io[1 + i].ptr;
+    }
+    VAP_TRY(ctx->ensure(ctx->meta, (size_t)B * 4 * sizeof(double)));
+    VAP_TRY(ctx->ensure(ctx->flags, (size_t)B * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpyAsync(ctx->io[0].ptr, h_waypoints, (size_t)B * W * 2 * e, hipMemcpyHostToDevice, ctx->stream));
+    VAP_TRY(vap_profile_batch(ctx, dt, B, W, S, dd, ctx->io[0].ptr, c, start_vel, end_vel, douts[0], douts[1],
+                              douts[2], douts[3], douts[4], (double *)ctx->meta.ptr, (uint32_t *)ctx->flags.ptr));
+    for (int i = 0; i < 5; i++)
+        if (houts[i]) HIP_TRY(hipMemcpyAsync(houts[i], douts[i], n_pts * e, hipMemcpyDeviceToHost, ctx->stream));
+    if (h_meta)
+        HIP_TRY(hipMemcpyAsync(h_meta, ctx->meta.ptr, (size_t)B * 4 * sizeof(double), hipMemcpyDeviceToHost,
+                               ctx->stream));
+    if (h_flags)
+        HIP_TRY(hipMemcpyAsync(h_flags, ctx->flags.ptr, (size_t)B * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                               ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return VAP_OK;
+}
+
+int vap_eval_host(vap_ctx *ctx, int W, const double *h_segments, double param_last, int order, int n,
+                  const double *h_t, double *h_out)
+{
+    VAP_TRY(set_device(ctx));
+    if (W < 2 || !h_segments) return fail(VAP_ERR_UNFITTED, "Spline has not been fitted yet");  // QHS:222-223
+    if (order < 0 || order > 2 || n < 0 || (n > 0 && (!h_t || !h_out))) return fail(VAP_ERR_INVALID, "bad argument");
+    if (n == 0) return VAP_OK;
+    const size_t sb = (size_t)(W - 1) * 12 * sizeof(double);
+    VAP_TRY(ctx->ensure(ctx->small_seg, sb));
+    VAP_TRY(ctx->ensure(ctx->small_in, (size_t)n * sizeof(double)));
+    VAP_TRY(ctx->ensure(ctx->small_out, (size_t)n * 2 * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(ctx->small_seg.ptr, h_segments, sb, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->small_in.ptr, h_t, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(vap::launch_eval(ctx->stream, W, (const double *)ctx->small_seg.ptr, param_last, order, n,
+                             (const double *)ctx->small_in.ptr, (double *)ctx->small_out.ptr));
+    HIP_TRY(hipMemcpyAsync(h_out, ctx->small_out.ptr, (size_t)n * 2 * sizeof(double), hipMemcpyDeviceToHost,
+                           ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return VAP_OK;
+}
+
+int vap_lookup_host(vap_ctx *ctx, int W, const double *h_segments, double param_last, const double *h_lut,
+                    int what, int n, const double *h_in, double *h_out)
+{
+    VAP_TRY(set_device(ctx));
+    if (W < 2 || !h_segments || !h_lut) return fail(VAP_ERR_UNFITTED, "No splines have been initialized");
+    if (what < 0 || what > 2 || n < 0 || (n > 0 && (!h_in || !h_out))) return fail(VAP_ERR_INVALID, "bad argument");
+    if (n == 0) return VAP_OK;
+    const size_t sb = (size_t)(W - 1) * 12 * sizeof(double);
+    VAP_TRY(ctx->ensure(ctx->small_seg, sb));
+    VAP_TRY(ctx->ensure(ctx->small_lut, VAP_LUT_SAMPLES * sizeof(double)));
+    VAP_TRY(ctx->ensure(ctx->small_in, (size_t)n * sizeof(double)));
+    VAP_TRY(ctx->ensure(ctx->small_out, (size_t)n * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(ctx->small_seg.ptr, h_segments, sb, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->small_lut.ptr, h_lut, VAP_LUT_SAMPLES * sizeof(double), hipMemcpyHostToDevice,
+                           ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->small_in.ptr, h_in, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(vap::launch_lookup(ctx->stream, W, (const double *)ctx->small_seg.ptr, param_last,
+                               (const double *)ctx->small_lut.ptr, what, n, (const double *)ctx->small_in.ptr,
+                               (double *)ctx->small_out.ptr));
+    HIP_TRY(hipMemcpyAsync(h_out, ctx->small_out.ptr, (size_t)n * sizeof(double), hipMemcpyDeviceToHost,
+                           ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return VAP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,279 @@
+// vap_device.h — device-side building blocks shared by the kernels (gfx950).
+//
+// Built with -ffp-contract=off: the parameter / index arithmetic must round exactly like the
+// reference's NumPy fp64; FMAs appear only where written as fma().
+//
+// Reference citations: QHS = splines/quintic_hermite_spline.py, SM = splines/spline_manager.py,
+// MPG = motion_profiling_v2/motion_profile_generator.py (under the reference's src/).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vap {
+
+constexpr int kLutN = 1000;        // SM:427
+constexpr int kSamplesPerNode = 1000;  // SM:477
+
+// meta[b][4] = {param_last, total_length, dd, n_samples}
+constexpr int kMetaStride = 4;
+
+// np.linspace(0, stop, num)[j] (numpy/_core/function_base.py): j*step, endpoint forced to stop.
+__device__ __forceinline__ double linspace_at(double stop, int num, int j)
+{
+    if (j == num - 1) return stop;
+    const double step = stop / (double)(num - 1);
+    return (double)j * step;
+}
+
+// QHS:506-541 _normalize_parameter for a spline with G segments and parameters[-1] = t_max.
+__device__ __forceinline__ void normalize_parameter(double t, double t_max, int G, double &lt, int &idx)
+{
+    double tt = t < t_max ? t : t_max;
+    tt = 0.0 > tt ? 0.0 : tt;
+    int i = (int)tt;
+    if (i == G) i = G - 1;
+    lt = tt - (double)i;
+    idx = i;
+}
+
+// QHS:324-363 first-derivative basis, in the reference's own association order (no FMA): used where
+// bit-identical arc-length tables matter (SM:447).
+__device__ __forceinline__ void hermite_d1_ref(const double *__restrict__ sg, double t, double &ox, double &oy)
+{
+    const double t2 = t * t, t3 = t2 * t, t4 = t3 * t;
+    double H[6];
+    H[0] = -30 * t2 + 60 * t3 - 30 * t4;
+    H[1] = 30 * t2 - 60 * t3 + 30 * t4;
+    H[2] = 1 - 18 * t2 + 32 * t3 - 15 * t4;
+    H[3] = -12 * t2 + 28 * t3 - 15 * t4;
+    H[4] = t - 4.5 * t2 + 6 * t3 - 2.5 * t4;
+    H[5] = 1.5 * t2 - 4 * t3 + 2.5 * t4;
+    double ax = 0.0, ay = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        ax += H[i] * sg[2 * i];
+        ay += H[i] * sg[2 * i + 1];
+    }
+    ox = ax;
+    oy = ay;
+}
+
+// QHS:288-322 / 365-416 position and second-derivative bases in the reference's association order.
+__device__ __forceinline__ void hermite_basis_ref(int order, double t, double H[6])
+{
+    const double t2 = t * t, t3 = t2 * t, t4 = t3 * t, t5 = t4 * t;
+    if (order == 0) {
+        H[0] = 1 - 10 * t3 + 15 * t4 - 6 * t5;
+        H[1] = 10 * t3 - 15 * t4 + 6 * t5;
+        H[2] = t - 6 * t3 + 8 * t4 - 3 * t5;
+        H[3] = -4 * t3 + 7 * t4 - 3 * t5;
+        H[4] = 0.5 * t2 - 1.5 * t3 + 1.5 * t4 - 0.5 * t5;
+        H[5] = 0.5 * t3 - t4 + 0.5 * t5;
+    } else if (order == 1) {
+        H[0] = -30 * t2 + 60 * t3 - 30 * t4;
+        H[1] = 30 * t2 - 60 * t3 + 30 * t4;
+        H[2] = 1 - 18 * t2 + 32 * t3 - 15 * t4;
+        H[3] = -12 * t2 + 28 * t3 - 15 * t4;
+        H[4] = t - 4.5 * t2 + 6 * t3 - 2.5 * t4;
+        H[5] = 1.5 * t2 - 4 * t3 + 2.5 * t4;
+    } else {
+        H[0] = -60 * t + 180 * t2 - 120 * t3;
+        H[1] = 60 * t - 180 * t2 + 120 * t3;
+        H[2] = -36 * t + 96 * t2 - 60 * t3;
+        H[3] = -24 * t + 84 * t2 - 60 * t3;
+        H[4] = 1 - 9 * t + 18 * t2 - 10 * t3;
+        H[5] = 3 * t - 12 * t2 + 10 * t3;
+    }
+}
+
+// QHS:221-251 / 473-504: sum_i basis_i * segment[idx][i], accumulated from zero in row order.
+__device__ __forceinline__ void hermite_eval_ref(const double *__restrict__ seg, double t_max, int G, int order,
+                                                 double t, double &ox, double &oy)
+{
+    double lt, H[6];
+    int idx;
+    normalize_parameter(t, t_max, G, lt, idx);
+    hermite_basis_ref(order, lt, H);
+    const double *sg = seg + (size_t)idx * 12;
+    double ax = 0.0, ay = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        ax += H[i] * sg[2 * i];
+        ay += H[i] * sg[2 * i + 1];
+    }
+    ox = ax;
+    oy = ay;
+}
+
+// Hermite rows [p0,p1,d0,d1,dd0,dd1] -> monomial coefficients c0..c5 of P(t) = sum c_j t^j, for one
+// coordinate.  (Expansion of the basis polynomials at QHS:293-298; p1-p0 is formed first so the
+// near-cancelling high-order terms of a gently curved segment stay small and accurate.)
+__device__ __forceinline__ void hermite_to_power(double r0, double r1, double r2, double r3, double r4,
+                                                 double r5, double c[6])
+{
+    const double d = r1 - r0;
+    c[0] = r0;
+    c[1] = r2;
+    c[2] = 0.5 * r4;
+    c[3] = 10 * d - 6 * r2 - 4 * r3 - 1.5 * r4 + 0.5 * r5;
+    c[4] = -15 * d + 8 * r2 + 7 * r3 + 1.5 * r4 - r5;
+    c[5] = 6 * d - 3 * r2 - 3 * r3 - 0.5 * r4 + 0.5 * r5;
+}
+
+// P, P', P'' of one coordinate from monomial coefficients (Horner, explicit FMA).
+__device__ __forceinline__ double poly_p(const double *__restrict__ c, double t)
+{
+    return fma(fma(fma(fma(fma(c[5], t, c[4]), t, c[3]), t, c[2]), t, c[1]), t, c[0]);
+}
+__device__ __forceinline__ double poly_d1(const double *__restrict__ c, double t)
+{
+    return fma(fma(fma(fma(5.0 * c[5], t, 4.0 * c[4]), t, 3.0 * c[3]), t, 2.0 * c[2]), t, c[1]);
+}
+__device__ __forceinline__ double poly_d2(const double *__restrict__ c, double t)
+{
+    return fma(fma(fma(20.0 * c[5], t, 12.0 * c[4]), t, 6.0 * c[3]), t, 2.0 * c[2]);
+}
+
+// np.searchsorted(D, s, side="left") over the 1000-entry distance table: first j with D[j] >= s.
+__device__ __forceinline__ int lut_search_left(const double *__restrict__ D, double s)
+{
+    int lo = 0, hi = kLutN;
+#pragma unroll 1
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (D[mid] < s) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// SM:291-318 distance_to_time.  D = lookup_table.distances (LDS or global), parameters are
+// linspace(0, t_max, 1000) (SM:443).  `end_param` = len(nodes)-1.
+__device__ __forceinline__ double distance_to_time(const double *__restrict__ D, double total, double t_max,
+                                                    double end_param, double s)
+{
+    if (s <= 0) return 0.0;
+    if (s >= total) return end_param;
+    const int idx = lut_search_left(D, s);
+    if (idx == 0) return 0.0;
+    const double d0 = D[idx - 1], d1 = D[idx];
+    const double t0 = linspace_at(t_max, kLutN, idx - 1), t1 = linspace_at(t_max, kLutN, idx);
+    return t0 + (t1 - t0) * (s - d0) / (d1 - d0);
+}
+
+// SM:550-580 _interpolate_property reduced to what it always does (a step lookup):
+// returns the index into the linspace(0, W-1, 1000*W) property table that the reference reads for
+// parameter t.  tab_n = 1000*W, end_param = W-1.
+__device__ __forceinline__ int table_index(double t, int tab_n, double end_param)
+{
+    const double step = end_param / (double)(tab_n - 1);
+    // searchsorted-left over tp[j] = j*step (tp[tab_n-1] = end_param): first j with tp[j] >= t
+    long j = (long)ceil(t / step);
+    if (j < 0) j = 0;
+    if (j > tab_n - 1) j = tab_n - 1;
+    while (j > 0 && linspace_at(end_param, tab_n, (int)(j - 1)) >= t) j--;
+    while (j < tab_n - 1 && linspace_at(end_param, tab_n, (int)j) < t) j++;
+    if (j == 0) return 0;
+    const double frac = t - floor(t);  // t % 1 for t >= 0
+    return (int)(frac > 0.5 ? j - 1 : j);
+}
+
+// Python's min(a, b): keeps a unless b < a (a NaN in b is skipped).
+template <typename R>
+__device__ __forceinline__ R pymin(R a, R b) { return b < a ? b : a; }
+
+template <typename R>
+struct VelConsts {
+    R vmax, amax, adec, tw;
+    R wmax;    // max_angular_vel   = 2*max_vel/track_width   (MPG:81)
+    R almax;   // max_angular_accel = 2*max_acc/track_width   (MPG:82)
+};
+
+// Curvature-only limits of one sample (MPG:204-233 / 264-293), in squared-velocity space.
+template <typename R>
+struct SampleLimits {
+    R q;       // kappa^2
+    R cap_u;   // min(max_linear_vel, max_vel/(1+tw*|k|/2))^2   (MPG:218-220, 243-249)
+    R a_acc;   // min(max_accel_ang, max_accel_kin, max_acc)    (MPG:222-233 without the wheel term)
+    R a_dec;   // same with max_dec                             (MPG:283-293)
+    bool straight;
+};
+
+template <typename R>
+__device__ __forceinline__ SampleLimits<R> sample_limits(const VelConsts<R> &c, R kabs, R cur_acc, R cur_dec)
+{
+    SampleLimits<R> o;
+    o.q = kabs * kabs;
+    o.straight = kabs < (R)1e-6;
+    const R vtw = fabs(c.vmax / ((R)1 + (c.tw * kabs / (R)2)));
+    if (o.straight) {
+        o.cap_u = pymin(c.vmax, vtw);
+        o.cap_u = o.cap_u * o.cap_u;
+        o.a_acc = cur_acc;
+        o.a_dec = cur_dec;
+    } else {
+        const R max_vel_ang = c.wmax / kabs;
+        const R max_vel_kin = (R)2 * c.vmax / (c.tw * kabs + (R)2);
+        // MPG:23-33 max_speed_at_curvature
+        R mts = (((R)2 * c.vmax / c.tw) * c.vmax) / (kabs * c.vmax + ((R)2 * c.vmax / c.tw));
+        mts = pymin(mts, c.vmax);
+        R vl = pymin(pymin(max_vel_ang, max_vel_kin), mts);
+        vl = pymin(vl, vtw);
+        o.cap_u = vl * vl;
+        const R a_ang = c.almax / kabs;
+        o.a_acc = pymin(pymin(a_ang, (R)2 * cur_acc / (c.tw * kabs + (R)2)), cur_acc);
+        o.a_dec = pymin(pymin(a_ang, (R)2 * cur_dec / (c.tw * kabs + (R)2)), cur_dec);
+    }
+    return o;
+}
+
+// One forward step i -> i+1 (MPG:193-249) in u = v^2 space.
+//   u      : u_i (already final for the forward pass)
+//   wprev  : (v_{i-1}|k_{i-1}|)^2, updated to (v_i|k_i|)^2
+//   dth    : |heading[i+1]-heading[i]|
+//   u_next : current content of u_{i+1} (the initial velocity cap squared)
+template <typename R>
+__device__ __forceinline__ R forward_step(const VelConsts<R> &c, const SampleLimits<R> &L, R cur_acc, R twodd,
+                                          R u, R &wprev, R dth, R u_next)
+{
+    const R w = u * L.q;
+    R a;
+    if (L.straight) {
+        a = L.a_acc;
+    } else {
+        const R accel_ang = (w - wprev) / ((R)2 * dth);
+        // MPG:52-59 max_accels_at_turn(abs(accel_ang)); MPG:228-229 clamp at 0
+        const R x = fabs(accel_ang) * c.tw / (R)2;
+        const R left = cur_acc + x, right = cur_acc - x;
+        R aw = fabs(left) < fabs(right) ? left : right;
+        if (aw < (R)0) aw = (R)0;
+        a = pymin(pymin(L.a_acc, aw), cur_acc);
+    }
+    wprev = w;
+    const R nu = u + twodd * a;
+    return pymin(pymin(u_next, nu), L.cap_u);
+}
+
+// One backward step i -> i-1 (MPG:255-311).  dth = |heading[i-1]-heading[i]|, u_prev = u_{i-1}.
+template <typename R>
+__device__ __forceinline__ R backward_step(const VelConsts<R> &c, const SampleLimits<R> &L, R cur_acc, R twodd,
+                                           R u, R &wprev, R dth, R u_prev)
+{
+    const R w = u * L.q;
+    R a;
+    if (L.straight) {
+        a = L.a_dec;
+    } else {
+        const R accel_ang = (w - wprev) / ((R)2 * dth);
+        const R x = accel_ang * c.tw / (R)2;  // signed (MPG:288)
+        const R left = cur_acc + x, right = cur_acc - x;
+        R aw = fabs(left) < fabs(right) ? left : right;
+        if (aw < (R)0) aw = (R)0;
+        a = pymin(L.a_dec, aw);
+    }
+    wprev = w;
+    const R nu = u + twodd * a;
+    return pymin(pymin(nu, u_prev), L.cap_u);
+}
+
+}  // namespace vap

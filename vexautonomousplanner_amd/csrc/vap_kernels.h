@@ -1,0 +1,33 @@
+// vap_kernels.h — launcher declarations shared by vap_kernels.hip and vap_api.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vap {
+
+constexpr uint32_t VAP_FLAG_DEGENERATE_BIT = 1u;
+constexpr uint32_t VAP_FLAG_TRUNCATED_BIT = 2u;
+constexpr uint32_t VAP_FLAG_NOCONVERGE_BIT = 4u;
+
+constexpr int kSampleThreads = 256;
+constexpr int kSampleTile = kSampleThreads - 1;  // last thread only feeds its left neighbour
+constexpr int kMaxWaypoints = 2048;              // k_fit LDS: 7*W doubles
+
+hipError_t launch_fit(hipStream_t st, bool f64, int B, int W, const void *wp, const double *tin,
+                      const double *tout, double *seg, double *pw, double *meta, uint32_t *flags);
+hipError_t launch_lut(hipStream_t st, int B, int W, const double *seg, double *lut, double *meta,
+                      uint32_t *flags);
+hipError_t launch_grid(hipStream_t st, int B, int S, double dd, double *meta, uint32_t *flags);
+hipError_t launch_sample(hipStream_t st, bool f64, int B, int W, int S, const double *pw, const double *lut,
+                         const double *meta, void *x, void *y, void *h, void *k, void *dth);
+hipError_t launch_velocity_seq(hipStream_t st, bool f64, int B, int S, const double c[6], double sv, double ev,
+                               const double *meta, const void *curv, const void *dth, const void *vcap,
+                               void *vel);
+
+hipError_t launch_power(hipStream_t st, int n_seg, const double *seg, double *pw);
+hipError_t launch_eval(hipStream_t st, int W, const double *seg, double t_max, int order, int n, const double *t,
+                       double *out);
+hipError_t launch_lookup(hipStream_t st, int W, const double *seg, double t_max, const double *lut, int what,
+                         int n, const double *in, double *out);
+
+}  // namespace vap
