@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py — trajectory sample-points/s of the batched hot path on N MI355X (one rank per GPU).
+
+    python bench.py [--gpus N --steps K --warmup W] [--workload c3|c5|c2] [--dtype f32|f64]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path (fit -> arc-length LUT -> sampling -> forward/backward velocity
+pass) over this rank's batch of synthetic paths, inputs already resident in HBM.  Paths are
+independent, so the batch is sharded over ranks with NO data-path collective (weak scaling: every
+rank processes the same number of paths); RCCL only broadcasts the constraints before and gathers
+per-path summaries after the timed region.
+
+Workloads (BASELINE.json configs):
+  c3 (default): 4096 paths x 32 waypoints x 10 000 samples per GPU  — the config the metric
+                "sample-points/s (batched paths)" is quoted on
+  c5          : 131 072 paths x 8 waypoints x 1024 samples per GPU
+  c2          : 1 path x 256 waypoints x 1 000 000 samples
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    "c3": dict(paths=4096, W=32, S=10000, seed=3, name="c3: 4096 paths x 32 waypoints x 10000 samples per GPU"),
+    "c5": dict(paths=131072, W=8, S=1024, seed=5, name="c5: 131072 paths x 8 waypoints x 1024 samples per GPU"),
+    "c2": dict(paths=1, W=256, S=1000000, seed=2, name="c2: 1 path x 256 waypoints x 1e6 samples"),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def cpu_baseline(wl, budget_s=12.0):
+    """The fp64 C restatement (oracle/, kind "port") on this box's host cores, bounded sample."""
+    from oracle import oracle
+    from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
+    cores = os.cpu_count() or 1
+    W, S = wl["W"], min(wl["S"], 100000)
+    wp = make_waypoints(max(2 * cores, 8), W, wl["seed"]).astype(np.float64)
+    t0 = time.perf_counter()
+    oracle.profile_batch(wp[:cores], S, DEFAULT_CONSTRAINTS, n_threads=cores, want=("velocity",))
+    t_cal = max(time.perf_counter() - t0, 1e-4)
+    n = int(min(4096, max(cores, cores * int(budget_s / t_cal))))
+    wp = make_waypoints(n, W, wl["seed"]).astype(np.float64)
+    t0 = time.perf_counter()
+    oracle.profile_batch(wp, S, DEFAULT_CONSTRAINTS, n_threads=cores, want=("velocity",))
+    dt = time.perf_counter() - t0
+    return {"value": n * S / dt, "unit": "sample-points/s", "cores": cores, "kind": "port",
+            "sample": f"{n} paths x {W} waypoints x {S} samples of the same generator, "
+                      f"{cores} threads, {dt:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--dtype", default="f32", choices=("f32", "f64"))
+    ap.add_argument("--paths-per-gpu", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from vexautonomousplanner_amd.batch import BatchedTrajectoryGenerator
+    from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    wl = dict(WORKLOADS[args.workload])
+    if args.paths_per_gpu:
+        wl["paths"] = args.paths_per_gpu
+    B, W, S = wl["paths"], wl["W"], wl["S"]
+    tdt = torch.float32 if args.dtype == "f32" else torch.float64
+
+    # rank 0 owns the constraints; everyone else receives them over RCCL (setup, untimed)
+    cons = torch.tensor(DEFAULT_CONSTRAINTS if rank == 0 else [0.0] * 6, dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.broadcast(cons, src=0)
+    constraints = [float(v) for v in cons.cpu()]
+    # shard r of the global batch: paths [r*B, (r+1)*B) of the seeded generator
+    wp_all = make_waypoints(B * world, W, wl["seed"], dtype=np.float32 if args.dtype == "f32" else np.float64)
+    wp = torch.tensor(wp_all[rank * B:(rank + 1) * B], dtype=tdt, device=dev)
+    del wp_all
+
+    gen = BatchedTrajectoryGenerator(local_rank, args.dtype)
+    out = None
+
+    def step():
+        nonlocal out
+        out = gen.profile(wp, constraints=constraints, samples=S, out=out)
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+
+    # per-kernel durations, HIP events on the library's stream (averaged over the same K steps)
+    gen.ctx.set_timing(True)
+    acc = {}
+    for _ in range(args.steps):
+        step()
+        for k, v in gen.timing().items():
+            acc[k] = acc.get(k, 0.0) + v / args.steps
+    gen.ctx.set_timing(False)
+
+    flags = int(out["flags"].abs().max().item())
+    # after the timed region: gather per-path summaries (length, samples) on every rank over RCCL
+    summ = out["meta"][:, [1, 3]].contiguous()
+    if world > 1:
+        gathered = [torch.empty_like(summ) for _ in range(world)]
+        dist.all_gather(gathered, summ)
+        summ = torch.cat(gathered)
+    total_len = float(summ[:, 0].sum().item())
+
+    if rank == 0:
+        points = B * S * world
+        esz = 4 if args.dtype == "f32" else 8
+        bytes_per_point = 5 * esz + (12 * esz * (W - 1)) / S   # 20 B + 48*G/S (fp32)
+        stage_bytes = {"sample": 4 * esz + (12 * esz * (W - 1)) / S, "velocity": esz,
+                       "fit": (12 * esz * (W - 1)) / S, "lut": 0.0}
+        dom = max(("fit", "lut", "sample", "velocity"), key=lambda k: acc.get(k, 0.0))
+        dom_ms = acc[dom]
+        achieved = stage_bytes[dom] * B * S / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        line = {
+            "metric": "trajectory sample-points/sec (batched paths)",
+            "value": points / elapsed * args.steps,
+            "unit": "sample-points/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": wl["name"], "paths_per_gpu": B, "waypoints": W, "samples": S,
+                       "global_paths": B * world, "parallelism": f"paths sharded x{world}, no data-path collective",
+                       "flags_or": flags, "sum_path_length_ft": total_len},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms": dom_ms, "algorithmic_bytes_per_point": stage_bytes[dom]},
+            "pipeline": {"bytes_per_point": bytes_per_point,
+                         "achieved_GBs": bytes_per_point * B * S / (acc["total"] * 1e-3) / 1e9,
+                         "frac_of_hbm_peak": bytes_per_point * B * S / (acc["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "stage_ms": {k: round(v, 4) for k, v in acc.items()}},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(wl)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

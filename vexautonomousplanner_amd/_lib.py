@@ -62,6 +62,10 @@ def lib():
         raise ImportError(
             f"{LIB_PATH} is missing: the HIP extension has not been built "
             "(run `make -C vexautonomousplanner_amd/csrc`).  This package has no CPU fallback.")
+    # PyTorch-ROCm bundles its own libamdhip64.so.7; load it FIRST so libvap.so binds to the same HIP
+    # runtime instance as the tensors it is handed (two runtimes in one process do not share
+    # devices or streams).  A plain C caller links libvap.so against /opt/rocm as usual.
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     L.vap_version.restype = C.c_int
     L.vap_status_string.restype = C.c_char_p
