@@ -80,6 +80,13 @@ int vap_ctx_destroy(vap_ctx *ctx);
  * context's own stream. */
 int vap_ctx_set_stream(vap_ctx *ctx, void *hip_stream);
 int vap_ctx_synchronize(vap_ctx *ctx);
+/* Tuning / test knobs.  VAP_OPT_VELOCITY_KERNEL selects the K5 implementation: AUTO (default) picks
+ * the register-resident relaxation kernel when the row fits and the sequential sweep otherwise;
+ * SEQ_LITERAL is the statement-by-statement form of MPG:188-311, SEQ_FAST the same sweep with the
+ * collapsed limits (bit-identical to RELAX). */
+enum { VAP_OPT_VELOCITY_KERNEL = 0 };
+enum { VAP_VELOCITY_AUTO = 0, VAP_VELOCITY_SEQ_LITERAL = 1, VAP_VELOCITY_SEQ_FAST = 2, VAP_VELOCITY_RELAX = 3 };
+int vap_ctx_set_option(vap_ctx *ctx, int option, int value);
 /* Enable/disable per-stage hipEvent timing (replaces the reference's time.time() log lines,
  * SM:587-594, MPG:398-411).  Off by default. */
 int vap_ctx_set_timing(vap_ctx *ctx, int enabled);

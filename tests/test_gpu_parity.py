@@ -117,3 +117,45 @@ def test_invalid_arguments(torch_mod, gens):
     wp = torch_mod.zeros((1, 4, 2), dtype=gen.tdtype, device=gen.device)
     with pytest.raises(ValueError):
         gen.profile(wp)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("B,W,S,seed", [(8, 32, 10000, 3), (33, 8, 1024, 5), (5, 5, 257, 10), (4, 32, 4097, 12),
+                                        (3, 2, 64, 9), (2, 16, 7001, 13)])
+def test_relaxation_is_bit_identical_to_sequential_sweep(torch_mod, B, W, S, seed, dtype):
+    """The speculative chunk relaxation (K5b) must reach exactly the fixed point the sequential
+    sweep (K5a, same step arithmetic) computes: compare bit patterns, not tolerances."""
+    from vexautonomousplanner_amd.batch import BatchedTrajectoryGenerator
+    from vexautonomousplanner_amd.synth import make_waypoints
+    if dtype == "f64" and S > 8192:
+        pytest.skip("fp64 relaxation kernel covers S <= 8192")
+    wp = make_waypoints(B, W, seed).astype(np.float64)
+    outs = {}
+    for which in ("relax", "seq_fast", "seq_literal"):
+        gen = BatchedTrajectoryGenerator(0, dtype, velocity_kernel=which)
+        r = run_gpu(torch_mod, gen, wp, samples=S)
+        assert np.all(r["flags"] == 0), which
+        outs[which] = r["velocity"]
+    assert np.array_equal(outs["relax"], outs["seq_fast"])
+    tol = 5e-6 if dtype == "f32" else 1e-9  # two fp32 roundings of the same recurrence
+    assert np.max(np.abs(outs["seq_fast"] - outs["seq_literal"]) / outs["seq_literal"]) <= tol
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-5), ("f64", 1e-9)])
+def test_relaxation_on_reference_grid_ragged_rows(torch_mod, dtype, tol):
+    """dd-mode (ragged n_samples per path) through the relaxation kernel, against the oracle."""
+    from oracle import oracle
+    from vexautonomousplanner_amd.batch import BatchedTrajectoryGenerator
+    from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
+    wp = make_waypoints(6, 8, 21).astype(np.float64)
+    gen = BatchedTrajectoryGenerator(0, dtype, velocity_kernel="relax")
+    r = run_gpu(torch_mod, gen, wp, dd=0.005, capacity=2048)
+    for b in range(len(wp)):
+        p = oracle.OraclePath(wp[b])
+        p.rebuild_tables()
+        ref = p.forward_backward(DEFAULT_CONSTRAINTS, 0.005)
+        N = len(ref["velocity"])
+        assert int(r["meta"][b, 3]) == N
+        got = {k: r[k][b][:N] for k in ("x", "y", "heading", "curvature", "velocity")}
+        check_fields(got, ref, tol, f"ragged path {b}/{dtype}")
+        assert np.all(r["velocity"][b][N:] == 0)

@@ -23,13 +23,16 @@ FLAG_DEGENERATE = 1
 FLAG_TRUNCATED = 2
 FLAG_NOCONVERGE = 4
 T_FIT, T_LUT, T_SAMPLE, T_VELOCITY, T_TOTAL, T_COUNT = 0, 1, 2, 3, 4, 8
+OPT_VELOCITY_KERNEL = 0
+VELOCITY_AUTO, VELOCITY_SEQ_LITERAL, VELOCITY_SEQ_FAST, VELOCITY_RELAX = 0, 1, 2, 3
 LUT_SAMPLES = 1000
 SAMPLES_PER_NODE = 1000
 
 # every symbol include/vap.h declares; tests check the library exports exactly these
 EXPORTS = (
     "vap_version", "vap_status_string", "vap_last_error", "vap_device_count", "vap_ctx_create",
-    "vap_ctx_destroy", "vap_ctx_set_stream", "vap_ctx_synchronize", "vap_ctx_set_timing",
+    "vap_ctx_destroy", "vap_ctx_set_stream", "vap_ctx_synchronize", "vap_ctx_set_option",
+    "vap_ctx_set_timing",
     "vap_last_timing", "vap_fit", "vap_build_lut", "vap_sample", "vap_velocity_pass",
     "vap_profile_batch", "vap_profile_batch_host", "vap_eval_host", "vap_lookup_host",
 )
@@ -77,6 +80,7 @@ def lib():
     L.vap_ctx_set_stream.argtypes = [vp, vp]
     L.vap_ctx_synchronize.argtypes = [vp]
     L.vap_ctx_set_timing.argtypes = [vp, C.c_int]
+    L.vap_ctx_set_option.argtypes = [vp, C.c_int, C.c_int]
     L.vap_last_timing.argtypes = [vp, C.POINTER(C.c_float)]
     L.vap_fit.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
     L.vap_build_lut.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp]
@@ -131,6 +135,9 @@ class Context:
 
     def synchronize(self):
         check(self._L.vap_ctx_synchronize(self.handle), "vap_ctx_synchronize")
+
+    def set_option(self, option, value):
+        check(self._L.vap_ctx_set_option(self.handle, int(option), int(value)), "vap_ctx_set_option")
 
     def set_timing(self, enabled=True):
         check(self._L.vap_ctx_set_timing(self.handle, int(bool(enabled))), "vap_ctx_set_timing")

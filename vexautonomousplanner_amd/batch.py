@@ -26,7 +26,7 @@ class BatchedTrajectoryGenerator:
     """rebuild_tables + forward_backward_pass (SM:582-594, MPG:70-316) for B independent
     plain-node paths per call, outputs resident in HBM as (B, S) tensors."""
 
-    def __init__(self, device=0, dtype="f32", timing=False):
+    def __init__(self, device=0, dtype="f32", timing=False, velocity_kernel="auto"):
         if not torch.cuda.is_available():
             raise RuntimeError("no HIP device visible: vexautonomousplanner_amd has no CPU path")
         self.device = torch.device("cuda", device)
@@ -35,6 +35,13 @@ class BatchedTrajectoryGenerator:
         if timing:
             self.ctx.set_timing(True)
         self._L = _lib.lib()
+        self.set_velocity_kernel(velocity_kernel)
+
+    def set_velocity_kernel(self, which):
+        """"auto" | "seq_literal" | "seq_fast" | "relax" (VAP_OPT_VELOCITY_KERNEL)."""
+        table = {"auto": _lib.VELOCITY_AUTO, "seq_literal": _lib.VELOCITY_SEQ_LITERAL,
+                 "seq_fast": _lib.VELOCITY_SEQ_FAST, "relax": _lib.VELOCITY_RELAX}
+        self.ctx.set_option(_lib.OPT_VELOCITY_KERNEL, table[which])
 
     def profile(self, waypoints, constraints=DEFAULT_CONSTRAINTS, samples=None, dd=None,
                 start_vel=START_VEL, end_vel=END_VEL, want=FIELDS, out=None, capacity=None):

@@ -48,6 +48,7 @@ struct vap_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     bool timing = false;
+    int velocity_kernel = 0;  // VAP_OPT_VELOCITY_KERNEL
     hipEvent_t ev[VAP_T_COUNT + 1] = {};
     float ms[VAP_T_COUNT] = {};
     // scratch arena (grow-only, reused across calls)
@@ -104,6 +105,25 @@ int check_shape(int B, int W, int S)
     if (W < 2) return fail(VAP_ERR_INVALID, "a path needs at least 2 waypoints (got %d)", W);  // SM:50-51
     if (W > vap::kMaxWaypoints) return fail(VAP_ERR_UNSUPPORTED, "W=%d exceeds %d", W, vap::kMaxWaypoints);
     if (S < 2) return fail(VAP_ERR_INVALID, "sample capacity must be >= 2 (got %d)", S);
+    return VAP_OK;
+}
+
+
+// K5 dispatch.  auto: register-resident relaxation whenever the row fits, else the sequential sweep.
+int run_velocity(vap_ctx *ctx, bool f64, int B, int S, const double cc[6], double sv, double ev, const double *meta,
+                 const void *curv, const void *dth, const void *vcap, void *vel, uint32_t *flags)
+{
+    int mode = ctx->velocity_kernel;
+    if (mode == VAP_VELOCITY_AUTO)
+        mode = (!vcap && S <= vap::velocity_relax_max_samples(f64)) ? VAP_VELOCITY_RELAX : VAP_VELOCITY_SEQ_FAST;
+    if (mode == VAP_VELOCITY_RELAX) {
+        if (vcap || S > vap::velocity_relax_max_samples(f64))
+            return fail(VAP_ERR_UNSUPPORTED, "relaxation kernel: S=%d too large or per-sample caps given", S);
+        HIP_TRY(vap::launch_velocity_relax(ctx->stream, f64, B, S, cc, sv, ev, meta, curv, dth, vel, flags));
+    } else {
+        HIP_TRY(vap::launch_velocity_seq(ctx->stream, f64, mode == VAP_VELOCITY_SEQ_FAST, B, S, cc, sv, ev, meta, curv,
+                                         dth, vcap, vel));
+    }
     return VAP_OK;
 }
 
@@ -194,6 +214,16 @@ int vap_ctx_synchronize(vap_ctx *ctx)
     return VAP_OK;
 }
 
+int vap_ctx_set_option(vap_ctx *ctx, int option, int value)
+{
+    if (!ctx) return fail(VAP_ERR_INVALID, "null context");
+    if (option == VAP_OPT_VELOCITY_KERNEL && value >= VAP_VELOCITY_AUTO && value <= VAP_VELOCITY_RELAX) {
+        ctx->velocity_kernel = value;
+        return VAP_OK;
+    }
+    return fail(VAP_ERR_INVALID, "unknown option %d / value %d", option, value);
+}
+
 int vap_ctx_set_timing(vap_ctx *ctx, int enabled)
 {
     if (!ctx) return fail(VAP_ERR_INVALID, "null context");
@@ -260,13 +290,12 @@ int vap_velocity_pass(vap_ctx *ctx, vap_dtype dt, int B, int S, const vap_constr
                       double end_vel, const double *d_meta, const void *d_curvature, const void *d_dtheta,
                       const void *d_vcap, void *d_velocity, uint32_t *d_flags)
 {
-    (void)d_flags;
     VAP_TRY(set_device(ctx));
     VAP_TRY(check_shape(B, 2, S));
     if (!c || !d_meta || !d_curvature || !d_dtheta || !d_velocity) return fail(VAP_ERR_INVALID, "null buffer");
     const double cc[6] = {c->max_vel, c->max_acc, c->max_dec, c->friction_coef, c->max_jerk, c->track_width};
-    HIP_TRY(vap::launch_velocity_seq(ctx->stream, dt == VAP_F64, B, S, cc, start_vel, end_vel, d_meta, d_curvature,
-                                     d_dtheta, d_vcap, d_velocity));
+    VAP_TRY(run_velocity(ctx, dt == VAP_F64, B, S, cc, start_vel, end_vel, d_meta, d_curvature, d_dtheta, d_vcap,
+                         d_velocity, d_flags));
     return VAP_OK;
 }
 
@@ -309,8 +338,8 @@ int vap_profile_batch(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd
     HIP_TRY(vap::launch_sample(ctx->stream, f64, B, W, S, (const double *)ctx->power.ptr,
                                (const double *)ctx->lut.ptr, meta, d_x, d_y, d_heading, curv, ctx->dth.ptr));
     tm.mark(VAP_T_SAMPLE);
-    HIP_TRY(vap::launch_velocity_seq(ctx->stream, f64, B, S, cc, start_vel, end_vel, meta, curv, ctx->dth.ptr,
-                                     nullptr, d_velocity));
+    VAP_TRY(run_velocity(ctx, f64, B, S, cc, start_vel, end_vel, meta, curv, ctx->dth.ptr, nullptr, d_velocity,
+                         flags));
     tm.mark(VAP_T_VELOCITY);
     return VAP_OK;
 }

@@ -276,4 +276,119 @@ __device__ __forceinline__ R backward_step(const VelConsts<R> &c, const SampleLi
     return pymin(pymin(nu, u_prev), L.cap_u);
 }
 
+// ------------------------------------------------------------------------------------------------
+// "Fast" form of the velocity-pass step (what the production kernels use).
+//
+// In real arithmetic the reference's limits collapse (MPG:210-224, 23-33):
+//   max_vel_kin = max_curve_vel = max_vel/(1+tw*k/2) =: vmax*r   and  max_vel_ang = 2vmax/(tw*k) > vmax*r
+//   max_accel_kin = max_acc*r                                    and  max_accel_ang = 2amax/(tw*k) > amax*r
+// with r = 1/(1 + tw*k/2), so   cap = (vmax*r)^2,  A = amax*r   (straight samples: A = amax exactly,
+// MPG:204-206).  All accelerations are pre-multiplied by 2*dd ("p" suffix) so a step is
+//   u' = min(u_init', cap, u + clamp(amaxp - |dw|*g, 0, Ap)).
+// Heading-difference zero (two samples on one table entry) makes the reference produce +-inf / NaN
+// (SURVEY §8(a) "Edge semantics"); g is clamped to kHuge so the same decisions fall out without
+// NaNs: forward  dw==0 -> A, dw!=0 -> 0;  backward  dw>0 -> 0, dw<=0 -> A.
+// ------------------------------------------------------------------------------------------------
+template <typename R> struct Huge;
+template <> struct Huge<float> { static constexpr float v = 1e30f; };
+template <> struct Huge<double> { static constexpr double v = 1e300; };
+
+template <typename R>
+struct FastConsts {
+    R vmax;
+    R amaxp;   // 2*dd*max_acc
+    R adecp;   // 2*dd*max_dec
+    R h;       // track_width/2
+    R gk;      // 2*dd*track_width/4
+};
+
+template <typename R>
+__device__ __forceinline__ FastConsts<R> make_fast(const VelConsts<R> &c, R twodd)
+{
+    FastConsts<R> f;
+    f.vmax = c.vmax;
+    f.amaxp = twodd * c.amax;
+    f.adecp = twodd * c.adec;
+    f.h = c.tw / (R)2;
+    f.gk = twodd * c.tw / (R)4;
+    return f;
+}
+
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ double fast_rcp(double x) { return 1.0 / x; }
+__device__ __forceinline__ float vmin(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ double vmin(double a, double b) { return fmin(a, b); }
+__device__ __forceinline__ float vmax_(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ double vmax_(double a, double b) { return fmax(a, b); }
+__device__ __forceinline__ float clamp0(float x, float hi) { return __builtin_amdgcn_fmed3f(x, 0.0f, hi); }
+__device__ __forceinline__ double clamp0(double x, double hi) { return fmin(fmax(x, 0.0), hi); }
+
+// Per-sample step coefficients from (|curvature|, |dtheta|):
+//   q = k^2,  g = 2dd*tw/(4*dtheta) (0 on straight samples, clamped to kHuge),
+//   A = base_p * r,  cap = (vmax*r)^2  with r = 1/(1 + tw*k/2)  (straight samples: A = base_p).
+template <typename R>
+__device__ __forceinline__ void fast_derive(const FastConsts<R> &c, R kabs, R dth, R base_p, R &q, R &g, R &A, R &cap)
+{
+    q = kabs * kabs;
+    const bool straight = kabs < (R)1e-6;
+    const R r = fast_rcp((R)1 + c.h * kabs);
+    const R vr = c.vmax * r;
+    cap = vr * vr;
+    A = straight ? base_p : base_p * r;
+    const R gg = vmin(c.gk * fast_rcp(dth), Huge<R>::v);
+    g = straight ? (R)0 : gg;
+}
+
+// Coefficients of a slot that holds no step (past the end of the path, or the fixed end sample in
+// the backward sweep): q = 0 zeroes the angular-velocity memory and the huge limits let the step
+// return min(u + amaxp, u_init) = u_init with wprev = 0 — i.e. walking through it restarts the chain.
+template <typename R>
+__device__ __forceinline__ void idle_coef(R &q, R &g, R &A, R &cap)
+{
+    q = (R)0;
+    g = (R)0;
+    A = Huge<R>::v;
+    cap = Huge<R>::v;
+}
+
+// Hides a value from loop-invariant code motion.
+__device__ __forceinline__ float opaque(float x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ double opaque(double x) { asm volatile("" : "+v"(x)); return x; }
+
+__device__ __forceinline__ float med3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
+__device__ __forceinline__ double med3(double a, double lo, double hi) { return fmin(fmax(a, lo), hi); }
+
+// Forward step, MPG:193-249:  u' = min(cap, u_init, clamp(u + amaxp - |d|*g, u, u + A)),
+// d = u*q - wprev.  DUP = the path has samples sharing a table entry (g == kHuge): d must then be
+// formed from the rounded product so that "angular velocity unchanged" is an exact zero (the
+// reference's 0/0 -> NaN -> skipped case); otherwise one fma takes an operation off the chain.
+template <bool DUP, typename R>
+__device__ __forceinline__ R fast_forward(const FastConsts<R> &c, R q, R g, R A, R cap, R u, R &wprev, R u_next)
+{
+    const R w = u * q;
+    const R d = DUP ? w - wprev : fma(u, q, -wprev);
+    const R x = fma(-fabs(d), g, u + c.amaxp);
+    wprev = w;
+    return vmin(vmin(med3(x, u, u + A), cap), u_next);
+}
+
+// Backward step, MPG:255-311.  DUP = the path has samples sharing a table entry (g == kHuge): the
+// reference's signed +-inf handling then differs from the forward one (dw > 0 -> 0, dw <= 0 -> A).
+template <bool DUP, typename R>
+__device__ __forceinline__ R fast_backward(const FastConsts<R> &c, R q, R g, R A, R cap, R u, R &wprev, R u_prev)
+{
+    const R w = u * q;
+    const R d = DUP ? w - wprev : fma(u, q, -wprev);
+    R x;
+    if constexpr (DUP) {
+        g = opaque(g);   // keep the select below inside the round loop (one register per sample otherwise)
+        const R gn = g >= Huge<R>::v ? (R)0 : g;
+        x = (u + c.amaxp) - vmax_(d * g, -d * gn);
+    } else {
+        x = fma(-fabs(d), g, u + c.amaxp);
+    }
+    wprev = w;
+    return vmin(vmin(med3(x, u, u + A), cap), u_prev);
+}
+
 }  // namespace vap

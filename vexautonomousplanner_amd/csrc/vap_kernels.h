@@ -20,10 +20,13 @@ hipError_t launch_lut(hipStream_t st, int B, int W, const double *seg, double *l
 hipError_t launch_grid(hipStream_t st, int B, int S, double dd, double *meta, uint32_t *flags);
 hipError_t launch_sample(hipStream_t st, bool f64, int B, int W, int S, const double *pw, const double *lut,
                          const double *meta, void *x, void *y, void *h, void *k, void *dth);
-hipError_t launch_velocity_seq(hipStream_t st, bool f64, int B, int S, const double c[6], double sv, double ev,
-                               const double *meta, const void *curv, const void *dth, const void *vcap,
+hipError_t launch_velocity_seq(hipStream_t st, bool f64, bool fast, int B, int S, const double c[6], double sv,
+                               double ev, const double *meta, const void *curv, const void *dth, const void *vcap,
                                void *vel);
-
+int velocity_relax_max_samples(bool f64);
+hipError_t launch_velocity_relax(hipStream_t st, bool f64, int B, int S, const double c[6], double sv, double ev,
+                                 const double *meta, const void *curv, const void *dth, void *vel,
+                                 uint32_t *flags);
 hipError_t launch_power(hipStream_t st, int n_seg, const double *seg, double *pw);
 hipError_t launch_eval(hipStream_t st, int W, const double *seg, double t_max, int order, int n, const double *t,
                        double *out);

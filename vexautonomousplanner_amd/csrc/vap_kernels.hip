@@ -11,6 +11,11 @@
 #include "vap_device.h"
 #include "vap_kernels.h"
 
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+#include <vector>
+
 namespace vap {
 
 // ------------------------------------------------------------------------------------------------
@@ -314,11 +319,12 @@ __global__ __launch_bounds__(kSampleThreads) void k_sample(int W, int S, const d
 }
 
 // ------------------------------------------------------------------------------------------------
-// K5 (v0): forward/backward velocity pass, one lane per path, strictly sequential — the exact
-// statement of MPG:188-311 in squared-velocity space.  Used as the in-library reference for the
-// relaxation kernel and for batches with very many short paths.
+// K5a: forward/backward velocity pass, one lane per path, strictly sequential — MPG:188-311 in
+// squared-velocity space.  FAST = false is the literal statement (every min/max of the reference);
+// FAST = true uses the collapsed limits of vap_device.h and is bit-identical to the relaxation
+// kernel below, which makes it the in-library check of that kernel.
 // ------------------------------------------------------------------------------------------------
-template <typename R>
+template <typename R, bool FAST>
 __global__ __launch_bounds__(64) void k_velocity_seq(int B, int S, VelConsts<R> c, R start_u, R end_u,
                                                      const double *__restrict__ meta,
                                                      const R *__restrict__ curv, const R *__restrict__ dtheta,
@@ -333,26 +339,351 @@ __global__ __launch_bounds__(64) void k_velocity_seq(int B, int S, VelConsts<R> 
     const R *K = curv + row, *DT = dtheta + row;
     R *V = vel + row;
     const R vmax2 = c.vmax * c.vmax;
+    const FastConsts<R> fc = make_fast(c, twodd);
+    // same per-path decision as the relaxation kernel: does any step have a clamped (huge) g?
+    bool dup = false;
+    if constexpr (FAST) {
+        for (int i = 0; i < N - 1; i++) {
+            R q, g, A, cap;
+            fast_derive(fc, (R)fabs(K[i]), DT[i], fc.amaxp, q, g, A, cap);
+            dup |= g >= Huge<R>::v;
+        }
+    }
     // forward, MPG:188-249
     R u = start_u, wprev = (R)0;
     V[0] = u;
     for (int i = 0; i < N - 1; i++) {
-        const SampleLimits<R> L = sample_limits(c, (R)fabs(K[i]), c.amax, c.adec);
-        R un = (i + 1 == N - 1) ? end_u : (vcap ? vcap[row + i + 1] * vcap[row + i + 1] : vmax2);
-        u = forward_step(c, L, c.amax, twodd, u, wprev, DT[i], un);
+        const R un = (i + 1 == N - 1) ? end_u : (vcap ? vcap[row + i + 1] * vcap[row + i + 1] : vmax2);
+        if constexpr (FAST) {
+            R q, g, A, cap;
+            fast_derive(fc, (R)fabs(K[i]), DT[i], fc.amaxp, q, g, A, cap);
+            u = dup ? fast_forward<true>(fc, q, g, A, cap, u, wprev, un)
+                    : fast_forward<false>(fc, q, g, A, cap, u, wprev, un);
+        } else {
+            const SampleLimits<R> L = sample_limits(c, (R)fabs(K[i]), c.amax, c.adec);
+            u = forward_step(c, L, c.amax, twodd, u, wprev, DT[i], un);
+        }
         V[i + 1] = u;
     }
     // backward, MPG:251-311
     u = end_u;
     wprev = (R)0;
     for (int i = N - 1; i > 0; i--) {
-        const SampleLimits<R> L = sample_limits(c, (R)fabs(K[i]), c.amax, c.adec);
-        const R up = backward_step(c, L, c.amax, twodd, u, wprev, DT[i - 1], V[i - 1]);
+        R up;
+        if constexpr (FAST) {
+            R q, g, A, cap;
+            fast_derive(fc, (R)fabs(K[i]), DT[i - 1], fc.adecp, q, g, A, cap);
+            up = dup ? fast_backward<true>(fc, q, g, A, cap, u, wprev, V[i - 1])
+                     : fast_backward<false>(fc, q, g, A, cap, u, wprev, V[i - 1]);
+        } else {
+            const SampleLimits<R> L = sample_limits(c, (R)fabs(K[i]), c.amax, c.adec);
+            up = backward_step(c, L, c.amax, twodd, u, wprev, DT[i - 1], V[i - 1]);
+        }
         V[i] = sqrt(u);
         u = up;
     }
     V[0] = sqrt(u);
     for (int i = N; i < S; i++) V[i] = (R)0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5b: velocity pass by speculative chunk relaxation.  One workgroup per path; thread c owns the L
+// consecutive samples [c*L, c*L+L) and keeps their step coefficients and squared velocities in
+// registers.  The recurrence is sequential only through the 2-word state (u_i, w_{i-1}) that
+// crosses a chunk boundary, so every round each thread whose incoming state changed re-runs its L
+// steps from that state and publishes its outgoing state; a thread whose incoming state is
+// bit-identical to the one it last used is already final.  Chunk 0's incoming state is exact, so by
+// induction chunk c is exact after at most c+1 rounds, and the fixed point (no state changed) is
+// bit-identical to the sequential sweep — in practice the velocity rides its curvature cap often
+// enough that ~10-100 rounds suffice for 10^4 samples.
+// LDS: two words per thread for the boundary states.  No HBM traffic besides one read of
+// (curvature, dtheta) per sweep direction and the final velocity store.
+// ------------------------------------------------------------------------------------------------
+template <typename R> struct BitsOf;
+template <> struct BitsOf<float> { using type = uint32_t; };
+template <> struct BitsOf<double> { using type = uint64_t; };
+template <typename R>
+__device__ __forceinline__ bool same_bits(R a, R b)
+{
+    using U = typename BitsOf<R>::type;
+    return __builtin_bit_cast(U, a) == __builtin_bit_cast(U, b);
+}
+
+// Cooperative, fully coalesced copy of one row (n elements) between HBM and the padded LDS stage:
+// element i lives at stage[i + i / L], so thread c's chunk [c*L, c*L+L) is read with lane stride
+// L+1 words (odd => no bank conflicts) while HBM sees 16 bytes per lane.
+template <typename R, int L>
+__device__ __forceinline__ int stage_pos(int i) { return i + i / L; }
+
+template <typename R, int L>
+__device__ __forceinline__ void stage_load(R *__restrict__ stage, const R *__restrict__ src, int n, int cap_n,
+                                           bool aligned, int tid, int T)
+{
+    constexpr int V = 16 / sizeof(R);
+    constexpr int ITER = (L + V - 1) / V + 1;   // covers cap_n <= T*L + 1 elements
+    if (aligned) {
+        using VT = typename std::conditional<sizeof(R) == 4, float4, double2>::type;
+        const VT *src4 = reinterpret_cast<const VT *>(src);
+        VT v[ITER];
+        // all loads first (independent, so the memory latency is paid once), then the LDS writes
+#pragma unroll
+        for (int it = 0; it < ITER; it++) {
+            const int i = tid + it * T;
+            if ((i + 1) * V <= n) v[it] = src4[i];
+        }
+#pragma unroll
+        for (int it = 0; it < ITER; it++) {
+            const int i = tid + it * T;
+            const R *e = reinterpret_cast<const R *>(&v[it]);
+#pragma unroll
+            for (int k = 0; k < V; k++) {
+                const int idx = i * V + k;
+                if (idx < cap_n) stage[stage_pos<R, L>(idx)] = (i + 1) * V <= n ? e[k] : (idx < n ? src[idx] : (R)0);
+            }
+        }
+    } else {
+        R v[L + 1];
+#pragma unroll
+        for (int it = 0; it < L + 1; it++) {
+            const int i = tid + it * T;
+            v[it] = i < n ? src[i] : (R)0;
+        }
+#pragma unroll
+        for (int it = 0; it < L + 1; it++) {
+            const int i = tid + it * T;
+            if (i < cap_n) stage[stage_pos<R, L>(i)] = v[it];
+        }
+    }
+}
+
+template <typename R, int L, int MAXT, int MINW>
+__global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<R> c, R start_u, R end_u,
+                                                               const double *__restrict__ meta,
+                                                               const R *__restrict__ curv,
+                                                               const R *__restrict__ dtheta,
+                                                               R *__restrict__ vel, uint32_t *__restrict__ flags,
+                                                               long long *__restrict__ stats)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    R *stage = reinterpret_cast<R *>(smem_raw);   // (T*L + T + 2) elements
+    // boundary states, double-buffered by round parity so one barrier per round suffices
+    __shared__ R s_u[2][MAXT + 2], s_w[2][MAXT + 2];
+    __shared__ int s_any[3];   // "some chunk's incoming state changed" per round, rotating slots
+    __shared__ int s_dup;
+    const long long t_start = stats ? __builtin_amdgcn_s_memtime() : 0;
+    const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+    const double *m = meta + (size_t)b * kMetaStride;
+    const R twodd = (R)2 * (R)m[2];
+    const int N = (int)m[3];
+    const size_t row = (size_t)b * S;
+    const R *K = curv + row, *DT = dtheta + row;
+    const FastConsts<R> fc = make_fast(c, twodd);
+    const int lo = tid * L;
+    const int TL = T * L;
+    const bool aligned = (S % (16 / (int)sizeof(R))) == 0;
+    R q[L], g[L], A[L], cp[L], u[L];
+    if (tid == 0) { s_any[0] = 0; s_any[1] = 0; s_any[2] = 0; s_dup = 0; }
+
+    // ---------------- forward sweep: the step (j-1 -> j) into owned sample j uses k[j-1], dth[j-1]
+    stage_load<R, L>(stage, K, N < TL ? N : TL, TL, aligned, tid, T);
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < L; s++) {
+        const int j = lo + s;
+        const bool valid = j >= 1 && j <= N - 1;
+        const R kabs = (R)fabs(stage[stage_pos<R, L>(valid ? j - 1 : 0)]);
+        R gdummy;
+        fast_derive(fc, kabs, (R)1, fc.amaxp, q[s], gdummy, A[s], cp[s]);
+        if (!valid) idle_coef(q[s], gdummy, A[s], cp[s]);
+        u[s] = start_u;
+    }
+    __syncthreads();
+    stage_load<R, L>(stage, DT, N < TL ? N : TL, TL, aligned, tid, T);
+    __syncthreads();
+    bool dup = false;
+#pragma unroll
+    for (int s = 0; s < L; s++) {
+        const int j = lo + s;
+        const bool valid = j >= 1 && j <= N - 1;
+        const R dth = stage[stage_pos<R, L>(valid ? j - 1 : 0)];
+        const R gg = vmin(fc.gk * fast_rcp(dth), Huge<R>::v);
+        g[s] = (valid && q[s] >= (R)1e-12) ? gg : (R)0;   // q = k^2: straight <=> k < 1e-6
+        dup |= g[s] >= Huge<R>::v;
+    }
+    R in_u, in_w;
+    if (tid == 0) { in_u = start_u; in_w = (R)0; }
+    else { in_u = cp[0]; in_w = in_u * q[0]; }
+    const bool fwd_active = lo <= N - 1;       // the chunk holds at least one real sample
+    bool need = fwd_active;
+    R out_u = in_u, out_w = in_w;
+    int rounds = 0;
+    if (dup) s_dup = 1;
+    __syncthreads();
+    const bool any_dup = s_dup != 0;
+    const long long t_fwd0 = stats ? __builtin_amdgcn_s_memtime() : 0;
+    // Round r: evaluate if the incoming state changed; publish (always) into buffer r&1; barrier;
+    // pick up the neighbour's state; raise s_any[r%3] if it differs.  s_any[r%3] is read after the
+    // NEXT barrier (round r+1), so termination lags one cheap round and needs no second barrier.
+    while (true) {
+        if (need) {
+            R uu = in_u, wp = in_w;
+            if (any_dup) {
+#pragma unroll
+                for (int s = 0; s < L; s++) {
+                    if (s == 0 && tid == 0) continue;   // sample 0 is the given start velocity (MPG:189)
+                    uu = fast_forward<true>(fc, q[s], g[s], A[s], cp[s], uu, wp, Huge<R>::v);
+                    u[s] = uu;
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < L; s++) {
+                    if (s == 0 && tid == 0) continue;
+                    uu = fast_forward<false>(fc, q[s], g[s], A[s], cp[s], uu, wp, Huge<R>::v);
+                    u[s] = uu;
+                }
+            }
+            out_u = uu;
+            out_w = wp;
+        }
+        const int pb = rounds & 1;
+        s_u[pb][tid + 1] = out_u;
+        s_w[pb][tid + 1] = out_w;
+        if (tid == 0) s_any[(rounds + 1) % 3] = 0;
+        __syncthreads();
+        if (rounds > 0 && s_any[(rounds - 1) % 3] == 0) break;   // nobody changed last round
+        need = false;
+        if (tid > 0 && fwd_active) {
+            const R nu = s_u[pb][tid], nw = s_w[pb][tid];
+            need = !(same_bits(nu, in_u) && same_bits(nw, in_w));
+            in_u = nu;
+            in_w = nw;
+        }
+        if (need) s_any[rounds % 3] = 1;
+        rounds++;
+        if (rounds > T + 3) {
+            if (tid == 0 && flags) atomicOr(&flags[b], VAP_FLAG_NOCONVERGE_BIT);
+            break;
+        }
+    }
+    const int fwd_rounds = rounds;
+    const long long t_fwd1 = stats ? __builtin_amdgcn_s_memtime() : 0;
+
+    // ---------------- backward sweep: the step (j+1 -> j) into owned sample j uses k[j+1], dth[j]
+    // Slots at or past the fixed end sample N-1 are idle slots holding u = end_u: walking through
+    // them restarts the chain exactly as MPG:252-253 does.  (The stage still holds dtheta.)
+#pragma unroll
+    for (int s = 0; s < L; s++) {
+        const int j = lo + s;
+        const bool valid = j <= N - 2;
+        const R dth = stage[stage_pos<R, L>(valid ? j : 0)];
+        g[s] = vmin(fc.gk * fast_rcp(dth), Huge<R>::v);
+    }
+    __syncthreads();
+    stage_load<R, L>(stage, K, N < TL + 1 ? N : TL + 1, TL + 1, aligned, tid, T);
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < L; s++) {
+        const int j = lo + s;
+        const bool valid = j <= N - 2;
+        const R kabs = (R)fabs(stage[stage_pos<R, L>(valid ? j + 1 : 0)]);
+        R gdummy;
+        fast_derive(fc, kabs, (R)1, fc.adecp, q[s], gdummy, A[s], cp[s]);
+        if (q[s] < (R)1e-12) g[s] = (R)0;
+        if (!valid) { idle_coef(q[s], g[s], A[s], cp[s]); u[s] = end_u; }
+    }
+    const int last_chunk = (N - 1) / L;     // chunk that owns the fixed end sample
+    if (tid >= last_chunk) { in_u = end_u; in_w = (R)0; }
+    else { in_u = u[L - 1]; in_w = in_u * q[L - 1]; }
+    // The backward step reads the forward value of the sample it overwrites, so a chunk cannot be
+    // re-run in place: the rounds only propagate boundary states (u[] stays the forward result) and
+    // one commit evaluation with the final incoming state stores the backward velocities.
+    const bool bwd_active = tid <= last_chunk;
+    need = bwd_active;
+    out_u = in_u;
+    out_w = in_w;
+    rounds = 0;
+    if (tid == 0) { s_any[0] = 0; s_any[1] = 0; s_any[2] = 0; }
+    __syncthreads();
+    while (true) {
+        if (need) {
+            R uu = in_u, wp = in_w;
+            if (any_dup) {
+#pragma unroll
+                for (int s = L - 1; s >= 0; s--) uu = fast_backward<true>(fc, q[s], g[s], A[s], cp[s], uu, wp, u[s]);
+            } else {
+#pragma unroll
+                for (int s = L - 1; s >= 0; s--) uu = fast_backward<false>(fc, q[s], g[s], A[s], cp[s], uu, wp, u[s]);
+            }
+            out_u = uu;
+            out_w = wp;
+        }
+        const int pb = rounds & 1;
+        s_u[pb][tid] = out_u;
+        s_w[pb][tid] = out_w;
+        if (tid == 0) s_any[(rounds + 1) % 3] = 0;
+        __syncthreads();
+        if (rounds > 0 && s_any[(rounds - 1) % 3] == 0) break;
+        need = false;
+        if (tid < last_chunk) {
+            const R nu = s_u[pb][tid + 1], nw = s_w[pb][tid + 1];
+            need = !(same_bits(nu, in_u) && same_bits(nw, in_w));
+            in_u = nu;
+            in_w = nw;
+        }
+        if (need) s_any[rounds % 3] = 1;
+        rounds++;
+        if (rounds > T + 3) {
+            if (tid == 0 && flags) atomicOr(&flags[b], VAP_FLAG_NOCONVERGE_BIT);
+            break;
+        }
+    }
+    const long long t_bwd1 = stats ? __builtin_amdgcn_s_memtime() : 0;
+    if (bwd_active) {
+        R uu = in_u, wp = in_w;
+#pragma unroll
+        for (int s = L - 1; s >= 0; s--) {
+            uu = any_dup ? fast_backward<true>(fc, q[s], g[s], A[s], cp[s], uu, wp, u[s])
+                         : fast_backward<false>(fc, q[s], g[s], A[s], cp[s], uu, wp, u[s]);
+            u[s] = uu;
+        }
+    }
+    // velocities leave through the stage so the row is written with 16 bytes per lane
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < L; s++) {
+        const int j = lo + s;
+        stage[stage_pos<R, L>(j)] = j < N ? sqrt(u[s]) : (R)0;
+    }
+    __syncthreads();
+    R *V = vel + row;
+    {
+        constexpr int VW = 16 / sizeof(R);
+        const int n = S < TL ? S : TL;
+        if (aligned) {
+            using VT = typename std::conditional<sizeof(R) == 4, float4, double2>::type;
+            VT *dst = reinterpret_cast<VT *>(V);
+            for (int i = tid; i < n / VW; i += T) {
+                VT v;
+                R *e = reinterpret_cast<R *>(&v);
+#pragma unroll
+                for (int k = 0; k < VW; k++) e[k] = stage[stage_pos<R, L>(i * VW + k)];
+                dst[i] = v;
+            }
+            for (int i = (n / VW) * VW + tid; i < n; i += T) V[i] = stage[stage_pos<R, L>(i)];
+        } else {
+            for (int i = tid; i < n; i += T) V[i] = stage[stage_pos<R, L>(i)];
+        }
+    }
+    for (int j = TL + tid; j < S; j += T) V[j] = (R)0;
+    if (stats && tid == 0) {
+        long long *st = stats + (size_t)b * 8;
+        st[0] = fwd_rounds;
+        st[1] = rounds;
+        st[2] = t_fwd0 - t_start;                       // load + derive
+        st[3] = t_fwd1 - t_fwd0;                        // forward rounds
+        st[4] = t_bwd1 - t_fwd1;                        // backward derive + rounds
+        st[5] = __builtin_amdgcn_s_memtime() - t_bwd1;  // commit + store
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -472,21 +803,78 @@ static VelConsts<R> make_consts(const double c[6])
     return v;
 }
 
-hipError_t launch_velocity_seq(hipStream_t st, bool f64, int B, int S, const double c[6], double sv, double ev,
-                               const double *meta, const void *curv, const void *dth, const void *vcap,
+hipError_t launch_velocity_seq(hipStream_t st, bool f64, bool fast, int B, int S, const double c[6], double sv,
+                               double ev, const double *meta, const void *curv, const void *dth, const void *vcap,
                                void *vel)
 {
     const dim3 grid((B + 63) / 64);
     if (f64) {
-        hipLaunchKernelGGL(k_velocity_seq<double>, grid, dim3(64), 0, st, B, S, make_consts<double>(c), sv * sv,
-                           ev * ev, meta, (const double *)curv, (const double *)dth, (const double *)vcap,
-                           (double *)vel);
+        auto k = fast ? k_velocity_seq<double, true> : k_velocity_seq<double, false>;
+        hipLaunchKernelGGL(k, grid, dim3(64), 0, st, B, S, make_consts<double>(c), sv * sv, ev * ev, meta,
+                           (const double *)curv, (const double *)dth, (const double *)vcap, (double *)vel);
     } else {
         const float svf = (float)sv, evf = (float)ev;
-        hipLaunchKernelGGL(k_velocity_seq<float>, grid, dim3(64), 0, st, B, S, make_consts<float>(c), svf * svf,
-                           evf * evf, meta, (const float *)curv, (const float *)dth, (const float *)vcap,
-                           (float *)vel);
+        auto k = fast ? k_velocity_seq<float, true> : k_velocity_seq<float, false>;
+        hipLaunchKernelGGL(k, grid, dim3(64), 0, st, B, S, make_consts<float>(c), svf * svf, evf * evf, meta,
+                           (const float *)curv, (const float *)dth, (const float *)vcap, (float *)vel);
     }
+    return hipGetLastError();
+}
+
+// Largest sample capacity the register-resident relaxation kernel covers.
+int velocity_relax_max_samples(bool f64) { return f64 ? 512 * 16 : 512 * 40; }
+
+template <typename R, int L, int MAXT, int MINW>
+static void launch_relax_t(hipStream_t st, int B, int S, const double c[6], double sv, double ev,
+                           const double *meta, const void *curv, const void *dth, void *vel, uint32_t *flags)
+{
+    int T = (S + L - 1) / L;
+    T = (T + 63) / 64 * 64;
+    const R s = (R)sv, e = (R)ev;
+    // developer knob: VAP_RELAX_STATS=1 prints rounds and in-kernel cycle shares (synchronises!)
+    static const bool want_stats = getenv("VAP_RELAX_STATS") != nullptr;
+    long long *stats = nullptr;
+    if (want_stats) (void)hipMalloc(&stats, (size_t)B * 8 * sizeof(long long));
+    const size_t lds = sizeof(R) * ((size_t)T * L + T + 8);
+    hipLaunchKernelGGL((k_velocity_relax<R, L, MAXT, MINW>), dim3(B), dim3(T), lds, st, S, make_consts<R>(c), s * s,
+                       e * e, meta, (const R *)curv, (const R *)dth, (R *)vel, flags, stats);
+    if (stats) {
+        std::vector<long long> h((size_t)B * 8);
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(h.data(), stats, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+        (void)hipFree(stats);
+        double sum[6] = {0, 0, 0, 0, 0, 0};
+        long long mx[6] = {0, 0, 0, 0, 0, 0};
+        for (int b = 0; b < B; b++)
+            for (int k = 0; k < 6; k++) {
+                sum[k] += (double)h[(size_t)b * 8 + k];
+                if (h[(size_t)b * 8 + k] > mx[k]) mx[k] = h[(size_t)b * 8 + k];
+            }
+        fprintf(stderr, "[relax L=%d T=%d] rounds fwd mean %.1f max %lld | bwd mean %.1f max %lld | ticks mean: load %.0f fwd %.0f bwd %.0f commit %.0f | max: %lld %lld %lld %lld\n",
+                L, T, sum[0] / B, mx[0], sum[1] / B, mx[1], sum[2] / B, sum[3] / B, sum[4] / B, sum[5] / B, mx[2], mx[3], mx[4], mx[5]);
+    }
+}
+
+hipError_t launch_velocity_relax(hipStream_t st, bool f64, int B, int S, const double c[6], double sv, double ev,
+                                 const double *meta, const void *curv, const void *dth, void *vel,
+                                 uint32_t *flags)
+{
+#define VAP_RELAX(R_, L_, MAXT_, W_) launch_relax_t<R_, L_, MAXT_, W_>(st, B, S, c, sv, ev, meta, curv, dth, vel, flags)
+    if (f64) {
+        if (S <= 256 * 4) VAP_RELAX(double, 4, 256, 4);
+        else VAP_RELAX(double, 16, 512, 2);
+        return hipGetLastError();
+    }
+    // developer knob (tuning only): VAP_RELAX_CFG=<L>, one of the instantiated chunk lengths
+    static const char *cfg = getenv("VAP_RELAX_CFG");
+    int L = cfg ? atoi(cfg) : 0;
+    if (L == 0) L = S <= 256 * 4 ? 4 : (S <= 256 * 16 ? 16 : 40);
+    if (L == 4 && S <= 1024 * 4) VAP_RELAX(float, 4, 1024, 8);
+    else if (L == 10 && S <= 1024 * 10) VAP_RELAX(float, 10, 1024, 4);
+    else if (L == 16 && S <= 512 * 16) VAP_RELAX(float, 16, 512, 4);
+    else if (L == 20 && S <= 512 * 20) VAP_RELAX(float, 20, 512, 4);
+    else VAP_RELAX(float, 40, 512, 2);
+#undef VAP_RELAX
     return hipGetLastError();
 }
 
