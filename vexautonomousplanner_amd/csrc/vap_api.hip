@@ -52,7 +52,7 @@ struct vap_ctx {
     hipEvent_t ev[VAP_T_COUNT + 1] = {};
     float ms[VAP_T_COUNT] = {};
     // scratch arena (grow-only, reused across calls)
-    Buffer seg, power, lut, meta, dth, flags, io[8], small_in, small_out, small_seg, small_lut;
+    Buffer seg, power, lut, slopes, aux, meta, dth, flags, io[8], small_in, small_out, small_seg, small_lut;
 
     int ensure(Buffer &b, size_t bytes)
     {
@@ -187,7 +187,7 @@ int vap_ctx_destroy(vap_ctx *ctx)
     if (!ctx) return VAP_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    Buffer *bufs[] = {&ctx->seg, &ctx->power, &ctx->lut, &ctx->meta, &ctx->dth, &ctx->flags, &ctx->small_in,
+    Buffer *bufs[] = {&ctx->seg, &ctx->power, &ctx->lut, &ctx->slopes, &ctx->aux, &ctx->meta, &ctx->dth, &ctx->flags, &ctx->small_in,
                       &ctx->small_out, &ctx->small_seg, &ctx->small_lut};
     for (Buffer *b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
@@ -266,7 +266,7 @@ int vap_build_lut(vap_ctx *ctx, int B, int W, const double *d_segments, double *
     VAP_TRY(set_device(ctx));
     VAP_TRY(check_shape(B, W, 2));
     if (!d_segments || !d_lut || !d_meta) return fail(VAP_ERR_INVALID, "null buffer");
-    HIP_TRY(vap::launch_lut(ctx->stream, B, W, d_segments, d_lut, d_meta, d_flags));
+    HIP_TRY(vap::launch_lut(ctx->stream, B, W, d_segments, d_lut, nullptr, d_meta, d_flags));
     return VAP_OK;
 }
 
@@ -278,11 +278,15 @@ int vap_sample(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd, const
     VAP_TRY(check_shape(B, W, S));
     if (!d_segments || !d_lut || !d_meta) return fail(VAP_ERR_INVALID, "null buffer");
     const size_t n_seg = (size_t)B * (W - 1);
-    VAP_TRY(ctx->ensure(ctx->power, n_seg * 12 * sizeof(double)));
+    VAP_TRY(ctx->ensure(ctx->power, n_seg * 30 * sizeof(double)));
+    VAP_TRY(ctx->ensure(ctx->slopes, (size_t)B * VAP_LUT_SAMPLES * sizeof(double)));
+    VAP_TRY(ctx->ensure(ctx->aux, (size_t)B * 4 * sizeof(double)));
     HIP_TRY(vap::launch_power(ctx->stream, (int)n_seg, d_segments, (double *)ctx->power.ptr));
-    HIP_TRY(vap::launch_grid(ctx->stream, B, S, dd, d_meta, d_flags));
-    HIP_TRY(vap::launch_sample(ctx->stream, dt == VAP_F64, B, W, S, (const double *)ctx->power.ptr, d_lut, d_meta,
-                               d_x, d_y, d_heading, d_curvature, d_dtheta));
+    HIP_TRY(vap::launch_lut_slopes(ctx->stream, B, d_lut, d_meta, (double *)ctx->slopes.ptr));
+    HIP_TRY(vap::launch_grid(ctx->stream, B, W, S, dd, d_meta, (double *)ctx->aux.ptr, d_flags));
+    HIP_TRY(vap::launch_sample(ctx->stream, dt == VAP_F64, B, W, S, (const double *)ctx->power.ptr, d_lut,
+                               (const double *)ctx->slopes.ptr, d_meta, (const double *)ctx->aux.ptr, d_x, d_y,
+                               d_heading, d_curvature, d_dtheta));
     return VAP_OK;
 }
 
@@ -309,8 +313,10 @@ int vap_profile_batch(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd
     const bool f64 = dt == VAP_F64;
     const size_t n_seg = (size_t)B * (W - 1), n_pts = (size_t)B * S;
     VAP_TRY(ctx->ensure(ctx->seg, n_seg * 12 * sizeof(double)));
-    VAP_TRY(ctx->ensure(ctx->power, n_seg * 12 * sizeof(double)));
+    VAP_TRY(ctx->ensure(ctx->power, n_seg * 30 * sizeof(double)));
     VAP_TRY(ctx->ensure(ctx->lut, (size_t)B * VAP_LUT_SAMPLES * sizeof(double)));
+    VAP_TRY(ctx->ensure(ctx->slopes, (size_t)B * VAP_LUT_SAMPLES * sizeof(double)));
+    VAP_TRY(ctx->ensure(ctx->aux, (size_t)B * 4 * sizeof(double)));
     VAP_TRY(ctx->ensure(ctx->dth, n_pts * esz(dt)));
     double *meta = d_meta;
     if (!meta) {
@@ -332,11 +338,13 @@ int vap_profile_batch(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd
     HIP_TRY(vap::launch_fit(ctx->stream, f64, B, W, d_waypoints, nullptr, nullptr, (double *)ctx->seg.ptr,
                             (double *)ctx->power.ptr, meta, flags));
     tm.mark(VAP_T_FIT);
-    HIP_TRY(vap::launch_lut(ctx->stream, B, W, (const double *)ctx->seg.ptr, (double *)ctx->lut.ptr, meta, flags));
-    HIP_TRY(vap::launch_grid(ctx->stream, B, S, dd, meta, flags));
+    HIP_TRY(vap::launch_lut(ctx->stream, B, W, (const double *)ctx->seg.ptr, (double *)ctx->lut.ptr,
+                            (double *)ctx->slopes.ptr, meta, flags));
+    HIP_TRY(vap::launch_grid(ctx->stream, B, W, S, dd, meta, (double *)ctx->aux.ptr, flags));
     tm.mark(VAP_T_LUT);
     HIP_TRY(vap::launch_sample(ctx->stream, f64, B, W, S, (const double *)ctx->power.ptr,
-                               (const double *)ctx->lut.ptr, meta, d_x, d_y, d_heading, curv, ctx->dth.ptr));
+                               (const double *)ctx->lut.ptr, (const double *)ctx->slopes.ptr, meta,
+                               (const double *)ctx->aux.ptr, d_x, d_y, d_heading, curv, ctx->dth.ptr));
     tm.mark(VAP_T_SAMPLE);
     VAP_TRY(run_velocity(ctx, f64, B, S, cc, start_vel, end_vel, meta, curv, ctx->dth.ptr, nullptr, d_velocity,
                          flags));

@@ -14,8 +14,10 @@ namespace vap {
 constexpr int kLutN = 1000;        // SM:427
 constexpr int kSamplesPerNode = 1000;  // SM:477
 
-// meta[b][4] = {param_last, total_length, dd, n_samples}
+// meta[b][4] = {param_last, total_length, dd, n_samples}             (public, include/vap.h)
 constexpr int kMetaStride = 4;
+// aux[b][4]  = {lut_step, table_step, 1/table_step, spare}              (internal scratch)
+constexpr int kAuxStride = 4;
 
 // np.linspace(0, stop, num)[j] (numpy/_core/function_base.py): j*step, endpoint forced to stop.
 __device__ __forceinline__ double linspace_at(double stop, int num, int j)
@@ -120,6 +122,36 @@ __device__ __forceinline__ void hermite_to_power(double r0, double r1, double r2
     c[5] = 6 * d - 3 * r2 - 3 * r3 - 0.5 * r4 + 0.5 * r5;
 }
 
+// Per-segment coefficient block used by the sampling kernel (fp64, kCoefDoubles values):
+//   [0..5] x: c0..c5   [6..11] y: c0..c5            P   = sum c_j t^j
+//   [12..16] x: j*c_j (j=1..5)   [17..21] y          P'
+//   [22..25] x: j(j-1)*c_j (j=2..5)   [26..29] y     P''
+constexpr int kCoefDoubles = 30;
+__device__ __forceinline__ void make_coef_block(const double r[12], double *__restrict__ o)
+{
+    double cx[6], cy[6];
+    hermite_to_power(r[0], r[2], r[4], r[6], r[8], r[10], cx);
+    hermite_to_power(r[1], r[3], r[5], r[7], r[9], r[11], cy);
+#pragma unroll
+    for (int k = 0; k < 6; k++) { o[k] = cx[k]; o[6 + k] = cy[k]; }
+#pragma unroll
+    for (int k = 1; k < 6; k++) { o[12 + k - 1] = (double)k * cx[k]; o[17 + k - 1] = (double)k * cy[k]; }
+#pragma unroll
+    for (int k = 2; k < 6; k++) { o[22 + k - 2] = (double)(k * (k - 1)) * cx[k]; o[26 + k - 2] = (double)(k * (k - 1)) * cy[k]; }
+}
+__device__ __forceinline__ double horner5(const double *__restrict__ c, double t)   // c[0..5]
+{
+    return fma(fma(fma(fma(fma(c[5], t, c[4]), t, c[3]), t, c[2]), t, c[1]), t, c[0]);
+}
+__device__ __forceinline__ double horner4(const double *__restrict__ c, double t)   // c[0..4]
+{
+    return fma(fma(fma(fma(c[4], t, c[3]), t, c[2]), t, c[1]), t, c[0]);
+}
+__device__ __forceinline__ double horner3(const double *__restrict__ c, double t)   // c[0..3]
+{
+    return fma(fma(fma(c[3], t, c[2]), t, c[1]), t, c[0]);
+}
+
 // P, P', P'' of one coordinate from monomial coefficients (Horner, explicit FMA).
 __device__ __forceinline__ double poly_p(const double *__restrict__ c, double t)
 {
@@ -176,6 +208,55 @@ __device__ __forceinline__ int table_index(double t, int tab_n, double end_param
     if (j == 0) return 0;
     const double frac = t - floor(t);  // t % 1 for t >= 0
     return (int)(frac > 0.5 ? j - 1 : j);
+}
+
+// Fast form of the same index: with x = t * (1/step), ceil(x) is the searchsorted-left position
+// unless x sits within 1e-8 of an integer (x is within ~1e-9 of t/step and of the NumPy-rounded
+// table parameters), and the "t % 1 > 0.5" decision is safe unless t is within 1e-11 of an integer
+// or of a segment midpoint.  In those rare cases `near` is set and the caller takes the exact path
+// (reference rounding of t, table_index above), so the selected entry always equals the reference's.
+__device__ __forceinline__ int table_index_fast(double t, int tab_n, double inv_step, bool &near)
+{
+    const double x = t * inv_step;
+    const double cx = ceil(x);
+    int j = (int)cx;
+    j = j > tab_n - 1 ? tab_n - 1 : j;
+    const double dxi = cx - x;                 // in [0,1): distance (in entries) up to the chosen entry
+    const double frac = t - floor(t);          // t % 1 for t >= 0
+    const double fh = fabs(frac - 0.5);
+    near = dxi < 1e-8 || dxi > 1.0 - 1e-8 || fh < 1e-11 || fh > 0.5 - 1e-11;
+    return (j > 0 && frac > 0.5) ? j - 1 : j;
+}
+
+// QHS:506-541 for parameters already inside [0, len(nodes)-1]: segment = min(int(t), G-1).  (When
+// parameters[-1] rounds one ulp below G the reference's clamp moves the end sample's local parameter
+// from 1 to 1-2^-53; that is the only difference.)
+__device__ __forceinline__ void normalize_inside(double t, int G, double &lt, int &idx)
+{
+    int i = (int)t;
+    i = i > G - 1 ? G - 1 : i;
+    lt = t - (double)i;
+    idx = i;
+}
+
+// atan2 for fp32 headings: octant reduction + the classic degree-4 (in z^2) minimax for |z| <= tan(pi/8),
+// branch-free; absolute error ~1.5e-7, relative error ~2e-7 for small angles (what |dtheta| needs).
+__device__ __forceinline__ float atan2_f32(float y, float x)
+{
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    float a = mn * __builtin_amdgcn_rcpf(mx);
+    a = mx == 0.0f ? 0.0f : a;
+    const bool big = a > 0.41421356237f;
+    const float z = big ? (a - 1.0f) * __builtin_amdgcn_rcpf(a + 1.0f) : a;
+    const float z2 = z * z;
+    const float p = fmaf(fmaf(fmaf(8.05374449538e-2f, z2, -1.38776856032e-1f), z2, 1.99777106478e-1f), z2,
+                         -3.33329491539e-1f);
+    float r = fmaf(p * z2, z, z);
+    r = big ? r + 0.78539816339744831f : r;
+    r = ay > ax ? 1.57079632679489662f - r : r;
+    r = x < 0.0f ? 3.14159265358979324f - r : r;
+    return copysignf(r, y);
 }
 
 // Python's min(a, b): keeps a unless b < a (a NaN in b is skipped).

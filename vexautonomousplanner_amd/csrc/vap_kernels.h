@@ -10,16 +10,21 @@ constexpr uint32_t VAP_FLAG_TRUNCATED_BIT = 2u;
 constexpr uint32_t VAP_FLAG_NOCONVERGE_BIT = 4u;
 
 constexpr int kSampleThreads = 256;
-constexpr int kSampleTile = kSampleThreads - 1;  // last thread only feeds its left neighbour
+constexpr int kSPT = 4;                                   // consecutive samples per thread (one 16-byte store)
+constexpr int kSampleChunk = kSampleThreads * kSPT;       // samples evaluated per workgroup
+constexpr int kSampleTile = kSampleChunk - kSPT;          // samples written: the last thread only feeds its neighbour
+constexpr int kLdsCoefSegments = 136;                     // segments whose coefficient blocks are staged in LDS
 constexpr int kMaxWaypoints = 2048;              // k_fit LDS: 7*W doubles
 
 hipError_t launch_fit(hipStream_t st, bool f64, int B, int W, const void *wp, const double *tin,
                       const double *tout, double *seg, double *pw, double *meta, uint32_t *flags);
-hipError_t launch_lut(hipStream_t st, int B, int W, const double *seg, double *lut, double *meta,
+hipError_t launch_lut(hipStream_t st, int B, int W, const double *seg, double *lut, double *slopes, double *meta,
                       uint32_t *flags);
-hipError_t launch_grid(hipStream_t st, int B, int S, double dd, double *meta, uint32_t *flags);
+hipError_t launch_lut_slopes(hipStream_t st, int B, const double *lut, const double *meta, double *slopes);
+hipError_t launch_grid(hipStream_t st, int B, int W, int S, double dd, double *meta, double *aux, uint32_t *flags);
 hipError_t launch_sample(hipStream_t st, bool f64, int B, int W, int S, const double *pw, const double *lut,
-                         const double *meta, void *x, void *y, void *h, void *k, void *dth);
+                         const double *slopes, const double *meta, const double *aux, void *x, void *y, void *h,
+                         void *k, void *dth);
 hipError_t launch_velocity_seq(hipStream_t st, bool f64, bool fast, int B, int S, const double c[6], double sv,
                                double ev, const double *meta, const void *curv, const void *dth, const void *vcap,
                                void *vel);

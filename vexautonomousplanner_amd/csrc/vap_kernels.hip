@@ -3,7 +3,7 @@
 // Stage map: K1 fit -> K2 arc-length LUT -> K3+K4 sample -> K5 velocity pass.
 // Data layout in HBM (B paths, W waypoints, G = W-1 segments, S sample capacity):
 //   segments [B][G][6][2] fp64   reference row order (QHS:120-122)
-//   power    [B][G][2][6] fp64   monomial coefficients c0..c5 of x then y (scratch)
+//   power    [B][G][30]   fp64   monomial coefficients of P, P', P'' (x then y each; scratch)
 //   lut      [B][1000]    fp64   cumulative trapezoid distances (SM:448-454)
 //   meta     [B][4]       fp64   {param_last, total_length, dd, n_samples}
 //   x,y,heading,curvature,dtheta,velocity [B][S]  fp32 or fp64, sample-major per path so that a
@@ -117,14 +117,7 @@ __global__ __launch_bounds__(256) void k_fit(int W, const IT *__restrict__ waypo
         double *sg = segments + ((size_t)b * G + i) * 12;
 #pragma unroll
         for (int k = 0; k < 12; k++) sg[k] = r[k];
-        if (power) {
-            double cx[6], cy[6];
-            hermite_to_power(r[0], r[2], r[4], r[6], r[8], r[10], cx);
-            hermite_to_power(r[1], r[3], r[5], r[7], r[9], r[11], cy);
-            double *pw = power + ((size_t)b * G + i) * 12;
-#pragma unroll
-            for (int k = 0; k < 6; k++) { pw[k] = cx[k]; pw[6 + k] = cy[k]; }
-        }
+        if (power) make_coef_block(r, power + ((size_t)b * G + i) * kCoefDoubles);
     }
     __syncthreads();
     if (tid == 0 && flags) flags[b] = s_flag;
@@ -136,8 +129,8 @@ __global__ __launch_bounds__(256) void k_fit(int W, const IT *__restrict__ waypo
 // SEQUENTIAL cumulative sum (np.cumsum order) so the table is bit-identical to the reference's.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_lut(int W, const double *__restrict__ segments,
-                                             double *__restrict__ lut, double *__restrict__ meta,
-                                             uint32_t *__restrict__ flags)
+                                             double *__restrict__ lut, double *__restrict__ slopes,
+                                             double *__restrict__ meta, uint32_t *__restrict__ flags)
 {
     __shared__ double mag[kLutN];
     __shared__ double cum[kLutN];
@@ -159,22 +152,64 @@ __global__ __launch_bounds__(256) void k_lut(int W, const double *__restrict__ s
         const double dt = linspace_at(t_max, kLutN, 1) - linspace_at(t_max, kLutN, 0);  // SM:444
         double acc = 0.0;
         cum[0] = 0.0 + 0.0;
-        for (int j = 1; j < kLutN; j++) {
-            acc += (mag[j - 1] + mag[j]) * 0.5 * dt;  // SM:452-454
-            cum[j] = acc + 0.0;                        // + current_dist (single spline), SM:457
+        // np.cumsum order is strictly left to right; read the magnitudes 8 at a time so only the adds
+        // are on the dependent chain, not the LDS latency
+        double prev = mag[0];
+        for (int j0 = 1; j0 < kLutN; j0 += 8) {
+            double mv[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) mv[k] = (j0 + k < kLutN) ? mag[j0 + k] : 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (j0 + k < kLutN) {
+                    acc += (prev + mv[k]) * 0.5 * dt;  // SM:452-454
+                    cum[j0 + k] = acc + 0.0;           // + current_dist (single spline), SM:457
+                    prev = mv[k];
+                }
+            }
         }
         const double total = cum[kLutN - 1];
         meta[(size_t)b * kMetaStride + 1] = total;
         if (flags && !(total > 0.0 && isfinite(total))) atomicOr(&flags[b], VAP_FLAG_DEGENERATE_BIT);
     }
     __syncthreads();
-    for (int j = tid; j < kLutN; j += nt) lut[(size_t)b * kLutN + j] = cum[j];
+    const double lstep = t_max / (double)(kLutN - 1);
+    for (int j = tid; j < kLutN; j += nt) {
+        lut[(size_t)b * kLutN + j] = cum[j];
+        if (slopes) {
+            // (t1 - t0)/(d1 - d0) of SM:311-317 for the interval ending at entry j
+            double w = 0.0;
+            if (j > 0) {
+                const double t0 = (double)(j - 1) * lstep, t1 = (j == kLutN - 1) ? t_max : (double)j * lstep;
+                w = (t1 - t0) / (cum[j] - cum[j - 1]);
+            }
+            slopes[(size_t)b * kLutN + j] = w;
+        }
+    }
+}
+
+// Slopes for a distance table that came in through the staged API.
+__global__ void k_lut_slopes(int B, const double *__restrict__ lut, const double *__restrict__ meta,
+                             double *__restrict__ slopes)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * kLutN) return;
+    const int b = i / kLutN, j = i % kLutN;
+    const double t_max = meta[(size_t)b * kMetaStride + 0];
+    const double lstep = t_max / (double)(kLutN - 1);
+    double w = 0.0;
+    if (j > 0) {
+        const double t0 = (double)(j - 1) * lstep, t1 = (j == kLutN - 1) ? t_max : (double)j * lstep;
+        w = (t1 - t0) / (lut[i] - lut[i - 1]);
+    }
+    slopes[i] = w;
 }
 
 // ------------------------------------------------------------------------------------------------
 // Grid definition: one thread per path.  MPG:112-122 sample count, or this build's fixed-S grid.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_grid(int B, int S, double dd_in, double *__restrict__ meta, uint32_t *__restrict__ flags)
+__global__ void k_grid(int B, int W, int S, double dd_in, double *__restrict__ meta, double *__restrict__ aux,
+                       uint32_t *__restrict__ flags)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -199,32 +234,53 @@ __global__ void k_grid(int B, int S, double dd_in, double *__restrict__ meta, ui
     }
     meta[(size_t)b * kMetaStride + 2] = dd;
     meta[(size_t)b * kMetaStride + 3] = n;
+    const double t_max = meta[(size_t)b * kMetaStride + 0];
+    const double tstep = (double)(W - 1) / (double)(W * kSamplesPerNode - 1);  // np.linspace step, SM:487
+    aux[(size_t)b * kAuxStride + 0] = t_max / (double)(kLutN - 1);             // SM:443
+    aux[(size_t)b * kAuxStride + 1] = tstep;
+    aux[(size_t)b * kAuxStride + 2] = 1.0 / tstep;
+    aux[(size_t)b * kAuxStride + 3] = 0.0;
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3+K4: sampling.  grid = (tiles, B); a tile is kSampleTile consecutive samples of one path.
-//   thread i evaluates sample k0+i (the last thread's sample is the next tile's first one: it only
-//   supplies the neighbour needed for |dtheta|).
-// LDS: the path's distance table (8 KB) + per-sample derivative/table index for the neighbour
-// exchange.  Coefficients are read from HBM/L2: a wavefront's 64 consecutive samples touch one or
-// two 96-byte segment blocks, so those loads are broadcasts.
+// K3+K4: sampling.  grid = (tiles, B); a workgroup evaluates kSampleChunk consecutive samples of one
+// path, each thread kSPT consecutive ones (so every output leaves as one 16-byte store per lane and
+// the arc-length table is walked, not searched, after the thread's first sample).  The last thread's
+// samples belong to the next tile: they only supply the neighbour for |dtheta|.
+// LDS: distance table + interval slopes (16 KB), the path's coefficient blocks when they fit
+// (G <= kLdsCoefSegments; otherwise they are read through L1/L2, where a wavefront's consecutive
+// samples hit one or two blocks), and a 256-entry neighbour exchange.
+// Arithmetic: parameter/index path, derivative evaluation and curvature in fp64 (DESIGN.md
+// §Numerics); no fp64 division on the per-sample path.
 // ------------------------------------------------------------------------------------------------
 template <typename OT>
 __device__ __forceinline__ OT heading_of(double dy, double dx);
 template <>
-__device__ __forceinline__ float heading_of<float>(double dy, double dx) { return atan2f((float)dy, (float)dx); }
+__device__ __forceinline__ float heading_of<float>(double dy, double dx) { return atan2_f32((float)dy, (float)dx); }
 template <>
 __device__ __forceinline__ double heading_of<double>(double dy, double dx) { return atan2(dy, dx); }
 
-template <typename OT>
+// 1/sqrt(x)^3 * num without fp64 sqrt/div: hardware estimate + two Newton steps (~1e-16 relative)
+__device__ __forceinline__ double curvature_of(double num, double ss)
+{
+    double r = __builtin_amdgcn_rsq(ss);
+    r = r * fma(-0.5 * ss * r, r, 1.5);
+    r = r * fma(-0.5 * ss * r, r, 1.5);
+    return num * r * r * r;
+}
+
+template <typename OT, bool COEF_LDS>
 __global__ __launch_bounds__(kSampleThreads) void k_sample(int W, int S, const double *__restrict__ power,
                                                            const double *__restrict__ lut,
+                                                           const double *__restrict__ slopes,
                                                            const double *__restrict__ meta,
+                                                           const double *__restrict__ aux,
                                                            OT *__restrict__ ox, OT *__restrict__ oy,
                                                            OT *__restrict__ oh, OT *__restrict__ ok,
                                                            OT *__restrict__ odth)
 {
-    __shared__ double sD[kLutN];
+    extern __shared__ __attribute__((aligned(16))) double s_coef[];   // G * kCoefDoubles when COEF_LDS
+    __shared__ double sD[kLutN], sWt[kLutN];
     __shared__ double s_dx[kSampleThreads], s_dy[kSampleThreads];
     __shared__ int s_j[kSampleThreads];
     __shared__ OT s_th[kSampleThreads];
@@ -233,88 +289,136 @@ __global__ __launch_bounds__(kSampleThreads) void k_sample(int W, int S, const d
     const double *m = meta + (size_t)b * kMetaStride;
     const double t_max = m[0], total = m[1], dd = m[2];
     const int N = (int)m[3];
+    const double *ax = aux + (size_t)b * kAuxStride;
+    const double lstep = ax[0], tstep = ax[1], inv_tstep = ax[2];
     const int k0 = blockIdx.x * kSampleTile;
     if (k0 >= S) return;
     const size_t row = (size_t)b * S;
+    const int kbase = k0 + tid * kSPT;
+    const bool writer = tid < kSampleThreads - 1;
+    constexpr int VW = 16 / sizeof(OT);   // elements per 16-byte store
+    const bool aligned = (S % VW) == 0;   // rows (and k0, a multiple of kSPT) then start 16-byte aligned
+
+    auto store_vec = [&](OT *dst, const OT v[kSPT]) {
+        if (!dst || !writer) return;
+        if (aligned && kbase + kSPT <= S) {
+            if constexpr (sizeof(OT) == 4) {
+                *reinterpret_cast<float4 *>(dst + row + kbase) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                *reinterpret_cast<double2 *>(dst + row + kbase) = make_double2(v[0], v[1]);
+                *reinterpret_cast<double2 *>(dst + row + kbase + 2) = make_double2(v[2], v[3]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < kSPT; i++)
+                if (kbase + i < S) dst[row + kbase + i] = v[i];
+        }
+    };
+
     if (k0 >= N) {
         // past this path's grid (ragged dd mode): zero-fill so every output element is defined
-        const int k = k0 + tid;
-        if (tid < kSampleTile && k < S) {
-            if (ox) ox[row + k] = (OT)0;
-            if (oy) oy[row + k] = (OT)0;
-            if (oh) oh[row + k] = (OT)0;
-            if (ok) ok[row + k] = (OT)0;
-            if (odth) odth[row + k] = (OT)0;
-        }
+        const OT z[kSPT] = {(OT)0, (OT)0, (OT)0, (OT)0};
+        store_vec(ox, z); store_vec(oy, z); store_vec(oh, z); store_vec(ok, z); store_vec(odth, z);
         return;
     }
-    for (int j = tid; j < kLutN; j += kSampleThreads) sD[j] = lut[(size_t)b * kLutN + j];
+    for (int j = tid; j < kLutN; j += kSampleThreads) {
+        sD[j] = lut[(size_t)b * kLutN + j];
+        sWt[j] = slopes[(size_t)b * kLutN + j];
+    }
+    const double *pw = power + (size_t)b * G * kCoefDoubles;
+    if constexpr (COEF_LDS) {
+        for (int j = tid; j < G * kCoefDoubles; j += kSampleThreads) s_coef[j] = pw[j];
+    }
     __syncthreads();
+    const double *coef = COEF_LDS ? s_coef : pw;
 
-    const int k = k0 + tid;
     const double end_param = (double)(W - 1);
     const int tab_n = W * kSamplesPerNode;
-    const double *pw = power + (size_t)b * G * 12;
-    OT th = (OT)0, kap = (OT)0, px = (OT)0, py = (OT)0;
-    double d1x = 0.0, d1y = 0.0;
-    int jj = -1;
-    if (k < N) {
+    OT vx[kSPT], vy[kSPT], vh[kSPT], vk[kSPT], vd[kSPT];
+    double d1x[kSPT], d1y[kSPT];
+    int jjv[kSPT];
+    int idx = 0;
+#pragma unroll
+    for (int i = 0; i < kSPT; i++) {
+        // samples past the end of the grid (last tile only) are evaluated at the end sample and
+        // blanked on store: the body stays straight-line
+        const int k = kbase + i < N - 1 ? kbase + i : N - 1;
         // MPG:112-122 distance grid; the reference accumulates s += dd, we form k*dd
         const double s = (k == N - 1) ? total : (double)k * dd;
-        const double t = distance_to_time(sD, total, t_max, end_param, s);
-        // SM:340-346 / 550-580: table entry selected by the step lookup, evaluated on demand
-        jj = table_index(t, tab_n, end_param);
-        const double tp = linspace_at(end_param, tab_n, jj);
+        // SM:291-318 distance_to_time.  s = 0 lands on entry 1 with t = 0 exactly; s = total is the
+        // reference's early return of len(nodes)-1.
+        if (i == 0) idx = lut_search_left(sD, s);
+        else while (idx < kLutN - 1 && sD[idx] < s) idx++;
+        idx = idx < 1 ? 1 : idx;
+        const double d0 = sD[idx - 1];
+        const double t0 = (double)(idx - 1) * lstep;
+        const bool exact = s <= 0.0 || s >= total;      // the reference's early returns: t is exact
+        double t = fma(sWt[idx], s - d0, t0);
+        t = s >= total ? end_param : t;
+        // SM:340-346 / 550-580: the table entry the reference's step lookup selects
+        bool near;
+        int jj = table_index_fast(t, tab_n, inv_tstep, near);
+        if (near && !exact) {   // a few ulps from a decision point: redo with the reference's own rounding
+            const double t1 = (idx == kLutN - 1) ? t_max : (double)idx * lstep;
+            t = t0 + (t1 - t0) * (s - d0) / (sD[idx] - d0);
+            jj = table_index(t, tab_n, end_param);
+        }
+        const double tp = (jj == tab_n - 1) ? end_param : (double)jj * tstep;
         double lt;
         int sg;
-        normalize_parameter(tp, t_max, G, lt, sg);
-        const double *cx = pw + (size_t)sg * 12, *cy = cx + 6;
-        d1x = poly_d1(cx, lt);
-        d1y = poly_d1(cy, lt);
-        const double d2x = poly_d2(cx, lt), d2y = poly_d2(cy, lt);
-        const double ss = d1x * d1x + d1y * d1y;                       // SM:517
-        const double num = d1x * d2y - d1y * d2x;                      // SM:523
-        const double kd = (ss >= 1e-10) ? num / (ss * sqrt(ss)) : 0.0;  // SM:526-527
-        kap = (OT)kd;
-        th = heading_of<OT>(d1y, d1x);                                 // SM:536
+        normalize_inside(tp, G, lt, sg);
+        const double *c = coef + sg * kCoefDoubles;
+        const double ex = horner4(c + 12, lt), ey = horner4(c + 17, lt);     // P'
+        const double fx = horner3(c + 22, lt), fy = horner3(c + 26, lt);     // P''
+        const double ss = fma(ex, ex, ey * ey);                               // SM:517
+        const double num = fma(ex, fy, -(ey * fx));                           // SM:523
+        vk[i] = (OT)((ss >= 1e-10) ? curvature_of(num, ss) : 0.0);            // SM:526-527
+        vh[i] = heading_of<OT>(ey, ex);                                       // SM:536
+        d1x[i] = ex;
+        d1y[i] = ey;
+        jjv[i] = jj;
         // SM:204-215 get_point_at_parameter(t) at the sample's own parameter
-        normalize_parameter(t, t_max, G, lt, sg);
-        cx = pw + (size_t)sg * 12;
-        cy = cx + 6;
-        px = (OT)poly_p(cx, lt);
-        py = (OT)poly_p(cy, lt);
+        normalize_inside(t, G, lt, sg);
+        c = coef + sg * kCoefDoubles;
+        vx[i] = (OT)horner5(c, lt);
+        vy[i] = (OT)horner5(c + 6, lt);
+        vd[i] = (OT)0;
     }
-    s_dx[tid] = d1x;
-    s_dy[tid] = d1y;
-    s_j[tid] = jj;
-    s_th[tid] = th;
+    s_dx[tid] = d1x[0];
+    s_dy[tid] = d1y[0];
+    s_j[tid] = jjv[0];
+    s_th[tid] = vh[0];
     __syncthreads();
-    if (tid < kSampleTile && k < S) {
-        OT dth = (OT)0;
-        if (k < N - 1) {
-            // |heading[k+1] - heading[k]| of the reference's raw (un-unwrapped) atan2 values
-            if constexpr (sizeof(OT) == 8) {
-                dth = fabs(s_th[tid + 1] - th);
-            } else {
-                if (s_j[tid + 1] != jj) {
-                    // small-angle accurate: angle between the two fp64 derivative vectors, then the
-                    // 2*pi multiple that the raw difference of the two atan2 values carries
-                    const double nx = s_dx[tid + 1], ny = s_dy[tid + 1];
-                    const float cr = (float)(d1x * ny - d1y * nx);
-                    const float dt = (float)(d1x * nx + d1y * ny);
-                    const float dl = atan2f(cr, dt);
-                    const float raw = s_th[tid + 1] - th;
-                    const float n = rintf((raw - dl) * 0.15915494309189535f);
-                    dth = fabsf(fmaf(n, 6.283185307179586f, dl));
+    if (writer) {
+        // |heading[k+1] - heading[k]| of the reference's raw (un-unwrapped) atan2 values
+#pragma unroll
+        for (int i = 0; i < kSPT; i++) {
+            const int k = kbase + i;
+            if (k < N - 1) {
+                const double nx = (i + 1 < kSPT) ? d1x[(i + 1) % kSPT] : s_dx[tid + 1];
+                const double ny = (i + 1 < kSPT) ? d1y[(i + 1) % kSPT] : s_dy[tid + 1];
+                const int nj = (i + 1 < kSPT) ? jjv[(i + 1) % kSPT] : s_j[tid + 1];
+                const OT nth = (i + 1 < kSPT) ? vh[(i + 1) % kSPT] : s_th[tid + 1];
+                if constexpr (sizeof(OT) == 8) {
+                    vd[i] = fabs(nth - vh[i]);
+                } else {
+                    if (nj != jjv[i]) {
+                        // small-angle accurate: angle between the two fp64 derivative vectors, then
+                        // the 2*pi multiple that the raw difference of the two atan2 values carries
+                        const float cr = (float)fma(d1x[i], ny, -(d1y[i] * nx));
+                        const float dt = (float)fma(d1x[i], nx, d1y[i] * ny);
+                        const float dl = atan2_f32(cr, dt);
+                        const float raw = nth - vh[i];
+                        const float n = rintf((raw - dl) * 0.15915494309189535f);
+                        vd[i] = fabsf(fmaf(n, 6.283185307179586f, dl));
+                    }
                 }
             }
         }
-        if (k >= N) { px = py = th = kap = (OT)0; }
-        if (ox) ox[row + k] = px;
-        if (oy) oy[row + k] = py;
-        if (oh) oh[row + k] = th;
-        if (ok) ok[row + k] = kap;
-        if (odth) odth[row + k] = dth;
+#pragma unroll
+        for (int i = 0; i < kSPT; i++)
+            if (kbase + i >= N) vx[i] = vy[i] = vh[i] = vk[i] = vd[i] = (OT)0;
+        store_vec(ox, vx); store_vec(oy, vy); store_vec(oh, vh); store_vec(ok, vk); store_vec(odth, vd);
     }
 }
 
@@ -693,13 +797,10 @@ __global__ void k_power(int n_seg, const double *__restrict__ segments, double *
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_seg) return;
-    const double *r = segments + (size_t)i * 12;
-    double cx[6], cy[6];
-    hermite_to_power(r[0], r[2], r[4], r[6], r[8], r[10], cx);
-    hermite_to_power(r[1], r[3], r[5], r[7], r[9], r[11], cy);
-    double *pw = power + (size_t)i * 12;
+    double r[12];
 #pragma unroll
-    for (int k = 0; k < 6; k++) { pw[k] = cx[k]; pw[6 + k] = cy[k]; }
+    for (int k = 0; k < 12; k++) r[k] = segments[(size_t)i * 12 + k];
+    make_coef_block(r, power + (size_t)i * kCoefDoubles);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -764,29 +865,38 @@ hipError_t launch_fit(hipStream_t st, bool f64, int B, int W, const void *wp, co
                : launch_fit_t<float>(st, B, W, wp, tin, tout, seg, pw, meta, flags);
 }
 
-hipError_t launch_lut(hipStream_t st, int B, int W, const double *seg, double *lut, double *meta,
+hipError_t launch_lut(hipStream_t st, int B, int W, const double *seg, double *lut, double *slopes, double *meta,
                       uint32_t *flags)
 {
-    hipLaunchKernelGGL(k_lut, dim3(B), dim3(256), 0, st, W, seg, lut, meta, flags);
+    hipLaunchKernelGGL(k_lut, dim3(B), dim3(256), 0, st, W, seg, lut, slopes, meta, flags);
     return hipGetLastError();
 }
 
-hipError_t launch_grid(hipStream_t st, int B, int S, double dd, double *meta, uint32_t *flags)
+hipError_t launch_lut_slopes(hipStream_t st, int B, const double *lut, const double *meta, double *slopes)
 {
-    hipLaunchKernelGGL(k_grid, dim3((B + 255) / 256), dim3(256), 0, st, B, S, dd, meta, flags);
+    hipLaunchKernelGGL(k_lut_slopes, dim3((B * kLutN + 255) / 256), dim3(256), 0, st, B, lut, meta, slopes);
+    return hipGetLastError();
+}
+
+hipError_t launch_grid(hipStream_t st, int B, int W, int S, double dd, double *meta, double *aux, uint32_t *flags)
+{
+    hipLaunchKernelGGL(k_grid, dim3((B + 255) / 256), dim3(256), 0, st, B, W, S, dd, meta, aux, flags);
     return hipGetLastError();
 }
 
 hipError_t launch_sample(hipStream_t st, bool f64, int B, int W, int S, const double *pw, const double *lut,
-                         const double *meta, void *x, void *y, void *h, void *k, void *dth)
+                         const double *slopes, const double *meta, const double *aux, void *x, void *y, void *h,
+                         void *k, void *dth)
 {
     const dim3 grid((S + kSampleTile - 1) / kSampleTile, B);
-    if (f64)
-        hipLaunchKernelGGL(k_sample<double>, grid, dim3(kSampleThreads), 0, st, W, S, pw, lut, meta, (double *)x,
-                           (double *)y, (double *)h, (double *)k, (double *)dth);
-    else
-        hipLaunchKernelGGL(k_sample<float>, grid, dim3(kSampleThreads), 0, st, W, S, pw, lut, meta, (float *)x,
-                           (float *)y, (float *)h, (float *)k, (float *)dth);
+    const bool in_lds = (W - 1) <= kLdsCoefSegments;
+    const size_t lds = in_lds ? sizeof(double) * (size_t)(W - 1) * kCoefDoubles : 0;
+#define VAP_SAMPLE(OT_, LDS_)                                                                                      \
+    hipLaunchKernelGGL((k_sample<OT_, LDS_>), grid, dim3(kSampleThreads), lds, st, W, S, pw, lut, slopes, meta, aux, \
+                       (OT_ *)x, (OT_ *)y, (OT_ *)h, (OT_ *)k, (OT_ *)dth)
+    if (f64) { if (in_lds) VAP_SAMPLE(double, true); else VAP_SAMPLE(double, false); }
+    else { if (in_lds) VAP_SAMPLE(float, true); else VAP_SAMPLE(float, false); }
+#undef VAP_SAMPLE
     return hipGetLastError();
 }
 
