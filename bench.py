@@ -92,14 +92,14 @@ def main():
     B, W, S = wl["paths"], wl["W"], wl["S"]
     tdt = torch.float32 if args.dtype == "f32" else torch.float64
 
+    from vexautonomousplanner_amd import dist as vdist
     # rank 0 owns the constraints; everyone else receives them over RCCL (setup, untimed)
-    cons = torch.tensor(DEFAULT_CONSTRAINTS if rank == 0 else [0.0] * 6, dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.broadcast(cons, src=0)
-    constraints = [float(v) for v in cons.cpu()]
-    # shard r of the global batch: paths [r*B, (r+1)*B) of the seeded generator
+    constraints = vdist.broadcast_constraints(DEFAULT_CONSTRAINTS if rank == 0 else None, dev)
+    # rank r works on the contiguous block [r*B, (r+1)*B) of the seeded global batch (every rank can
+    # generate its own block, so the waypoint scatter of vdist.scatter_waypoints is not needed here)
+    lo, hi = vdist.shard_bounds(B * world, rank, world)
     wp_all = make_waypoints(B * world, W, wl["seed"], dtype=np.float32 if args.dtype == "f32" else np.float64)
-    wp = torch.tensor(wp_all[rank * B:(rank + 1) * B], dtype=tdt, device=dev)
+    wp = torch.tensor(wp_all[lo:hi], dtype=tdt, device=dev)
     del wp_all
 
     gen = BatchedTrajectoryGenerator(local_rank, args.dtype)
@@ -140,13 +140,11 @@ def main():
     gen.ctx.set_timing(False)
 
     flags = int(out["flags"].abs().max().item())
-    # after the timed region: gather per-path summaries (length, samples) on every rank over RCCL
-    summ = out["meta"][:, [1, 3]].contiguous()
-    if world > 1:
-        gathered = [torch.empty_like(summ) for _ in range(world)]
-        dist.all_gather(gathered, summ)
-        summ = torch.cat(gathered)
+    # after the timed region: all-gather per-path summaries (length, samples, traversal time) over RCCL —
+    # 24 B/path, what a caller ranking candidate trajectories needs from the other GPUs
+    summ = vdist.all_gather_rows(vdist.path_summaries(out["meta"], out["velocity"]), B * world)
     total_len = float(summ[:, 0].sum().item())
+    best_time = float(summ[:, 2].min().item())
 
     if rank == 0:
         points = B * S * world
@@ -167,7 +165,8 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": wl["name"], "paths_per_gpu": B, "waypoints": W, "samples": S,
                        "global_paths": B * world, "parallelism": f"paths sharded x{world}, no data-path collective",
-                       "flags_or": flags, "sum_path_length_ft": total_len},
+                       "flags_or": flags, "sum_path_length_ft": total_len,
+                       "fastest_traversal_s": best_time},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel_ms": dom_ms, "algorithmic_bytes_per_point": stage_bytes[dom]},

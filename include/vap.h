@@ -76,8 +76,10 @@ int vap_device_count(void);
 /* One context = one device + one stream + its scratch arena.  Not thread-safe; one per thread. */
 int vap_ctx_create(int device, vap_ctx **out);
 int vap_ctx_destroy(vap_ctx *ctx);
-/* Run subsequent work on `hip_stream` (a hipStream_t, e.g. torch's current stream); NULL = the
- * context's own stream. */
+/* Run subsequent work on `hip_stream` (a hipStream_t, e.g. torch's current stream; NULL is HIP's
+ * default stream).  VAP_STREAM_OWN selects the context's own non-blocking stream again (the initial
+ * state). */
+#define VAP_STREAM_OWN ((void *)(intptr_t)-1)
 int vap_ctx_set_stream(vap_ctx *ctx, void *hip_stream);
 int vap_ctx_synchronize(vap_ctx *ctx);
 /* Tuning / test knobs.  VAP_OPT_VELOCITY_KERNEL selects the K5 implementation: AUTO (default) picks
@@ -107,7 +109,8 @@ int vap_last_timing(vap_ctx *ctx, float ms[VAP_T_COUNT]);
  * tangent overrides (NaN = None; SM:65-77, QHS:102-115), or NULL. */
 int vap_fit(vap_ctx *ctx, vap_dtype dt, int B, int W, const void *d_waypoints,
             const double *d_tangent_in, const double *d_tangent_out, double *d_segments,
-            double *d_meta, uint32_t *d_flags);
+            double *d_segment_lengths /* [B][G] fp64, QHS:84-85, may be NULL */, double *d_meta,
+            uint32_t *d_flags);
 
 /* SM:426-475 build_lookup_table.  Fills lut and meta[1] (= get_total_arc_length, SM:320-330). */
 int vap_build_lut(vap_ctx *ctx, int B, int W, const double *d_segments, double *d_lut,

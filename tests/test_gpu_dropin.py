@@ -1,0 +1,136 @@
+"""GPU: the drop-in classes (reference import paths and method names) against golden vectors from
+the real reference.  These tests read like the calls gui/path.py makes."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def mods():
+    import torch
+    assert torch.cuda.is_available()
+    sys.path.insert(0, os.path.join(ROOT, "dropin"))
+    from motion_profiling_v2 import motion_profile_generator
+    from splines.spline_manager import QuinticHermiteSplineManager
+    from vexautonomousplanner_amd.nodes import ActionPoint, Node
+    yield QuinticHermiteSplineManager, motion_profile_generator, Node, ActionPoint
+    sys.path.remove(os.path.join(ROOT, "dropin"))
+
+
+def build(mods, g, tangent=False):
+    Manager, _, Node, _ = mods
+    wp = g["waypoints"]
+    nodes = [Node() for _ in wp]
+    if tangent:
+        for i, row in enumerate(g["node_tangent"]):
+            if not np.isnan(row[0]):
+                nodes[i].tangent = row.copy()
+                nodes[i].incoming_magnitude, nodes[i].outgoing_magnitude = g["node_magnitudes"][i]
+    m = Manager()
+    assert m.build_path(wp, nodes, []) is True
+    return m, nodes
+
+
+@pytest.mark.parametrize("name", gu.names(("plain_w2_s0", "plain_w5_s1", "plain_w8_s2", "plain_w32_s3", "c1_w8")))
+def test_manager_build_and_tables(mods, name):
+    g = gu.load(name)
+    m, _ = build(mods, g)
+    assert m.splines and len(m.splines) == 1
+    sp = m.splines[0]
+    rseg, rsl, rpl = gu.ref_segments(g)
+    np.testing.assert_allclose(np.array(sp.segments), rseg, rtol=1e-15, atol=1e-16)
+    np.testing.assert_allclose(sp.segment_lengths, rsl, rtol=1e-15)
+    assert sp.parameters[-1] == rpl[0] and sp.parameters[0] == 0
+    m.rebuild_tables()
+    np.testing.assert_array_equal(m.lookup_table.distances, g["lut_distances"])     # bit-identical table
+    np.testing.assert_allclose(m.lookup_table.parameters, g["lut_parameters"], rtol=1e-15)
+    assert m.get_total_arc_length() == float(g["total_length"])
+
+
+@pytest.mark.parametrize("name", gu.names(("plain_w8_s0", "plain_w32_s1", "c1_w8")))
+def test_scalar_accessors_match_reference_walk(mods, name):
+    """distance_to_time / get_curvature / get_heading / get_point_at_parameter along the reference's
+    own distance grid (the values oracle/gen_golden.py recorded by calling the real manager)."""
+    g = gu.load(name)
+    m, _ = build(mods, g)
+    m.rebuild_tables()
+    dd = float(g["dd"])
+    for k in list(range(0, 40)) + list(range(40, int(g["n_samples"]) - 1, 37)):
+        t = m.distance_to_time(k * dd)
+        assert t == pytest.approx(float(g["grid_t"][k]), rel=1e-12, abs=1e-13)  # k*dd vs the accumulated grid
+        assert m.get_curvature(t) == pytest.approx(float(g["grid_curvature"][k]), rel=1e-10, abs=1e-12)
+        assert m.get_heading(t) == pytest.approx(float(g["grid_heading"][k]), abs=1e-12)
+        np.testing.assert_allclose(m.get_point_at_parameter(t), [g["grid_x"][k], g["grid_y"][k]], rtol=1e-11, atol=1e-11)
+    # reference early returns (SM:300-303)
+    assert m.distance_to_time(-1.0) == 0
+    assert m.distance_to_time(1e9) == len(g["waypoints"]) - 1
+
+
+@pytest.mark.parametrize("name", gu.names(("plain_", "c1_")))
+def test_forward_backward_pass_list(mods, name):
+    _, mpg, _, _ = mods
+    g = gu.load(name)
+    m, _ = build(mods, g)
+    c = mpg.Constraints(*g["constraints"])
+    m.rebuild_tables()
+    v = mpg.forward_backward_pass(m, c, float(g["dd"]))
+    assert isinstance(v, list) and len(v) == int(g["n_samples"])
+    np.testing.assert_allclose(np.array(v)[g["grid_idx"]], g["grid_velocity"], rtol=1e-9)
+    # the pass must leave the caller's constraints untouched (MPG:313-314)
+    assert (c.max_acc, c.max_dec) == (float(g["constraints"][1]), float(g["constraints"][2]))
+
+
+def test_tangent_overrides_and_magnitudes(mods):
+    g = gu.load("feat_tangent")
+    m, nodes = build(mods, g, tangent=True)
+    rseg, rsl, _ = gu.ref_segments(g)
+    np.testing.assert_allclose(np.array(m.splines[0].segments), rseg, rtol=1e-15, atol=1e-16)
+    assert m.get_magnitudes_at_parameter(2) == [nodes[2].incoming_magnitude, nodes[2].outgoing_magnitude]
+    assert m.get_magnitudes_at_parameter(0) == [0, rsl[0]]
+    assert m.get_magnitudes_at_parameter(7) == [rsl[-1], 0]
+    assert m.get_magnitudes_at_parameter(3) == [rsl[2], rsl[3]]
+    assert m.percent_to_parameter(0.5) == 4.0 and m.percent_to_parameter(2.0) == 7
+
+
+def test_failure_modes(mods):
+    Manager, mpg, Node, ActionPoint = mods
+    from splines.quintic_hermite_spline import QuinticHermiteSpline
+    wp = gu.load("c1_w8")["waypoints"]
+    m = Manager()
+    assert m.build_path(wp[:1], [Node()], []) is False                   # SM:50-51
+    assert m.build_path(wp, [Node() for _ in range(3)], []) is False
+    with pytest.raises(ValueError):
+        Manager().get_point_at_parameter(0.5)                             # SM:209-210
+    s = QuinticHermiteSpline()
+    assert s.fit(wp[:, 0], wp[:, 1]) is False                            # quirk Q1: no set_all_tangents
+    with pytest.raises(ValueError):
+        s.get_point(0.0)                                                  # QHS:222-223
+    s.set_all_tangents([[None, None]] * len(wp))
+    assert s.fit(wp[:, 0], wp[:, 1]) is True
+    assert s.get_total_arc_length() == pytest.approx(s.get_arc_length(0, s.parameters[-1]))
+    t = s.get_parameter_by_arc_length(1.0)
+    assert s.get_arc_length(0, t) == pytest.approx(1.0, abs=1e-6)
+    nodes = [Node() for _ in wp]
+    nodes[3].is_reverse_node = True
+    with pytest.raises(NotImplementedError):
+        Manager().build_path(wp, nodes, [])
+
+
+def test_redraw_polyline_vector_call(mods):
+    """gui/path.py:370-373 evaluates 25*len(nodes) points one by one; the vector accessor gives the
+    same points in one launch."""
+    g = gu.load("plain_w8_s4")
+    m, nodes = build(mods, g)
+    ts = np.linspace(0, len(nodes) - 1, 25 * len(nodes))
+    pts = m.get_points_at_parameters(ts)
+    for i in (0, 17, 99, 199):
+        np.testing.assert_array_equal(pts[i], m.get_point_at_parameter(ts[i]))
+    np.testing.assert_allclose(pts[0], g["waypoints"][0], atol=1e-14)
+    np.testing.assert_allclose(pts[-1], g["waypoints"][-1], atol=1e-14)

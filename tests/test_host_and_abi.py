@@ -1,0 +1,121 @@
+"""CPU-only checks: the C-ABI library loads and exports exactly what include/vap.h declares, the
+product refuses to run without a device (no CPU fallback), and the small host-side pieces of the
+drop-in surface behave like the reference."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+from vexautonomousplanner_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "vap.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(vap_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.lib()
+    declared = header_functions()
+    assert len(declared) >= 18
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/vap.h but not exported by libvap.so"
+    assert sorted(_lib.EXPORTS) == declared
+    assert L.vap_version() >= 100
+    assert L.vap_status_string(_lib.VAP_ERR_NO_DEVICE).decode() == "no HIP device"
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is present")
+    assert _lib.lib().vap_device_count() == 0
+    with pytest.raises(_lib.VapError) as e:
+        _lib.Context(0)
+    assert e.value.status == _lib.VAP_ERR_NO_DEVICE
+    from vexautonomousplanner_amd.batch import BatchedTrajectoryGenerator
+    with pytest.raises(RuntimeError):
+        BatchedTrajectoryGenerator(0)
+    # the drop-in manager cannot fit a path either: it must raise, not quietly compute on the host
+    from vexautonomousplanner_amd.nodes import Node
+    from vexautonomousplanner_amd.splines.spline_manager import QuinticHermiteSplineManager
+    wp = gu.load("c1_w8")["waypoints"]
+    with pytest.raises(RuntimeError):
+        QuinticHermiteSplineManager().build_path(wp, [Node() for _ in wp], [])
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", os.path.join(ROOT, "does_not_exist.so"))
+    with pytest.raises(ImportError):
+        _lib.lib()
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under the product package or dropin/ may import,
+    load or link it."""
+    pat = re.compile(r"(^|\W)(import\s+oracle|from\s+oracle|libvap_oracle|vap_oracle\.h|vapo_[a-z_]+)")
+    for top in ("vexautonomousplanner_amd", "dropin", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
+                    text = open(os.path.join(dirpath, f), encoding="utf-8").read()
+                    assert not pat.search(text), f"{top}/{f} references the oracle"
+
+
+def test_dropin_import_paths():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "dropin"))
+    try:
+        for mod in ("splines", "motion_profiling_v2"):
+            for k in [k for k in sys.modules if k.split(".")[0] == mod]:
+                del sys.modules[k]
+        from motion_profiling_v2 import motion_profile_generator
+        from splines.spline_manager import PathLookupTable, QuinticHermiteSplineManager
+        from splines.quintic_hermite_spline import QuinticHermiteSpline
+        assert QuinticHermiteSplineManager.__module__.startswith("vexautonomousplanner_amd")
+        assert hasattr(motion_profile_generator, "forward_backward_pass")
+        assert hasattr(motion_profile_generator, "generate_motion_profile")
+        assert PathLookupTable and QuinticHermiteSpline
+    finally:
+        sys.path.remove(os.path.join(ROOT, "dropin"))
+        for mod in ("splines", "motion_profiling_v2"):
+            for k in [k for k in sys.modules if k.split(".")[0] == mod]:
+                del sys.modules[k]
+
+
+def test_constraints_helpers_match_reference_formulas():
+    from vexautonomousplanner_amd.motion_profiling_v2.motion_profile_generator import Constraints, get_wheel_trajectory
+    c = Constraints(4.0, 8.0, 8.0, 0.8, 16.0, 12.5 / 12)
+    assert c.max_speed_at_curvature(5e-7) == 4.0
+    k = 1.3
+    w = 2 * 4.0 / c.track_width
+    assert c.max_speed_at_curvature(k) == min((w * 4.0) / (k * 4.0 + w), 4.0)
+    assert c.max_accels_at_turn(0.0) == 8.0            # tie -> the "right" branch (MPG:56-59)
+    assert c.max_accels_at_turn(2.0) == 8.0 - 2.0 * c.track_width / 2
+    assert c.max_accels_at_turn(-2.0) == 8.0 - 2.0 * c.track_width / 2
+    assert c.limit_velocity_by_ang_accel(0.0, 3.0) == 4.0
+    l, r = c.get_wheel_speeds(2.0, 1.0)
+    assert (l, r) == (2.0 - c.track_width / 2, 2.0 + c.track_width / 2)
+    assert get_wheel_trajectory([2.0], [1.0], c.track_width) == ([l], [r])
+
+
+def test_turn_profile_matches_oracle_time_domain_rows():
+    """motion_profile_angle + generate_trapezoidal_profile against the turn rows of the reference's
+    own output (feat_turn golden: the samples inserted at node 4, MPG:487-507)."""
+    from vexautonomousplanner_amd.motion_profiling_v2.motion_profile_generator import Constraints, motion_profile_angle
+    g = gu.load("feat_turn")
+    c = Constraints(*g["constraints"])
+    hs, ws = motion_profile_angle(np.radians(90), c, 0.01)
+    lin = g["profile_linear_vels"]
+    start = int(g["profile_nodes_map"][4])
+    # the inserted rows have linear velocity 0 and carry the angular velocities of the turn profile
+    rows = slice(start, start + len(ws))
+    assert np.all(lin[rows] == 0)
+    np.testing.assert_allclose(g["profile_angular_vels"][rows], ws, rtol=1e-12, atol=1e-12)

@@ -82,7 +82,7 @@ def lib():
     L.vap_ctx_set_timing.argtypes = [vp, C.c_int]
     L.vap_ctx_set_option.argtypes = [vp, C.c_int, C.c_int]
     L.vap_last_timing.argtypes = [vp, C.POINTER(C.c_float)]
-    L.vap_fit.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
+    L.vap_fit.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]
     L.vap_build_lut.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp]
     L.vap_sample.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, vp, vp, vp,
                              vp, vp, vp, vp, vp, vp]
@@ -131,7 +131,9 @@ class Context:
             pass
 
     def set_stream(self, stream_ptr):
-        check(self._L.vap_ctx_set_stream(self.handle, vp(stream_ptr or None)), "vap_ctx_set_stream")
+        """stream_ptr: a hipStream_t as int (0 = HIP's default stream); None = the context's own stream."""
+        arg = vp(-1 & 0xFFFFFFFFFFFFFFFF) if stream_ptr is None else vp(int(stream_ptr))
+        check(self._L.vap_ctx_set_stream(self.handle, arg), "vap_ctx_set_stream")
 
     def synchronize(self):
         check(self._L.vap_ctx_synchronize(self.handle), "vap_ctx_synchronize")

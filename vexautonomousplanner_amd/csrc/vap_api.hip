@@ -203,7 +203,7 @@ int vap_ctx_destroy(vap_ctx *ctx)
 int vap_ctx_set_stream(vap_ctx *ctx, void *hip_stream)
 {
     if (!ctx) return fail(VAP_ERR_INVALID, "null context");
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->stream = hip_stream == VAP_STREAM_OWN ? ctx->own_stream : (hipStream_t)hip_stream;
     return VAP_OK;
 }
 
@@ -250,13 +250,14 @@ int vap_last_timing(vap_ctx *ctx, float ms[VAP_T_COUNT])
 }
 
 int vap_fit(vap_ctx *ctx, vap_dtype dt, int B, int W, const void *d_waypoints, const double *d_tangent_in,
-            const double *d_tangent_out, double *d_segments, double *d_meta, uint32_t *d_flags)
+            const double *d_tangent_out, double *d_segments, double *d_segment_lengths, double *d_meta,
+            uint32_t *d_flags)
 {
     VAP_TRY(set_device(ctx));
     VAP_TRY(check_shape(B, W, 2));
     if (!d_waypoints || !d_segments || !d_meta) return fail(VAP_ERR_INVALID, "null buffer");
     HIP_TRY(vap::launch_fit(ctx->stream, dt == VAP_F64, B, W, d_waypoints, d_tangent_in, d_tangent_out,
-                            d_segments, nullptr, d_meta, d_flags));
+                            d_segments, nullptr, d_segment_lengths, d_meta, d_flags));
     return VAP_OK;
 }
 
@@ -336,7 +337,7 @@ int vap_profile_batch(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd
     const double cc[6] = {c->max_vel, c->max_acc, c->max_dec, c->friction_coef, c->max_jerk, c->track_width};
     StageTimer tm(ctx);
     HIP_TRY(vap::launch_fit(ctx->stream, f64, B, W, d_waypoints, nullptr, nullptr, (double *)ctx->seg.ptr,
-                            (double *)ctx->power.ptr, meta, flags));
+                            (double *)ctx->power.ptr, nullptr, meta, flags));
     tm.mark(VAP_T_FIT);
     HIP_TRY(vap::launch_lut(ctx->stream, B, W, (const double *)ctx->seg.ptr, (double *)ctx->lut.ptr,
                             (double *)ctx->slopes.ptr, meta, flags));

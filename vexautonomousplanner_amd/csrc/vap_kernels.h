@@ -17,7 +17,7 @@ constexpr int kLdsCoefSegments = 136;                     // segments whose coef
 constexpr int kMaxWaypoints = 2048;              // k_fit LDS: 7*W doubles
 
 hipError_t launch_fit(hipStream_t st, bool f64, int B, int W, const void *wp, const double *tin,
-                      const double *tout, double *seg, double *pw, double *meta, uint32_t *flags);
+                      const double *tout, double *seg, double *pw, double *seglen, double *meta, uint32_t *flags);
 hipError_t launch_lut(hipStream_t st, int B, int W, const double *seg, double *lut, double *slopes, double *meta,
                       uint32_t *flags);
 hipError_t launch_lut_slopes(hipStream_t st, int B, const double *lut, const double *meta, double *slopes);

@@ -27,7 +27,8 @@ __global__ __launch_bounds__(256) void k_fit(int W, const IT *__restrict__ waypo
                                              const double *__restrict__ tan_in,
                                              const double *__restrict__ tan_out,
                                              double *__restrict__ segments, double *__restrict__ power,
-                                             double *__restrict__ meta, uint32_t *__restrict__ flags)
+                                             double *__restrict__ seglen, double *__restrict__ meta,
+                                             uint32_t *__restrict__ flags)
 {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
@@ -118,6 +119,7 @@ __global__ __launch_bounds__(256) void k_fit(int W, const IT *__restrict__ waypo
 #pragma unroll
         for (int k = 0; k < 12; k++) sg[k] = r[k];
         if (power) make_coef_block(r, power + ((size_t)b * G + i) * kCoefDoubles);
+        if (seglen) seglen[(size_t)b * G + i] = L;
     }
     __syncthreads();
     if (tid == 0 && flags) flags[b] = s_flag;
@@ -850,19 +852,20 @@ __global__ void k_lookup(int W, const double *__restrict__ seg, double t_max, co
 // ------------------------------------------------------------------------------------------------
 template <typename IT>
 static hipError_t launch_fit_t(hipStream_t st, int B, int W, const void *wp, const double *tin,
-                               const double *tout, double *seg, double *pw, double *meta, uint32_t *flags)
+                               const double *tout, double *seg, double *pw, double *seglen, double *meta,
+                               uint32_t *flags)
 {
     const size_t lds = sizeof(double) * (size_t)(7 * W);
     hipLaunchKernelGGL(k_fit<IT>, dim3(B), dim3(W <= 64 ? 64 : 256), lds, st, W, (const IT *)wp, tin, tout,
-                       seg, pw, meta, flags);
+                       seg, pw, seglen, meta, flags);
     return hipGetLastError();
 }
 
 hipError_t launch_fit(hipStream_t st, bool f64, int B, int W, const void *wp, const double *tin,
-                      const double *tout, double *seg, double *pw, double *meta, uint32_t *flags)
+                      const double *tout, double *seg, double *pw, double *seglen, double *meta, uint32_t *flags)
 {
-    return f64 ? launch_fit_t<double>(st, B, W, wp, tin, tout, seg, pw, meta, flags)
-               : launch_fit_t<float>(st, B, W, wp, tin, tout, seg, pw, meta, flags);
+    return f64 ? launch_fit_t<double>(st, B, W, wp, tin, tout, seg, pw, seglen, meta, flags)
+               : launch_fit_t<float>(st, B, W, wp, tin, tout, seg, pw, seglen, meta, flags);
 }
 
 hipError_t launch_lut(hipStream_t st, int B, int W, const double *seg, double *lut, double *slopes, double *meta,

@@ -1,0 +1,197 @@
+"""QuinticHermiteSplineManager with the reference's call surface (splines/spline_manager.py:24-594),
+backed by the HIP kernels of libvap.so.
+
+What runs where (SM = the reference's splines/spline_manager.py):
+  build_path                      -> K1 fit on the device (vap_fit)                          SM:42-172
+  rebuild_tables / build_lookup_table -> K2 arc-length table on the device (vap_build_lut)   SM:426-475, 582-594
+  precompute_path_properties      -> nothing is materialised: get_curvature / get_heading evaluate
+                                     the table entry the reference's step lookup would read  SM:477-580
+  get_*_at_parameter, distance_to_time, get_curvature, get_heading -> vap_eval_host / vap_lookup_host
+Paths with reverse or turn nodes (several splines, SM:84-158) are SURVEY §8(f) rank 2 and raise
+NotImplementedError for now.
+"""
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from .quintic_hermite_spline import QuinticHermiteSpline
+
+
+@dataclass
+class PathLookupTable:
+    """SM:15-21."""
+    distances: np.ndarray
+    parameters: np.ndarray
+    total_length: float
+
+
+class QuinticHermiteSplineManager:
+    def __init__(self):
+        self.splines: List[QuinticHermiteSpline] = []
+        self.nodes: List = []
+        self.action_points: List = []
+        self.path_parameters: Dict = {}
+        self.arc_length = 0.0
+        self.lookup_table: Optional[PathLookupTable] = None
+        self._precomputed_properties: Optional[Dict] = None
+
+    # -- construction -----------------------------------------------------------------------------
+    def build_path(self, points: np.ndarray, nodes: List, action_points: List) -> bool:
+        if len(points) != len(nodes) or len(points) < 2:
+            return False
+        points = np.asarray(points, dtype=float)
+        for i in range(1, len(points)):
+            if nodes[i].is_reverse_node or nodes[i].turn != 0:
+                raise NotImplementedError("reverse / turn nodes split the path into several splines "
+                                          "(SURVEY §8(f) rank 2): not on the device path yet")
+        self.splines = []
+        self.nodes = nodes
+        self.action_points = action_points
+        tangents = []
+        for node in nodes:
+            if node.tangent is not None:
+                tangents.append([np.asarray(node.tangent) * node.incoming_magnitude,
+                                 np.asarray(node.tangent) * node.outgoing_magnitude])
+            else:
+                tangents.append([None, None])
+        spline = QuinticHermiteSpline()
+        spline.set_all_tangents(tangents)
+        if not spline.fit(points[:, 0], points[:, 1]):
+            return False
+        self.splines.append(spline)
+        self.arc_length = None
+        self.lookup_table = None
+        return True
+
+    # -- helpers ------------------------------------------------------------------------------------
+    def _require(self):
+        if not self.splines:
+            raise ValueError("No splines have been initialized")
+
+    def _map_parameter_to_spline(self, t: float) -> Tuple[int, float]:
+        self._require()
+        cumulative = 0
+        for i, spline in enumerate(self.splines):
+            end = cumulative + len(spline.control_points) - 1
+            if t <= end or i == len(self.splines) - 1:
+                return i, t - cumulative
+            cumulative = end
+        raise ValueError("Failed to map parameter to spline segment")
+
+    def _dev(self):
+        return self.splines[0]._dev
+
+    # -- evaluators (SM:204-241) ----------------------------------------------------------------------
+    def get_point_at_parameter(self, t: float) -> np.ndarray:
+        self._require()
+        i, lt = self._map_parameter_to_spline(t)
+        return self.splines[i].get_point(lt)
+
+    def get_derivative_at_parameter(self, t: float) -> np.ndarray:
+        self._require()
+        i, lt = self._map_parameter_to_spline(t)
+        return self.splines[i].get_derivative(lt)
+
+    def get_second_derivative_at_parameter(self, t: float) -> np.ndarray:
+        self._require()
+        i, lt = self._map_parameter_to_spline(t)
+        return self.splines[i].get_second_derivative(lt)
+
+    def get_points_at_parameters(self, ts) -> np.ndarray:
+        """Vector form (one launch) of get_point_at_parameter — what a redraw wants (gui/path.py:370-373)."""
+        self._require()
+        return self.splines[0].get_points(ts)
+
+    def get_magnitudes_at_parameter(self, idx):
+        """SM:174-202."""
+        si, lt = self._map_parameter_to_spline(idx)
+        node = self.nodes[idx]
+        if node.tangent is not None:
+            return [node.incoming_magnitude, node.outgoing_magnitude]
+        sp = self.splines
+        end = sp[si].percent_to_parameter(100)
+        if si == 0 and lt == 0:
+            return [0, sp[si].get_magnitude(0)]
+        if si == len(sp) - 1 and lt == end:
+            return [sp[si].get_magnitude(-1), 0]
+        if lt == 0:
+            return [sp[si - 1].get_magnitude(-1), sp[si].get_magnitude(0)]
+        if lt == end:
+            return [sp[si].get_magnitude(-1), sp[si + 1].get_magnitude(0)]
+        return [sp[si].get_magnitude(round(lt) - 1), sp[si].get_magnitude(round(lt))]
+
+    def percent_to_parameter(self, percent: float):
+        """SM:277-289 (note: scales by len(nodes), clamps to len(nodes)-1; quirk Q6)."""
+        self._require()
+        return min(max(len(self.nodes) * percent, 0), len(self.nodes) - 1)
+
+    # -- tables ---------------------------------------------------------------------------------------
+    def build_lookup_table(self, min_samples=1000, max_samples=20000, tolerance=1e-6) -> None:
+        if not self.splines:
+            raise ValueError("No splines initialized")
+        if min_samples != 1000:
+            raise NotImplementedError("the device table has the reference's default 1000 samples")
+        dev = self._dev()
+        dev.build_lut()
+        n = len(dev.lut)
+        params = np.arange(n) * (dev.param_last / (n - 1))
+        params[-1] = dev.param_last
+        self.lookup_table = PathLookupTable(distances=dev.lut, parameters=params, total_length=dev.total)
+
+    def precompute_path_properties(self, samples_per_node: int = 1000) -> None:
+        """The reference fills 1000*len(nodes) curvature/heading entries here (SM:477-548); the device
+        path evaluates the one entry a lookup needs on demand, so only the table geometry is kept."""
+        if not self.splines:
+            raise ValueError("No splines initialized")
+        if samples_per_node != 1000:
+            raise NotImplementedError("the device lookup uses the reference's default 1000 samples per node")
+        self._precomputed_properties = {"samples": len(self.nodes) * samples_per_node, "on_demand": True}
+
+    def rebuild_tables(self):
+        self.build_lookup_table()
+        self.precompute_path_properties()
+
+    def get_total_arc_length(self) -> float:
+        self._require()
+        if self.lookup_table is None:
+            self.build_lookup_table()
+        return self.lookup_table.total_length
+
+    def distance_to_time(self, distance: float) -> float:
+        if self.lookup_table is None:
+            self.build_lookup_table()
+        if distance <= 0:
+            return 0
+        if distance >= self.lookup_table.total_length:
+            return len(self.nodes) - 1
+        return float(self._dev().lookup(0, distance)[0])
+
+    def get_heading(self, t: float) -> float:
+        if self._precomputed_properties is None:
+            self.precompute_path_properties()
+        if self.lookup_table is None:
+            self.build_lookup_table()
+        return float(self._dev().lookup(2, t)[0])
+
+    def get_curvature(self, t: float) -> float:
+        if self._precomputed_properties is None:
+            self.precompute_path_properties()
+        if self.lookup_table is None:
+            self.build_lookup_table()
+        return float(self._dev().lookup(1, t)[0])
+
+    def _get_heading(self, t: float) -> float:
+        d = self.get_derivative_at_parameter(t)
+        return float(np.arctan2(d[1], d[0]))
+
+    def _get_curvature(self, t: float) -> float:
+        d1 = self.get_derivative_at_parameter(t)
+        d2 = self.get_second_derivative_at_parameter(t)
+        s2 = d1[0] ** 2 + d1[1] ** 2
+        if s2 < 1e-10:
+            return 0.0
+        return float((d1[0] * d2[1] - d1[1] * d2[0]) / s2 ** 1.5)
+
+    def validate_path_continuity(self) -> bool:
+        pass  # an empty stub in the reference too (SM:420-424)
