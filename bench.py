@@ -56,6 +56,22 @@ def cpu_baseline(wl, budget_s=12.0):
                       f"{cores} threads, {dt:.1f}s"}
 
 
+def profiled_traffic(stage, workload, dtype, paths):
+    """HBM bytes per launch of the stage's kernel from the committed PMC profile of this round
+    (profiles/r*_traffic.json, made by tools/profile_round.sh: separate FETCH_SIZE / WRITE_SIZE passes,
+    gfx950 corrections applied).  Only meaningful for the default workload the profile was taken on."""
+    import glob
+    if workload != "c3" or dtype != "f32" or paths != WORKLOADS["c3"]["paths"]:
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None
+    kern = {"sample": "k_sample", "velocity": "k_velocity", "fit": "k_fit", "lut": "k_lut"}[stage]
+    data = json.load(open(files[-1]))["kernels"]
+    vals = [v["hbm_bytes"] for k, v in data.items() if kern in k]
+    return sum(vals) if vals else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -155,6 +171,7 @@ def main():
         dom = max(("fit", "lut", "sample", "velocity"), key=lambda k: acc.get(k, 0.0))
         dom_ms = acc[dom]
         achieved = stage_bytes[dom] * B * S / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        traffic = profiled_traffic(dom, args.workload, args.dtype, B)
         line = {
             "metric": "trajectory sample-points/sec (batched paths)",
             "value": points / elapsed * args.steps,
@@ -168,7 +185,7 @@ def main():
                        "flags_or": flags, "sum_path_length_ft": total_len,
                        "fastest_traversal_s": best_time},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": dom_ms, "algorithmic_bytes_per_point": stage_bytes[dom]},
             "pipeline": {"bytes_per_point": bytes_per_point,
                          "achieved_GBs": bytes_per_point * B * S / (acc["total"] * 1e-3) / 1e9,
