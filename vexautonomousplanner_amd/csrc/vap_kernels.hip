@@ -18,6 +18,26 @@
 
 namespace vap {
 
+// Cooperative copy of n doubles from HBM/L2 into LDS: up to ITER loads per thread are issued before
+// the first LDS write, so a workgroup pays the memory latency once instead of once per element.
+template <int ITER>
+__device__ __forceinline__ void lds_fill(double *__restrict__ dst, const double *__restrict__ src, int n, int tid, int nt)
+{
+    for (int base = 0; base < n; base += ITER * nt) {
+        double v[ITER];
+#pragma unroll
+        for (int it = 0; it < ITER; it++) {
+            const int i = base + tid + it * nt;
+            v[it] = i < n ? src[i] : 0.0;
+        }
+#pragma unroll
+        for (int it = 0; it < ITER; it++) {
+            const int i = base + tid + it * nt;
+            if (i < n) dst[i] = v[it];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1: fit.  One workgroup per path.  QHS:30-138, 149-219, 719-736; SM:65-77 tangent overrides.
 // LDS (dynamic): pts[W][2], dist[G], fd[W][2], sd[W][2]  (fp64)
@@ -130,16 +150,24 @@ __global__ __launch_bounds__(256) void k_fit(int W, const IT *__restrict__ waypo
 // 1000 uniform-parameter samples of |P'(t)| (reference basis, reference order), trapezoid, and a
 // SEQUENTIAL cumulative sum (np.cumsum order) so the table is bit-identical to the reference's.
 // ------------------------------------------------------------------------------------------------
+template <bool SEG_LDS>
 __global__ __launch_bounds__(256) void k_lut(int W, const double *__restrict__ segments,
                                              double *__restrict__ lut, double *__restrict__ slopes,
                                              double *__restrict__ meta, uint32_t *__restrict__ flags)
 {
-    __shared__ double mag[kLutN];
-    __shared__ double cum[kLutN];
+    extern __shared__ __attribute__((aligned(16))) double s_seg[];   // G * 12 when SEG_LDS
+    constexpr int kPad = (kLutN + 15) / 16 * 16;   // the sequential sum walks whole groups of 16
+    __shared__ double mag[kPad];
+    __shared__ double cum[kPad];
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int G = W - 1;
     const double t_max = meta[(size_t)b * kMetaStride + 0];
     const double *seg = segments + (size_t)b * G * 12;
+    if constexpr (SEG_LDS) {
+        lds_fill<4>(s_seg, seg, G * 12, tid, nt);
+        __syncthreads();
+        seg = s_seg;
+    }
     for (int j = tid; j < kLutN; j += nt) {
         const double t = linspace_at(t_max, kLutN, j);
         double lt;
@@ -150,25 +178,26 @@ __global__ __launch_bounds__(256) void k_lut(int W, const double *__restrict__ s
         mag[j] = sqrt(dx * dx + dy * dy);  // np.linalg.norm(derivatives, axis=1), SM:448
     }
     __syncthreads();
+    // trapezoid increments in parallel (SM:452-454: (m[j-1] + m[j]) * 0.5 * dt, that association) ...
+    const double dt = linspace_at(t_max, kLutN, 1) - linspace_at(t_max, kLutN, 0);  // SM:444
+    for (int j = tid; j < kPad; j += nt) cum[j] = (j > 0 && j < kLutN) ? (mag[j - 1] + mag[j]) * 0.5 * dt : 0.0;
+    __syncthreads();
+    // ... and np.cumsum's strictly left-to-right sum by one lane: 999 dependent adds, operands
+    // fetched 16 at a time so the LDS latency stays off the chain
     if (tid == 0) {
-        const double dt = linspace_at(t_max, kLutN, 1) - linspace_at(t_max, kLutN, 0);  // SM:444
-        double acc = 0.0;
-        cum[0] = 0.0 + 0.0;
-        // np.cumsum order is strictly left to right; read the magnitudes 8 at a time so only the adds
-        // are on the dependent chain, not the LDS latency
-        double prev = mag[0];
-        for (int j0 = 1; j0 < kLutN; j0 += 8) {
-            double mv[8];
+        double acc = 0.0;   // cum[0] = 0: the first add is the exact 0 + 0 of partial_distances[0]
+#pragma unroll 1
+        for (int j0 = 0; j0 < kPad; j0 += 16) {
+            double inc[16];
 #pragma unroll
-            for (int k = 0; k < 8; k++) mv[k] = (j0 + k < kLutN) ? mag[j0 + k] : 0.0;
+            for (int k = 0; k < 16; k++) inc[k] = cum[j0 + k];
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                if (j0 + k < kLutN) {
-                    acc += (prev + mv[k]) * 0.5 * dt;  // SM:452-454
-                    cum[j0 + k] = acc + 0.0;           // + current_dist (single spline), SM:457
-                    prev = mv[k];
-                }
+            for (int k = 0; k < 16; k++) {
+                acc += inc[k];
+                inc[k] = acc + 0.0;                    // + current_dist (single spline), SM:457
             }
+#pragma unroll
+            for (int k = 0; k < 16; k++) cum[j0 + k] = inc[k];
         }
         const double total = cum[kLutN - 1];
         meta[(size_t)b * kMetaStride + 1] = total;
@@ -272,20 +301,23 @@ __device__ __forceinline__ double curvature_of(double num, double ss)
 }
 
 template <typename OT, bool COEF_LDS>
-__global__ __launch_bounds__(kSampleThreads) void k_sample(int W, int S, const double *__restrict__ power,
+__global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int tiles_per_block,
+                                                           const double *__restrict__ power,
                                                            const double *__restrict__ lut,
                                                            const double *__restrict__ slopes,
                                                            const double *__restrict__ meta,
                                                            const double *__restrict__ aux,
                                                            OT *__restrict__ ox, OT *__restrict__ oy,
                                                            OT *__restrict__ oh, OT *__restrict__ ok,
-                                                           OT *__restrict__ odth)
+                                                           OT *__restrict__ odth, long long *__restrict__ stats)
 {
     extern __shared__ __attribute__((aligned(16))) double s_coef[];   // G * kCoefDoubles when COEF_LDS
     __shared__ double sD[kLutN], sWt[kLutN];
-    __shared__ double s_dx[kSampleThreads], s_dy[kSampleThreads];
-    __shared__ int s_j[kSampleThreads];
-    __shared__ OT s_th[kSampleThreads];
+    // neighbour exchange, double-buffered by tile parity (one barrier per tile)
+    __shared__ double s_dx[2][kSampleThreads], s_dy[2][kSampleThreads];
+    __shared__ int s_j[2][kSampleThreads];
+    __shared__ OT s_th[2][kSampleThreads];
+    const long long ts0 = stats ? __builtin_amdgcn_s_memtime() : 0;
     const int b = blockIdx.y, tid = threadIdx.x;
     const int G = W - 1;
     const double *m = meta + (size_t)b * kMetaStride;
@@ -293,134 +325,145 @@ __global__ __launch_bounds__(kSampleThreads) void k_sample(int W, int S, const d
     const int N = (int)m[3];
     const double *ax = aux + (size_t)b * kAuxStride;
     const double lstep = ax[0], tstep = ax[1], inv_tstep = ax[2];
-    const int k0 = blockIdx.x * kSampleTile;
-    if (k0 >= S) return;
+    const int tile0 = blockIdx.x * tiles_per_block;
+    if (tile0 * kSampleTile >= S) return;
     const size_t row = (size_t)b * S;
-    const int kbase = k0 + tid * kSPT;
     const bool writer = tid < kSampleThreads - 1;
     constexpr int VW = 16 / sizeof(OT);   // elements per 16-byte store
-    const bool aligned = (S % VW) == 0;   // rows (and k0, a multiple of kSPT) then start 16-byte aligned
+    const bool aligned = (S % VW) == 0;   // rows (and tile starts, multiples of kSPT) then start 16-byte aligned
 
-    auto store_vec = [&](OT *dst, const OT v[kSPT]) {
-        if (!dst || !writer) return;
-        if (aligned && kbase + kSPT <= S) {
-            if constexpr (sizeof(OT) == 4) {
-                *reinterpret_cast<float4 *>(dst + row + kbase) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-                *reinterpret_cast<double2 *>(dst + row + kbase) = make_double2(v[0], v[1]);
-                *reinterpret_cast<double2 *>(dst + row + kbase + 2) = make_double2(v[2], v[3]);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < kSPT; i++)
-                if (kbase + i < S) dst[row + kbase + i] = v[i];
-        }
-    };
-
-    if (k0 >= N) {
-        // past this path's grid (ragged dd mode): zero-fill so every output element is defined
-        const OT z[kSPT] = {(OT)0, (OT)0, (OT)0, (OT)0};
-        store_vec(ox, z); store_vec(oy, z); store_vec(oh, z); store_vec(ok, z); store_vec(odth, z);
-        return;
-    }
-    for (int j = tid; j < kLutN; j += kSampleThreads) {
-        sD[j] = lut[(size_t)b * kLutN + j];
-        sWt[j] = slopes[(size_t)b * kLutN + j];
-    }
+    // the path's tables are staged once and serve every tile of this workgroup
     const double *pw = power + (size_t)b * G * kCoefDoubles;
-    if constexpr (COEF_LDS) {
-        for (int j = tid; j < G * kCoefDoubles; j += kSampleThreads) s_coef[j] = pw[j];
+    if (tile0 * kSampleTile < N) {
+        lds_fill<4>(sD, lut + (size_t)b * kLutN, kLutN, tid, kSampleThreads);
+        lds_fill<4>(sWt, slopes + (size_t)b * kLutN, kLutN, tid, kSampleThreads);
+        if constexpr (COEF_LDS) lds_fill<4>(s_coef, pw, G * kCoefDoubles, tid, kSampleThreads);
     }
     __syncthreads();
     const double *coef = COEF_LDS ? s_coef : pw;
-
+    const long long ts1 = stats ? __builtin_amdgcn_s_memtime() : 0;
     const double end_param = (double)(W - 1);
     const int tab_n = W * kSamplesPerNode;
-    OT vx[kSPT], vy[kSPT], vh[kSPT], vk[kSPT], vd[kSPT];
-    double d1x[kSPT], d1y[kSPT];
-    int jjv[kSPT];
-    int idx = 0;
+
+    for (int tl = 0; tl < tiles_per_block; tl++) {
+        const int k0 = (tile0 + tl) * kSampleTile;
+        if (k0 >= S) break;
+        const int kbase = k0 + tid * kSPT;
+        auto store_vec = [&](OT *dst, const OT v[kSPT]) {
+            if (!dst || !writer) return;
+            if (aligned && kbase + kSPT <= S) {
+                if constexpr (sizeof(OT) == 4) {
+                    *reinterpret_cast<float4 *>(dst + row + kbase) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    *reinterpret_cast<double2 *>(dst + row + kbase) = make_double2(v[0], v[1]);
+                    *reinterpret_cast<double2 *>(dst + row + kbase + 2) = make_double2(v[2], v[3]);
+                }
+            } else {
 #pragma unroll
-    for (int i = 0; i < kSPT; i++) {
-        // samples past the end of the grid (last tile only) are evaluated at the end sample and
-        // blanked on store: the body stays straight-line
-        const int k = kbase + i < N - 1 ? kbase + i : N - 1;
-        // MPG:112-122 distance grid; the reference accumulates s += dd, we form k*dd
-        const double s = (k == N - 1) ? total : (double)k * dd;
-        // SM:291-318 distance_to_time.  s = 0 lands on entry 1 with t = 0 exactly; s = total is the
-        // reference's early return of len(nodes)-1.
-        if (i == 0) idx = lut_search_left(sD, s);
-        else while (idx < kLutN - 1 && sD[idx] < s) idx++;
-        idx = idx < 1 ? 1 : idx;
-        const double d0 = sD[idx - 1];
-        const double t0 = (double)(idx - 1) * lstep;
-        const bool exact = s <= 0.0 || s >= total;      // the reference's early returns: t is exact
-        double t = fma(sWt[idx], s - d0, t0);
-        t = s >= total ? end_param : t;
-        // SM:340-346 / 550-580: the table entry the reference's step lookup selects
-        bool near;
-        int jj = table_index_fast(t, tab_n, inv_tstep, near);
-        if (near && !exact) {   // a few ulps from a decision point: redo with the reference's own rounding
-            const double t1 = (idx == kLutN - 1) ? t_max : (double)idx * lstep;
-            t = t0 + (t1 - t0) * (s - d0) / (sD[idx] - d0);
-            jj = table_index(t, tab_n, end_param);
+                for (int i = 0; i < kSPT; i++)
+                    if (kbase + i < S) dst[row + kbase + i] = v[i];
+            }
+        };
+        if (k0 >= N) {
+            // past this path's grid (ragged dd mode): zero-fill so every output element is defined
+            const OT z[kSPT] = {(OT)0, (OT)0, (OT)0, (OT)0};
+            store_vec(ox, z); store_vec(oy, z); store_vec(oh, z); store_vec(ok, z); store_vec(odth, z);
+            continue;
         }
-        const double tp = (jj == tab_n - 1) ? end_param : (double)jj * tstep;
-        double lt;
-        int sg;
-        normalize_inside(tp, G, lt, sg);
-        const double *c = coef + sg * kCoefDoubles;
-        const double ex = horner4(c + 12, lt), ey = horner4(c + 17, lt);     // P'
-        const double fx = horner3(c + 22, lt), fy = horner3(c + 26, lt);     // P''
-        const double ss = fma(ex, ex, ey * ey);                               // SM:517
-        const double num = fma(ex, fy, -(ey * fx));                           // SM:523
-        vk[i] = (OT)((ss >= 1e-10) ? curvature_of(num, ss) : 0.0);            // SM:526-527
-        vh[i] = heading_of<OT>(ey, ex);                                       // SM:536
-        d1x[i] = ex;
-        d1y[i] = ey;
-        jjv[i] = jj;
-        // SM:204-215 get_point_at_parameter(t) at the sample's own parameter
-        normalize_inside(t, G, lt, sg);
-        c = coef + sg * kCoefDoubles;
-        vx[i] = (OT)horner5(c, lt);
-        vy[i] = (OT)horner5(c + 6, lt);
-        vd[i] = (OT)0;
-    }
-    s_dx[tid] = d1x[0];
-    s_dy[tid] = d1y[0];
-    s_j[tid] = jjv[0];
-    s_th[tid] = vh[0];
-    __syncthreads();
-    if (writer) {
-        // |heading[k+1] - heading[k]| of the reference's raw (un-unwrapped) atan2 values
+        OT vx[kSPT], vy[kSPT], vh[kSPT], vk[kSPT], vd[kSPT];
+        double d1x[kSPT], d1y[kSPT];
+        int jjv[kSPT];
+        int idx = 0;
 #pragma unroll
         for (int i = 0; i < kSPT; i++) {
-            const int k = kbase + i;
-            if (k < N - 1) {
-                const double nx = (i + 1 < kSPT) ? d1x[(i + 1) % kSPT] : s_dx[tid + 1];
-                const double ny = (i + 1 < kSPT) ? d1y[(i + 1) % kSPT] : s_dy[tid + 1];
-                const int nj = (i + 1 < kSPT) ? jjv[(i + 1) % kSPT] : s_j[tid + 1];
-                const OT nth = (i + 1 < kSPT) ? vh[(i + 1) % kSPT] : s_th[tid + 1];
-                if constexpr (sizeof(OT) == 8) {
-                    vd[i] = fabs(nth - vh[i]);
-                } else {
-                    if (nj != jjv[i]) {
-                        // small-angle accurate: angle between the two fp64 derivative vectors, then
-                        // the 2*pi multiple that the raw difference of the two atan2 values carries
-                        const float cr = (float)fma(d1x[i], ny, -(d1y[i] * nx));
-                        const float dt = (float)fma(d1x[i], nx, d1y[i] * ny);
-                        const float dl = atan2_f32(cr, dt);
-                        const float raw = nth - vh[i];
-                        const float n = rintf((raw - dl) * 0.15915494309189535f);
-                        vd[i] = fabsf(fmaf(n, 6.283185307179586f, dl));
+            // samples past the end of the grid (last tile only) are evaluated at the end sample and
+            // blanked on store: the body stays straight-line
+            const int k = kbase + i < N - 1 ? kbase + i : N - 1;
+            // MPG:112-122 distance grid; the reference accumulates s += dd, we form k*dd
+            const double s = (k == N - 1) ? total : (double)k * dd;
+            // SM:291-318 distance_to_time.  s = 0 lands on entry 1 with t = 0 exactly; s = total is the
+            // reference's early return of len(nodes)-1.
+            if (i == 0) idx = lut_search_left(sD, s);
+            else while (idx < kLutN - 1 && sD[idx] < s) idx++;
+            idx = idx < 1 ? 1 : idx;
+            const double d0 = sD[idx - 1];
+            const double t0 = (double)(idx - 1) * lstep;
+            const bool exact = s <= 0.0 || s >= total;      // the reference's early returns: t is exact
+            double t = fma(sWt[idx], s - d0, t0);
+            t = s >= total ? end_param : t;
+            // SM:340-346 / 550-580: the table entry the reference's step lookup selects
+            bool near;
+            int jj = table_index_fast(t, tab_n, inv_tstep, near);
+            if (near && !exact) {   // a few ulps from a decision point: redo with the reference's own rounding
+                const double t1 = (idx == kLutN - 1) ? t_max : (double)idx * lstep;
+                t = t0 + (t1 - t0) * (s - d0) / (sD[idx] - d0);
+                jj = table_index(t, tab_n, end_param);
+            }
+            const double tp = (jj == tab_n - 1) ? end_param : (double)jj * tstep;
+            double lt;
+            int sg;
+            normalize_inside(tp, G, lt, sg);
+            const double *c = coef + sg * kCoefDoubles;
+            const double ex = horner4(c + 12, lt), ey = horner4(c + 17, lt);     // P'
+            const double fx = horner3(c + 22, lt), fy = horner3(c + 26, lt);     // P''
+            const double ss = fma(ex, ex, ey * ey);                               // SM:517
+            const double num = fma(ex, fy, -(ey * fx));                           // SM:523
+            vk[i] = (OT)((ss >= 1e-10) ? curvature_of(num, ss) : 0.0);            // SM:526-527
+            vh[i] = heading_of<OT>(ey, ex);                                       // SM:536
+            d1x[i] = ex;
+            d1y[i] = ey;
+            jjv[i] = jj;
+            // SM:204-215 get_point_at_parameter(t) at the sample's own parameter
+            normalize_inside(t, G, lt, sg);
+            c = coef + sg * kCoefDoubles;
+            vx[i] = (OT)horner5(c, lt);
+            vy[i] = (OT)horner5(c + 6, lt);
+            vd[i] = (OT)0;
+        }
+        const int pb = tl & 1;
+        s_dx[pb][tid] = d1x[0];
+        s_dy[pb][tid] = d1y[0];
+        s_j[pb][tid] = jjv[0];
+        s_th[pb][tid] = vh[0];
+        __syncthreads();
+        if (writer) {
+            // |heading[k+1] - heading[k]| of the reference's raw (un-unwrapped) atan2 values
+#pragma unroll
+            for (int i = 0; i < kSPT; i++) {
+                const int k = kbase + i;
+                if (k < N - 1) {
+                    const double nx = (i + 1 < kSPT) ? d1x[(i + 1) % kSPT] : s_dx[pb][tid + 1];
+                    const double ny = (i + 1 < kSPT) ? d1y[(i + 1) % kSPT] : s_dy[pb][tid + 1];
+                    const int nj = (i + 1 < kSPT) ? jjv[(i + 1) % kSPT] : s_j[pb][tid + 1];
+                    const OT nth = (i + 1 < kSPT) ? vh[(i + 1) % kSPT] : s_th[pb][tid + 1];
+                    if constexpr (sizeof(OT) == 8) {
+                        vd[i] = fabs(nth - vh[i]);
+                    } else {
+                        if (nj != jjv[i]) {
+                            // small-angle accurate: angle between the two fp64 derivative vectors, then
+                            // the 2*pi multiple that the raw difference of the two atan2 values carries
+                            const float cr = (float)fma(d1x[i], ny, -(d1y[i] * nx));
+                            const float dt = (float)fma(d1x[i], nx, d1y[i] * ny);
+                            const float dl = atan2_f32(cr, dt);
+                            const float raw = nth - vh[i];
+                            const float n = rintf((raw - dl) * 0.15915494309189535f);
+                            vd[i] = fabsf(fmaf(n, 6.283185307179586f, dl));
+                        }
                     }
                 }
             }
-        }
 #pragma unroll
-        for (int i = 0; i < kSPT; i++)
-            if (kbase + i >= N) vx[i] = vy[i] = vh[i] = vk[i] = vd[i] = (OT)0;
-        store_vec(ox, vx); store_vec(oy, vy); store_vec(oh, vh); store_vec(ok, vk); store_vec(odth, vd);
+            for (int i = 0; i < kSPT; i++)
+                if (kbase + i >= N) vx[i] = vy[i] = vh[i] = vk[i] = vd[i] = (OT)0;
+            store_vec(ox, vx); store_vec(oy, vy); store_vec(oh, vh); store_vec(ok, vk); store_vec(odth, vd);
+        }
+    }
+    if (stats && (tid & 63) == 0) {
+        long long *st = stats + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + (tid >> 6)) * 4;
+        st[0] = ts1 - ts0;                                 // staging + barrier
+        st[1] = __builtin_amdgcn_s_memtime() - ts1;        // all tiles
+        st[2] = 0;
+        st[3] = 0;
     }
 }
 
@@ -871,7 +914,8 @@ hipError_t launch_fit(hipStream_t st, bool f64, int B, int W, const void *wp, co
 hipError_t launch_lut(hipStream_t st, int B, int W, const double *seg, double *lut, double *slopes, double *meta,
                       uint32_t *flags)
 {
-    hipLaunchKernelGGL(k_lut, dim3(B), dim3(256), 0, st, W, seg, lut, slopes, meta, flags);
+    if (W - 1 <= 512) hipLaunchKernelGGL(k_lut<true>, dim3(B), dim3(256), sizeof(double) * 12 * (W - 1), st, W, seg, lut, slopes, meta, flags);
+    else hipLaunchKernelGGL(k_lut<false>, dim3(B), dim3(256), 0, st, W, seg, lut, slopes, meta, flags);
     return hipGetLastError();
 }
 
@@ -891,15 +935,37 @@ hipError_t launch_sample(hipStream_t st, bool f64, int B, int W, int S, const do
                          const double *slopes, const double *meta, const double *aux, void *x, void *y, void *h,
                          void *k, void *dth)
 {
-    const dim3 grid((S + kSampleTile - 1) / kSampleTile, B);
+    // one workgroup stages a path's tables once and walks tiles_per_block consecutive tiles; paths are
+    // split over several workgroups only when the batch alone cannot fill the chip
+    const int n_tiles = (S + kSampleTile - 1) / kSampleTile;
+    int split = (2048 + B - 1) / B;
+    split = split < 1 ? 1 : (split > n_tiles ? n_tiles : split);
+    const int tiles_per_block = (n_tiles + split - 1) / split;
+    const dim3 grid((n_tiles + tiles_per_block - 1) / tiles_per_block, B);
     const bool in_lds = (W - 1) <= kLdsCoefSegments;
     const size_t lds = in_lds ? sizeof(double) * (size_t)(W - 1) * kCoefDoubles : 0;
+    // developer knob: VAP_SAMPLE_STATS=1 prints in-kernel cycle shares per wave (synchronises!)
+    static const bool want_stats = getenv("VAP_SAMPLE_STATS") != nullptr;
+    long long *stats = nullptr;
+    const size_t n_waves = (size_t)grid.x * grid.y * 4;
+    if (want_stats) (void)hipMalloc(&stats, n_waves * 4 * sizeof(long long));
 #define VAP_SAMPLE(OT_, LDS_)                                                                                      \
-    hipLaunchKernelGGL((k_sample<OT_, LDS_>), grid, dim3(kSampleThreads), lds, st, W, S, pw, lut, slopes, meta, aux, \
-                       (OT_ *)x, (OT_ *)y, (OT_ *)h, (OT_ *)k, (OT_ *)dth)
+    hipLaunchKernelGGL((k_sample<OT_, LDS_>), grid, dim3(kSampleThreads), lds, st, W, S, tiles_per_block, pw, lut, \
+                       slopes, meta, aux, (OT_ *)x, (OT_ *)y, (OT_ *)h, (OT_ *)k, (OT_ *)dth, stats)
     if (f64) { if (in_lds) VAP_SAMPLE(double, true); else VAP_SAMPLE(double, false); }
     else { if (in_lds) VAP_SAMPLE(float, true); else VAP_SAMPLE(float, false); }
 #undef VAP_SAMPLE
+    if (stats) {
+        std::vector<long long> h(n_waves * 4);
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(h.data(), stats, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+        (void)hipFree(stats);
+        double sum[4] = {0, 0, 0, 0};
+        for (size_t w = 0; w < n_waves; w++)
+            for (int k = 0; k < 4; k++) sum[k] += (double)h[w * 4 + k];
+        fprintf(stderr, "[sample grid %ux%u, %d tiles/block] per-wave mean ticks: stage %.0f tiles %.0f\n", grid.x,
+                grid.y, tiles_per_block, sum[0] / n_waves, sum[1] / n_waves);
+    }
     return hipGetLastError();
 }
 
