@@ -53,6 +53,7 @@ struct vap_ctx {
     float ms[VAP_T_COUNT] = {};
     // scratch arena (grow-only, reused across calls)
     Buffer seg, power, lut, slopes, aux, meta, dth, flags, io[8], small_in, small_out, small_seg, small_lut;
+    Buffer ufwd, lstate, lcount;   // long-row velocity pass
 
     int ensure(Buffer &b, size_t bytes)
     {
@@ -114,12 +115,19 @@ int run_velocity(vap_ctx *ctx, bool f64, int B, int S, const double cc[6], doubl
                  const void *curv, const void *dth, const void *vcap, void *vel, uint32_t *flags)
 {
     int mode = ctx->velocity_kernel;
-    if (mode == VAP_VELOCITY_AUTO)
-        mode = (!vcap && S <= vap::velocity_relax_max_samples(f64)) ? VAP_VELOCITY_RELAX : VAP_VELOCITY_SEQ_FAST;
+    if (mode == VAP_VELOCITY_AUTO) mode = vcap ? VAP_VELOCITY_SEQ_FAST : VAP_VELOCITY_RELAX;
     if (mode == VAP_VELOCITY_RELAX) {
-        if (vcap || S > vap::velocity_relax_max_samples(f64))
-            return fail(VAP_ERR_UNSUPPORTED, "relaxation kernel: S=%d too large or per-sample caps given", S);
-        HIP_TRY(vap::launch_velocity_relax(ctx->stream, f64, B, S, cc, sv, ev, meta, curv, dth, vel, flags));
+        if (vcap) return fail(VAP_ERR_UNSUPPORTED, "relaxation kernel: per-sample caps are not supported yet");
+        if (S <= vap::velocity_relax_max_samples(f64)) {
+            HIP_TRY(vap::launch_velocity_relax(ctx->stream, f64, B, S, cc, sv, ev, meta, curv, dth, vel, flags));
+        } else {
+            // long rows: two-level relaxation (host-synchronised super-rounds)
+            VAP_TRY(ctx->ensure(ctx->ufwd, (size_t)B * S * (f64 ? 8 : 4)));
+            VAP_TRY(ctx->ensure(ctx->lstate, vap::velocity_long_state_bytes(f64, B, S)));
+            VAP_TRY(ctx->ensure(ctx->lcount, vap::velocity_long_counter_bytes(f64, B, S)));
+            HIP_TRY(vap::launch_velocity_long(ctx->stream, f64, B, S, cc, sv, ev, meta, curv, dth, vel, flags,
+                                              ctx->ufwd.ptr, ctx->lstate.ptr, (int *)ctx->lcount.ptr));
+        }
     } else {
         HIP_TRY(vap::launch_velocity_seq(ctx->stream, f64, mode == VAP_VELOCITY_SEQ_FAST, B, S, cc, sv, ev, meta, curv,
                                          dth, vcap, vel));
@@ -187,7 +195,7 @@ int vap_ctx_destroy(vap_ctx *ctx)
     if (!ctx) return VAP_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    Buffer *bufs[] = {&ctx->seg, &ctx->power, &ctx->lut, &ctx->slopes, &ctx->aux, &ctx->meta, &ctx->dth, &ctx->flags, &ctx->small_in,
+    Buffer *bufs[] = {&ctx->ufwd, &ctx->lstate, &ctx->lcount, &ctx->seg, &ctx->power, &ctx->lut, &ctx->slopes, &ctx->aux, &ctx->meta, &ctx->dth, &ctx->flags, &ctx->small_in,
                       &ctx->small_out, &ctx->small_seg, &ctx->small_lut};
     for (Buffer *b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);

@@ -32,6 +32,12 @@ int velocity_relax_max_samples(bool f64);
 hipError_t launch_velocity_relax(hipStream_t st, bool f64, int B, int S, const double c[6], double sv, double ev,
                                  const double *meta, const void *curv, const void *dth, void *vel,
                                  uint32_t *flags);
+// rows longer than velocity_relax_max_samples(): two-level relaxation, synchronises the stream once per super-round
+size_t velocity_long_state_bytes(bool f64, int B, int S);
+size_t velocity_long_counter_bytes(bool f64, int B, int S);
+hipError_t launch_velocity_long(hipStream_t st, bool f64, int B, int S, const double c[6], double sv, double ev,
+                                const double *meta, const void *curv, const void *dth, void *vel, uint32_t *flags,
+                                void *ufwd, void *state, int *counters);
 hipError_t launch_power(hipStream_t st, int n_seg, const double *seg, double *pw);
 hipError_t launch_eval(hipStream_t st, int W, const double *seg, double t_max, int order, int n, const double *t,
                        double *out);

@@ -836,6 +836,241 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
 }
 
 // ------------------------------------------------------------------------------------------------
+// K5c: rows longer than the register-resident kernel covers (config 2: one path, 10^6 samples).
+// Same relaxation, two levels: a row is cut into super-chunks of SC = MAXT*L samples, one workgroup
+// each, which relax internally exactly like K5b for a given incoming interface state; the interface
+// states between super-chunks live in HBM and are iterated by re-launching ("super-rounds") until no
+// interface changes.  A super-chunk whose incoming state is bit-identical to the one it last used
+// returns at once.  Forward velocities go through an HBM scratch row (the backward sweep of a
+// super-chunk may be re-run), final velocities are written by the backward kernel.
+//   bnd   [2][B][nsc+1][2]  interface states by super-round parity
+//   used  [B][nsc][2]       incoming state of the last evaluation      (NaN pattern = never)
+//   outst [B][nsc][2]       outgoing state of the last evaluation
+// ------------------------------------------------------------------------------------------------
+__global__ void k_dup_scan(int B, int S, const double *__restrict__ meta, const float *__restrict__ curv_f,
+                           const double *__restrict__ curv_d, const float *__restrict__ dth_f,
+                           const double *__restrict__ dth_d, int *__restrict__ dup)
+{
+    const int b = blockIdx.y;
+    const int N = (int)meta[(size_t)b * kMetaStride + 3];
+    const double twodd = 2.0 * meta[(size_t)b * kMetaStride + 2];
+    bool any = false;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N - 1; i += gridDim.x * blockDim.x) {
+        const size_t o = (size_t)b * S + i;
+        // same predicate as the kernels: g = gk/dtheta clamped at kHuge, on a non-straight sample
+        if (curv_f) any |= fabsf(curv_f[o]) >= 1e-6f && !(dth_f[o] > 0.0f && (float)(twodd) * 0.25f / dth_f[o] < 1e29f);
+        else any |= fabs(curv_d[o]) >= 1e-6 && !(dth_d[o] > 0.0 && twodd * 0.25 / dth_d[o] < 1e299);
+    }
+    if (__syncthreads_or(any ? 1 : 0) && threadIdx.x == 0) atomicOr(&dup[b], 1);
+}
+
+template <typename R, int L, int MAXT, int MINW, bool BWD>
+__global__ __launch_bounds__(MAXT, MINW) void k_velocity_long(int S, int nsc, int round, VelConsts<R> c, R start_u,
+                                                              R end_u, const double *__restrict__ meta,
+                                                              const R *__restrict__ curv,
+                                                              const R *__restrict__ dtheta, R *__restrict__ ufwd,
+                                                              R *__restrict__ vel, R *__restrict__ bnd,
+                                                              R *__restrict__ used, R *__restrict__ outst,
+                                                              const int *__restrict__ dupflag,
+                                                              int *__restrict__ changed, uint32_t *__restrict__ flags)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    R *stage = reinterpret_cast<R *>(smem_raw);
+    __shared__ R s_u[2][MAXT + 2], s_w[2][MAXT + 2];
+    __shared__ int s_any[3];
+    constexpr int T = MAXT;
+    constexpr int SC = T * L;
+    const int sc = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int B = gridDim.y;
+    const double *m = meta + (size_t)b * kMetaStride;
+    const R twodd = (R)2 * (R)m[2];
+    const int N = (int)m[3];
+    const int base = sc * SC;
+    const int last_sc = (N - 1) / SC;
+    if (sc > last_sc) return;
+    const size_t row = (size_t)b * S;
+    const R *K = curv + row, *DT = dtheta + row;
+    const FastConsts<R> fc = make_fast(c, twodd);
+    const bool any_dup = dupflag[b] != 0;
+    const int lo = tid * L;
+    // interface arrays
+    const size_t ifs = (size_t)(nsc + 1) * 2;                          // per path
+    R *bnd_prev = bnd + ((size_t)((round + 1) & 1) * B + b) * ifs;
+    R *bnd_cur = bnd + ((size_t)(round & 1) * B + b) * ifs;
+    R *my_used = used + ((size_t)b * nsc + sc) * 2;
+    R *my_out = outst + ((size_t)b * nsc + sc) * 2;
+    const int if_in = BWD ? sc + 1 : sc, if_out = BWD ? sc : sc + 1;
+    const bool exact_in = BWD ? (sc == last_sc) : (sc == 0);
+    R in0_u = exact_in ? (BWD ? end_u : start_u) : (R)0, in0_w = (R)0;
+    if (round > 0) {
+        if (!exact_in) { in0_u = bnd_prev[if_in * 2]; in0_w = bnd_prev[if_in * 2 + 1]; }
+        if (exact_in || (same_bits(in0_u, my_used[0]) && same_bits(in0_w, my_used[1]))) {
+            // nothing new came in: republish the last outgoing state for the next super-round
+            if (tid == 0) { bnd_cur[if_out * 2] = my_out[0]; bnd_cur[if_out * 2 + 1] = my_out[1]; }
+            return;
+        }
+    }
+    if (tid == 0) { s_any[0] = 0; s_any[1] = 0; s_any[2] = 0; }
+    R q[L], g[L], A[L], cp[L], u[L];
+    const R base_p = BWD ? fc.adecp : fc.amaxp;
+    // element e of the stage = global sample g0 + e
+    const int g0 = BWD ? base : (base > 0 ? base - 1 : 0);
+    const int n_k = (BWD ? SC + 1 : SC + (base > 0 ? 0 : 0));
+    const bool aligned = (S % (16 / (int)sizeof(R))) == 0 && (g0 % (16 / (int)sizeof(R))) == 0;
+    {
+        int n = N - g0;
+        n = n < 0 ? 0 : (n > n_k ? n_k : n);
+        stage_load<R, L>(stage, K + g0, n, n_k, aligned, tid, T);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < L; s++) {
+        const int j = base + lo + s;                                  // global owned sample
+        const bool valid = BWD ? (j <= N - 2) : (j >= 1 && j <= N - 1);
+        const int src = BWD ? j + 1 : j - 1;                          // curvature sample of the step
+        const R kabs = (R)fabs(stage[stage_pos<R, L>(valid ? src - g0 : 0)]);
+        R gdummy;
+        fast_derive(fc, kabs, (R)1, base_p, q[s], gdummy, A[s], cp[s]);
+        if (!valid) idle_coef(q[s], gdummy, A[s], cp[s]);
+        u[s] = BWD ? end_u : start_u;
+    }
+    __syncthreads();
+    {
+        int n = N - g0;
+        n = n < 0 ? 0 : (n > SC ? SC : n);
+        stage_load<R, L>(stage, DT + g0, n, SC, aligned, tid, T);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < L; s++) {
+        const int j = base + lo + s;
+        const bool valid = BWD ? (j <= N - 2) : (j >= 1 && j <= N - 1);
+        const int src = BWD ? j : j - 1;                              // dtheta sample of the step
+        const R dth = stage[stage_pos<R, L>(valid ? src - g0 : 0)];
+        const R gg = vmin(fc.gk * fast_rcp(dth), Huge<R>::v);
+        g[s] = (valid && q[s] >= (R)1e-12) ? gg : (R)0;
+    }
+    if constexpr (BWD) {
+        // forward velocities of the owned samples (idle slots hold end_u)
+        __syncthreads();
+        int n = N - base;
+        n = n < 0 ? 0 : (n > SC ? SC : n);
+        stage_load<R, L>(stage, ufwd + row + base, n, SC, (S % (16 / (int)sizeof(R))) == 0, tid, T);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < L; s++) {
+            const int j = base + lo + s;
+            if (j <= N - 2) u[s] = stage[stage_pos<R, L>(lo + s)];
+        }
+    }
+    // chunk-local incoming states
+    R in_u, in_w;
+    const int local_last = BWD ? ((N - 1 - base) / L) : 0;   // BWD: chunk holding the fixed end sample (if in range)
+    const bool bwd_has_end = BWD && sc == last_sc;
+    if constexpr (!BWD) {
+        if (tid == 0) {
+            if (!exact_in && round == 0) { in0_u = cp[0]; in0_w = in0_u * q[0]; }
+            in_u = in0_u; in_w = in0_w;
+        } else { in_u = cp[0]; in_w = in_u * q[0]; }
+    } else {
+        const bool tail = bwd_has_end ? tid >= local_last : false;
+        if (tail) { in_u = end_u; in_w = (R)0; }
+        else if (tid == T - 1) {
+            if (round == 0) { in0_u = u[L - 1]; in0_w = in0_u * q[L - 1]; }
+            in_u = in0_u; in_w = in0_w;
+        } else { in_u = u[L - 1]; in_w = in_u * q[L - 1]; }
+    }
+    const bool active = BWD ? (!bwd_has_end || tid <= local_last) : (base + lo <= N - 1);
+    bool need = active;
+    R out_u = in_u, out_w = in_w;
+    int rounds = 0;
+    __syncthreads();
+    while (true) {
+        if (need) {
+            R uu = in_u, wp = in_w;
+            if constexpr (!BWD) {
+#pragma unroll
+                for (int s = 0; s < L; s++) {
+                    if (s == 0 && tid == 0 && base == 0) continue;   // sample 0 is the given start velocity
+                    uu = any_dup ? fast_forward<true>(fc, q[s], g[s], A[s], cp[s], uu, wp, Huge<R>::v)
+                                 : fast_forward<false>(fc, q[s], g[s], A[s], cp[s], uu, wp, Huge<R>::v);
+                    u[s] = uu;
+                }
+            } else {
+#pragma unroll
+                for (int s = L - 1; s >= 0; s--)
+                    uu = any_dup ? fast_backward<true>(fc, q[s], g[s], A[s], cp[s], uu, wp, u[s])
+                                 : fast_backward<false>(fc, q[s], g[s], A[s], cp[s], uu, wp, u[s]);
+            }
+            out_u = uu;
+            out_w = wp;
+        }
+        const int pb = rounds & 1;
+        s_u[pb][tid + (BWD ? 0 : 1)] = out_u;
+        s_w[pb][tid + (BWD ? 0 : 1)] = out_w;
+        if (tid == 0) s_any[(rounds + 1) % 3] = 0;
+        __syncthreads();
+        if (rounds > 0 && s_any[(rounds - 1) % 3] == 0) break;
+        need = false;
+        const bool has_nb = BWD ? (tid < T - 1 && (!bwd_has_end || tid < local_last)) : (tid > 0 && active);
+        if (has_nb) {
+            const R nu = s_u[pb][BWD ? tid + 1 : tid], nw = s_w[pb][BWD ? tid + 1 : tid];
+            need = !(same_bits(nu, in_u) && same_bits(nw, in_w));
+            in_u = nu;
+            in_w = nw;
+        }
+        if (need) s_any[rounds % 3] = 1;
+        rounds++;
+        if (rounds > T + 3) {
+            if (tid == 0 && flags) atomicOr(&flags[b], VAP_FLAG_NOCONVERGE_BIT);
+            break;
+        }
+    }
+    if constexpr (BWD) {
+        if (active) {
+            R uu = in_u, wp = in_w;
+#pragma unroll
+            for (int s = L - 1; s >= 0; s--) {
+                uu = any_dup ? fast_backward<true>(fc, q[s], g[s], A[s], cp[s], uu, wp, u[s])
+                             : fast_backward<false>(fc, q[s], g[s], A[s], cp[s], uu, wp, u[s]);
+                u[s] = uu;
+            }
+        }
+    }
+    // publish the super-chunk's outgoing interface state
+    const int pbl = (rounds) & 1;   // parity of the last published buffer
+    const int owner = BWD ? 0 : T - 1;
+    if (tid == owner) {
+        const R ou = BWD ? out_u : s_u[pbl][T], ow = BWD ? out_w : s_w[pbl][T];
+        const bool diff = round == 0 || !(same_bits(ou, bnd_prev[if_out * 2]) && same_bits(ow, bnd_prev[if_out * 2 + 1]));
+        bnd_cur[if_out * 2] = ou;
+        bnd_cur[if_out * 2 + 1] = ow;
+        my_out[0] = ou;
+        my_out[1] = ow;
+        // a guessed incoming state (super-round 0) is recorded as "never": the next super-round
+        // re-evaluates with whatever the neighbour published
+        const bool guessed = round == 0 && !exact_in;
+        my_used[0] = guessed ? (R)NAN : in0_u;
+        my_used[1] = guessed ? (R)NAN : in0_w;
+        if (diff) atomicAdd(changed, 1);
+    }
+    // rows leave through the stage: forward -> u (squared velocity) scratch, backward -> final velocity
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < L; s++) {
+        const int j = base + lo + s;
+        stage[stage_pos<R, L>(lo + s)] = BWD ? (j < N ? sqrt(u[s]) : (R)0) : u[s];
+    }
+    __syncthreads();
+    R *dst = (BWD ? vel : ufwd) + row + base;
+    int n = S - base;
+    n = n > SC ? SC : n;
+    for (int i = tid; i < n; i += T) dst[i] = stage[stage_pos<R, L>(i)];
+    if (BWD && sc == last_sc)
+        for (int j = (last_sc + 1) * SC + tid; j < S; j += T) vel[row + j] = (R)0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Segment blocks -> monomial coefficients (scratch used by k_sample).
 // ------------------------------------------------------------------------------------------------
 __global__ void k_power(int n_seg, const double *__restrict__ segments, double *__restrict__ power)
@@ -1055,6 +1290,69 @@ hipError_t launch_velocity_relax(hipStream_t st, bool f64, int B, int S, const d
     else VAP_RELAX(float, 40, 512, 2);
 #undef VAP_RELAX
     return hipGetLastError();
+}
+
+template <typename R, int L, int MAXT, int MINW>
+static hipError_t velocity_long_t(hipStream_t st, int B, int S, const double c[6], double sv, double ev,
+                                  const double *meta, const void *curv, const void *dth, void *vel, uint32_t *flags,
+                                  void *ufwd, void *state, int *counters)
+{
+    constexpr int SC = MAXT * L;
+    const int nsc = (S + SC - 1) / SC;
+    const R s = (R)sv, e = (R)ev;
+    const size_t lds = sizeof(R) * ((size_t)MAXT * L + MAXT + 8);
+    // state layout: bnd [2][B][nsc+1][2] | used [B][nsc][2] | outst [B][nsc][2]
+    R *bnd = (R *)state;
+    R *used = bnd + (size_t)2 * B * (nsc + 1) * 2;
+    R *outst = used + (size_t)B * nsc * 2;
+    int *dup = counters;            // [B]
+    int *changed = counters + B;    // [2 * (nsc + 2)] one counter per super-round and direction
+    hipError_t err;
+    if ((err = hipMemsetAsync(counters, 0, sizeof(int) * ((size_t)B + 2 * (nsc + 2)), st)) != hipSuccess) return err;
+    hipLaunchKernelGGL(k_dup_scan, dim3(64, B), dim3(256), 0, st, B, S, meta, sizeof(R) == 4 ? (const float *)curv : nullptr,
+                       sizeof(R) == 8 ? (const double *)curv : nullptr, sizeof(R) == 4 ? (const float *)dth : nullptr,
+                       sizeof(R) == 8 ? (const double *)dth : nullptr, dup);
+    for (int dir = 0; dir < 2; dir++) {
+        for (int round = 0; round <= nsc + 1; round++) {
+            int *ch = changed + dir * (nsc + 2) + round;
+            if (dir == 0)
+                hipLaunchKernelGGL((k_velocity_long<R, L, MAXT, MINW, false>), dim3(nsc, B), dim3(MAXT), lds, st, S, nsc,
+                                   round, make_consts<R>(c), s * s, e * e, meta, (const R *)curv, (const R *)dth,
+                                   (R *)ufwd, (R *)vel, bnd, used, outst, dup, ch, flags);
+            else
+                hipLaunchKernelGGL((k_velocity_long<R, L, MAXT, MINW, true>), dim3(nsc, B), dim3(MAXT), lds, st, S, nsc,
+                                   round, make_consts<R>(c), s * s, e * e, meta, (const R *)curv, (const R *)dth,
+                                   (R *)ufwd, (R *)vel, bnd, used, outst, dup, ch, flags);
+            if ((err = hipGetLastError()) != hipSuccess) return err;
+            // super-round convergence is decided on the host: one 4-byte read per super-round
+            int h = 0;
+            if ((err = hipMemcpyAsync(&h, ch, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return err;
+            if ((err = hipStreamSynchronize(st)) != hipSuccess) return err;
+            if (round > 0 && h == 0) break;
+        }
+    }
+    return hipSuccess;
+}
+
+size_t velocity_long_state_bytes(bool f64, int B, int S)
+{
+    const int SC = f64 ? 512 * 16 : 256 * 40;
+    const int nsc = (S + SC - 1) / SC;
+    return (f64 ? 8 : 4) * ((size_t)2 * B * (nsc + 1) * 2 + (size_t)2 * B * nsc * 2) + 64;
+}
+size_t velocity_long_counter_bytes(bool f64, int B, int S)
+{
+    const int SC = f64 ? 512 * 16 : 256 * 40;
+    const int nsc = (S + SC - 1) / SC;
+    return sizeof(int) * ((size_t)B + 2 * (nsc + 2)) + 64;
+}
+
+hipError_t launch_velocity_long(hipStream_t st, bool f64, int B, int S, const double c[6], double sv, double ev,
+                                const double *meta, const void *curv, const void *dth, void *vel, uint32_t *flags,
+                                void *ufwd, void *state, int *counters)
+{
+    if (f64) return velocity_long_t<double, 16, 512, 2>(st, B, S, c, sv, ev, meta, curv, dth, vel, flags, ufwd, state, counters);
+    return velocity_long_t<float, 40, 256, 2>(st, B, S, c, sv, ev, meta, curv, dth, vel, flags, ufwd, state, counters);
 }
 
 hipError_t launch_power(hipStream_t st, int n_seg, const double *seg, double *pw)
