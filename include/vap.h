@@ -165,6 +165,62 @@ int vap_eval_host(vap_ctx *ctx, int W, const double *h_segments, double param_la
 int vap_lookup_host(vap_ctx *ctx, int W, const double *h_segments, double param_last,
                     const double *h_lut, int what, int n, const double *h_in, double *h_out);
 
+/* ---- one general route (reverse / turn nodes, per-node limits, action points), fp64 -------------
+ * The completeness path behind the drop-in classes: everything generate_motion_profile needs for a
+ * GUI route, on the device.  Host buffers in, host buffers out; sizes are GUI-sized. */
+
+/* Node / action-point attributes the path code reads (gui/node.py:17-51, gui/action_point.py:16-41).
+ * Any attribute array may be NULL (= the GUI defaults: False / 0 / None). */
+typedef struct {
+    int n_nodes;                    /* W */
+    const double *waypoints;        /* [W][2] feet */
+    const int *is_reverse;          /* [W] */
+    const double *turn;             /* [W] degrees */
+    const int *stop;                /* [W] */
+    const double *wait_time;        /* [W] seconds */
+    const double *max_velocity;     /* [W] 0 = unset */
+    const double *max_acceleration; /* [W] 0 = unset */
+    const double *tangent;          /* [W][2], NaN row = None */
+    const double *magnitudes;       /* [W][2] incoming, outgoing */
+    int n_actions;                  /* M */
+    const double *ap_t;             /* [M] path parameter */
+    const int *ap_stop;
+    const double *ap_wait_time, *ap_max_velocity, *ap_max_acceleration;
+} vap_route_desc;
+
+typedef struct vap_route vap_route;
+
+/* SM:42-172 build_path (splits at reverse / turn nodes, SM:84-158 split tangents), QHS:30-219 fit per
+ * spline (quirk Q3 kept), SM:426-475 lookup table.  VAP_ERR_INVALID where the reference returns
+ * False or raises (fewer than 2 nodes; reverse/turn attribute on the last node). */
+int vap_route_create(vap_ctx *ctx, const vap_route_desc *desc, vap_route **out);
+int vap_route_destroy(vap_route *route);
+/* number of splines and lookup_table.total_length (SM:320-330) */
+int vap_route_info(vap_route *route, int *n_splines, double *total_length);
+/* Per-spline results for the host mirrors of the drop-in classes; any pointer may be NULL.
+ * start/npts/param_last [n_splines]; segments [(W-1)][6][2]; segment_lengths [W-1];
+ * lut_distances / lut_parameters [n_splines*1000] = PathLookupTable (SM:466-475). */
+int vap_route_get_splines(vap_route *route, int *h_start, int *h_npts, double *h_param_last, double *h_segments,
+                          double *h_segment_lengths, double *h_lut_distances, double *h_lut_parameters);
+/* SM:204-241 at n global parameters; order 0/1/2; out [n][2]. */
+int vap_route_eval(vap_route *route, int order, int n, const double *h_t, double *h_out);
+/* what: 0 = SM:291-318 distance_to_time, 1 = SM:340-346 get_curvature, 2 = SM:332-338 get_heading. */
+int vap_route_lookup(vap_route *route, int what, int n, const double *h_in, double *h_out);
+/* Samples forward_backward_pass produces for spacing dd (MPG:112-122, 172-175). */
+int vap_route_sample_count(vap_route *route, double dd, int *n_out);
+/* MPG:70-316 with node / action-point limits (MPG:100-163) and boundary_map (MPG:194-196, 256-257).
+ * Outputs (capacity each, any may be NULL): parameter t, x, y, heading, curvature, velocity. */
+int vap_route_forward_backward(vap_route *route, const vap_constraints *c, double dd, double start_vel,
+                               double end_vel, int capacity, int *n_out, double *h_t, double *h_x, double *h_y,
+                               double *h_heading, double *h_curvature, double *h_velocity);
+/* MPG:389-628 incl. in-place turns (MPG:319-346, one_dim_mp_generator.py:4-69) and waits.
+ * rows [capacity_rows][8] = {time, position, linear_vel, acceleration, heading, angular_vel, x, y};
+ * nodes_map (capacity W+1) / actions_map (capacity M+1) receive row indices (MPG:420, 528, 550).
+ * VAP_ERR_CAPACITY if more rows are needed; VAP_ERR_INVALID where the reference raises (turn at node 0). */
+int vap_route_motion_profile(vap_route *route, const vap_constraints *c, double dt, double dd, long capacity_rows,
+                             double *h_rows, long *n_rows, long *h_nodes_map, int *n_nodes_map,
+                             long *h_actions_map, int *n_actions_map);
+
 #ifdef __cplusplus
 }
 #endif

@@ -118,9 +118,15 @@ def test_failure_modes(mods):
     t = s.get_parameter_by_arc_length(1.0)
     assert s.get_arc_length(0, t) == pytest.approx(1.0, abs=1e-6)
     nodes = [Node() for _ in wp]
-    nodes[3].is_reverse_node = True
-    with pytest.raises(NotImplementedError):
+    nodes[-1].is_reverse_node = True
+    with pytest.raises(IndexError):                                       # SM:88,97 points[i+1]
         Manager().build_path(wp, nodes, [])
+    nodes = [Node() for _ in wp]
+    nodes[0].turn = 30
+    m2 = Manager()
+    assert m2.build_path(wp, nodes, []) is True
+    with pytest.raises(IndexError):                                       # MPG:440 headings[-1] of []
+        mpg.generate_motion_profile(m2, mpg.Constraints(4.0, 8.0, 8.0, 0.8, 16.0, 12.5 / 12))
 
 
 def test_redraw_polyline_vector_call(mods):
@@ -134,3 +140,91 @@ def test_redraw_polyline_vector_call(mods):
         np.testing.assert_array_equal(pts[i], m.get_point_at_parameter(ts[i]))
     np.testing.assert_allclose(pts[0], g["waypoints"][0], atol=1e-14)
     np.testing.assert_allclose(pts[-1], g["waypoints"][-1], atol=1e-14)
+
+
+def build_route(mods, g):
+    """Manager for any golden case, node and action-point attributes included."""
+    Manager, _, Node, ActionPoint = mods
+    wp = g["waypoints"]
+    nodes = []
+    for i in range(len(wp)):
+        n = Node(is_reverse_node=bool(g["node_is_reverse_node"][i]), turn=float(g["node_turn"][i]),
+                 wait_time=float(g["node_wait_time"][i]), stop=bool(g["node_stop"][i]),
+                 max_velocity=float(g["node_max_velocity"][i]), max_acceleration=float(g["node_max_acceleration"][i]))
+        if not np.isnan(g["node_tangent"][i][0]):
+            n.tangent = g["node_tangent"][i].copy()
+            n.incoming_magnitude, n.outgoing_magnitude = (float(v) for v in g["node_magnitudes"][i])
+        nodes.append(n)
+    aps = []
+    if "ap_t" in g.files:
+        for j in range(len(g["ap_t"])):
+            aps.append(ActionPoint(t=float(g["ap_t"][j]), stop=bool(g["ap_stop"][j]), wait_time=float(g["ap_wait_time"][j]),
+                                   max_velocity=float(g["ap_max_velocity"][j]),
+                                   max_acceleration=float(g["ap_max_acceleration"][j])))
+    m = Manager()
+    assert m.build_path(wp, nodes, aps) is True
+    return m
+
+
+FEATURES = gu.names("feat_")
+
+
+@pytest.mark.parametrize("name", FEATURES)
+def test_feature_routes_fit_and_tables(mods, name):
+    """Reverse / turn splits (several splines, split tangents, quirk Q3), tangent overrides."""
+    g = gu.load(name)
+    m = build_route(mods, g)
+    ns = int(g["n_splines"])
+    assert len(m.splines) == ns
+    for i, sp in enumerate(m.splines):
+        np.testing.assert_allclose(np.array(sp.segments), g[f"spline{i}_segments"], rtol=1e-14, atol=1e-15)
+        np.testing.assert_allclose(sp.segment_lengths, g[f"spline{i}_segment_lengths"], rtol=1e-15)
+        assert sp.parameters[-1] == float(g[f"spline{i}_param_last"])
+        assert len(sp.control_points) == int(g[f"spline{i}_n_points"])
+    m.rebuild_tables()
+    np.testing.assert_allclose(m.lookup_table.distances, g["lut_distances"], rtol=1e-14, atol=1e-15)
+    np.testing.assert_allclose(m.lookup_table.parameters, g["lut_parameters"], rtol=1e-15)
+    assert m.get_total_arc_length() == pytest.approx(float(g["total_length"]), rel=1e-14)
+
+
+@pytest.mark.parametrize("name", FEATURES)
+def test_feature_routes_forward_backward(mods, name):
+    """Per-node stop / max_velocity / max_acceleration, action points, boundary_map (MPG:100-163, 194-196, 256-257)."""
+    _, mpg, _, _ = mods
+    g = gu.load(name)
+    m = build_route(mods, g)
+    c = mpg.Constraints(*g["constraints"])
+    m.rebuild_tables()
+    v = np.array(mpg.forward_backward_pass(m, c, float(g["dd"])))
+    assert len(v) == int(g["n_samples"])
+    np.testing.assert_allclose(v[g["grid_idx"]], g["grid_velocity"], rtol=1e-9)
+    out, n = m._dev().forward_backward(c, float(g["dd"]), 0.01, 0.01, want=("t", "x", "y", "heading", "curvature"))
+    gi = g["grid_idx"]
+    np.testing.assert_allclose(out["t"][gi], g["grid_t"], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(out["curvature"][gi], g["grid_curvature"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(out["heading"][gi], g["grid_heading"], atol=1e-11)
+    np.testing.assert_allclose(out["x"][gi], g["grid_x"], rtol=1e-11, atol=1e-12)
+
+
+PROFILES = [n for n in gu.names() if "profile_times" in gu.load(n).files]
+
+
+@pytest.mark.parametrize("name", PROFILES)
+def test_generate_motion_profile_nine_tuple(mods, name):
+    """The call gui/path.py:323-335 makes, against the reference's own 9-tuple: time-domain resample,
+    in-place turns, waits, reversal, nodes_map / actions_map."""
+    _, mpg, _, _ = mods
+    g = gu.load(name)
+    m = build_route(mods, g)
+    res = mpg.generate_motion_profile(m, mpg.Constraints(*g["constraints"]))
+    assert len(res) == 9
+    times, positions, lin, acc, head, ang, nodes_map, actions_map, coords = res
+    assert all(isinstance(x, list) for x in res)
+    T = len(g["profile_times"])
+    assert len(times) == T
+    assert nodes_map == [int(v) for v in g["profile_nodes_map"]]
+    assert actions_map == [int(v) for v in g["profile_actions_map"]]
+    for got, key in ((times, "times"), (positions, "positions"), (lin, "linear_vels"), (acc, "accelerations"),
+                     (head, "headings"), (ang, "angular_vels")):
+        np.testing.assert_allclose(got, g["profile_" + key], rtol=1e-8, atol=1e-8, err_msg=key)
+    np.testing.assert_allclose(np.array(coords), g["profile_coords"], rtol=1e-10, atol=1e-10)

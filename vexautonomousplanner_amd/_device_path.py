@@ -112,3 +112,141 @@ class DevicePath:
                    "vap_velocity_pass")
         n = int(d["meta"][0, 3].item())
         return {k: outs[k][0, :n].cpu().numpy() for k in want}, n
+
+
+class DeviceRoute:
+    """One general route (any node / action-point attributes) on the GPU: vap_route_* of include/vap.h."""
+
+    def __init__(self, points, nodes, action_points, device=0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible: vexautonomousplanner_amd has no CPU path")
+        self.ctx = _lib.default_context(device)
+        self.ctx.set_stream(torch.cuda.current_stream(torch.device("cuda", device)).cuda_stream)
+        self._L = _lib.lib()
+        pts = np.ascontiguousarray(points, dtype=np.float64)
+        W, M = len(pts), len(action_points)
+        self.W, self.M = W, M
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+
+        def dcol(vals):
+            return np.ascontiguousarray(vals, dtype=np.float64)
+
+        def icol(vals):
+            return np.ascontiguousarray([1 if v else 0 for v in vals], dtype=np.int32)
+
+        tan = np.full((W, 2), np.nan)
+        mag = np.zeros((W, 2))
+        for i, n in enumerate(nodes):
+            if n.tangent is not None:
+                tan[i] = np.asarray(n.tangent, dtype=float)
+                mag[i] = (n.incoming_magnitude, n.outgoing_magnitude)
+        keep = {
+            "wp": pts, "rev": icol(n.is_reverse_node for n in nodes), "turn": dcol([n.turn for n in nodes]),
+            "stop": icol(n.stop for n in nodes), "wait": dcol([n.wait_time for n in nodes]),
+            "maxv": dcol([n.max_velocity for n in nodes]), "maxa": dcol([n.max_acceleration for n in nodes]),
+            "tan": tan, "mag": mag,
+            "apt": dcol([a.t for a in action_points]), "aps": icol(a.stop for a in action_points),
+            "apw": dcol([a.wait_time for a in action_points]), "apv": dcol([a.max_velocity for a in action_points]),
+            "apa": dcol([a.max_acceleration for a in action_points]),
+        }
+        d = _lib.RouteDesc()
+        d.n_nodes, d.n_actions = W, M
+        d.waypoints = keep["wp"].ctypes.data_as(dp)
+        d.is_reverse = keep["rev"].ctypes.data_as(ip)
+        d.turn = keep["turn"].ctypes.data_as(dp)
+        d.stop = keep["stop"].ctypes.data_as(ip)
+        d.wait_time = keep["wait"].ctypes.data_as(dp)
+        d.max_velocity = keep["maxv"].ctypes.data_as(dp)
+        d.max_acceleration = keep["maxa"].ctypes.data_as(dp)
+        d.tangent = keep["tan"].ctypes.data_as(dp)
+        d.magnitudes = keep["mag"].ctypes.data_as(dp)
+        if M:
+            d.ap_t = keep["apt"].ctypes.data_as(dp)
+            d.ap_stop = keep["aps"].ctypes.data_as(ip)
+            d.ap_wait_time = keep["apw"].ctypes.data_as(dp)
+            d.ap_max_velocity = keep["apv"].ctypes.data_as(dp)
+            d.ap_max_acceleration = keep["apa"].ctypes.data_as(dp)
+        h = C.c_void_p()
+        st = self._L.vap_route_create(self.ctx.handle, C.byref(d), C.byref(h))
+        self.handle = None
+        if st == _lib.VAP_ERR_INVALID:
+            raise IndexError(self._L.vap_last_error().decode())   # what the reference raises (SM:88,97)
+        _lib.check(st, "vap_route_create")
+        self.handle = h
+        ns, tot = C.c_int(), C.c_double()
+        _lib.check(self._L.vap_route_info(h, C.byref(ns), C.byref(tot)), "vap_route_info")
+        self.n_splines, self.total = ns.value, tot.value
+        n = self.n_splines
+        self.sp_start = np.zeros(n, dtype=np.int32)
+        self.sp_npts = np.zeros(n, dtype=np.int32)
+        self.sp_param_last = np.zeros(n)
+        self.segments = np.zeros((W - 1, 6, 2))
+        self.segment_lengths = np.zeros(W - 1)
+        self.lut_distances = np.zeros(n * _lib.LUT_SAMPLES)
+        self.lut_parameters = np.zeros(n * _lib.LUT_SAMPLES)
+        _lib.check(self._L.vap_route_get_splines(h, self.sp_start.ctypes.data_as(ip), self.sp_npts.ctypes.data_as(ip),
+                                                 self.sp_param_last.ctypes.data_as(dp), self.segments.ctypes.data_as(dp),
+                                                 self.segment_lengths.ctypes.data_as(dp),
+                                                 self.lut_distances.ctypes.data_as(dp),
+                                                 self.lut_parameters.ctypes.data_as(dp)), "vap_route_get_splines")
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._L.vap_route_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def eval(self, order, ts):
+        ts = np.ascontiguousarray(np.atleast_1d(ts), dtype=np.float64)
+        out = np.empty((len(ts), 2))
+        dp = C.POINTER(C.c_double)
+        _lib.check(self._L.vap_route_eval(self.handle, int(order), len(ts), ts.ctypes.data_as(dp),
+                                          out.ctypes.data_as(dp)), "vap_route_eval")
+        return out
+
+    def lookup(self, what, xs):
+        xs = np.ascontiguousarray(np.atleast_1d(xs), dtype=np.float64)
+        out = np.empty(len(xs))
+        dp = C.POINTER(C.c_double)
+        _lib.check(self._L.vap_route_lookup(self.handle, int(what), len(xs), xs.ctypes.data_as(dp),
+                                            out.ctypes.data_as(dp)), "vap_route_lookup")
+        return out
+
+    def forward_backward(self, constraints, dd, start_vel, end_vel, want=("velocity",)):
+        n = C.c_int()
+        _lib.check(self._L.vap_route_sample_count(self.handle, float(dd), C.byref(n)), "vap_route_sample_count")
+        N = n.value
+        dp = C.POINTER(C.c_double)
+        names = ("t", "x", "y", "heading", "curvature", "velocity")
+        bufs = {k: (np.empty(N) if k in want else None) for k in names}
+        c = _lib.make_constraints(constraints)
+        args = [bufs[k].ctypes.data_as(dp) if bufs[k] is not None else None for k in names]
+        _lib.check(self._L.vap_route_forward_backward(self.handle, C.byref(c), float(dd), float(start_vel),
+                                                      float(end_vel), N, C.byref(n), *args), "vap_route_forward_backward")
+        return {k: v for k, v in bufs.items() if v is not None}, N
+
+    def motion_profile(self, constraints, dt, dd):
+        c = _lib.make_constraints(constraints)
+        cap = int(self.total / 0.0005) + 4096
+        dp, lp = C.POINTER(C.c_double), C.POINTER(C.c_long)
+        for _ in range(4):
+            rows = np.empty((cap, 8))
+            nmap = np.zeros(self.W + 2, dtype=np.int64)
+            amap = np.zeros(self.M + 2, dtype=np.int64)
+            T, nn, na = C.c_long(), C.c_int(), C.c_int()
+            st = self._L.vap_route_motion_profile(self.handle, C.byref(c), float(dt), float(dd), cap,
+                                                  rows.ctypes.data_as(dp), C.byref(T), nmap.ctypes.data_as(lp),
+                                                  C.byref(nn), amap.ctypes.data_as(lp), C.byref(na))
+            if st == _lib.VAP_ERR_CAPACITY:
+                cap *= 4
+                continue
+            if st == _lib.VAP_ERR_INVALID:
+                raise IndexError(self._L.vap_last_error().decode())   # MPG:440 / 499 in the reference
+            _lib.check(st, "vap_route_motion_profile")
+            return rows[:T.value], nmap[:nn.value], amap[:na.value]
+        raise RuntimeError("motion profile did not fit the row buffer")

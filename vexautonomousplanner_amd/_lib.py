@@ -35,6 +35,8 @@ EXPORTS = (
     "vap_ctx_set_timing",
     "vap_last_timing", "vap_fit", "vap_build_lut", "vap_sample", "vap_velocity_pass",
     "vap_profile_batch", "vap_profile_batch_host", "vap_eval_host", "vap_lookup_host",
+    "vap_route_create", "vap_route_destroy", "vap_route_info", "vap_route_get_splines", "vap_route_eval",
+    "vap_route_lookup", "vap_route_sample_count", "vap_route_forward_backward", "vap_route_motion_profile",
 )
 
 
@@ -42,6 +44,20 @@ class Constraints(C.Structure):
     """vap_constraints == motion_profile_generator.Constraints field order (MPG:14-21)."""
     _fields_ = [("max_vel", C.c_double), ("max_acc", C.c_double), ("max_dec", C.c_double),
                 ("friction_coef", C.c_double), ("max_jerk", C.c_double), ("track_width", C.c_double)]
+
+
+ip = C.POINTER(C.c_int)
+
+
+class RouteDesc(C.Structure):
+    """vap_route_desc (include/vap.h)."""
+    _fields_ = [("n_nodes", C.c_int), ("waypoints", C.POINTER(C.c_double)), ("is_reverse", C.POINTER(C.c_int)),
+                ("turn", C.POINTER(C.c_double)), ("stop", C.POINTER(C.c_int)), ("wait_time", C.POINTER(C.c_double)),
+                ("max_velocity", C.POINTER(C.c_double)), ("max_acceleration", C.POINTER(C.c_double)),
+                ("tangent", C.POINTER(C.c_double)), ("magnitudes", C.POINTER(C.c_double)),
+                ("n_actions", C.c_int), ("ap_t", C.POINTER(C.c_double)), ("ap_stop", C.POINTER(C.c_int)),
+                ("ap_wait_time", C.POINTER(C.c_double)), ("ap_max_velocity", C.POINTER(C.c_double)),
+                ("ap_max_acceleration", C.POINTER(C.c_double))]
 
 
 class VapError(RuntimeError):
@@ -94,6 +110,18 @@ def lib():
     L.vap_profile_batch_host.argtypes = L.vap_profile_batch.argtypes
     L.vap_eval_host.argtypes = [vp, C.c_int, dp, C.c_double, C.c_int, C.c_int, dp, dp]
     L.vap_lookup_host.argtypes = [vp, C.c_int, dp, C.c_double, dp, C.c_int, C.c_int, dp, dp]
+    lp = C.POINTER(C.c_long)
+    L.vap_route_create.argtypes = [vp, C.POINTER(RouteDesc), C.POINTER(vp)]
+    L.vap_route_destroy.argtypes = [vp]
+    L.vap_route_info.argtypes = [vp, ip, dp]
+    L.vap_route_get_splines.argtypes = [vp, ip, ip, dp, dp, dp, dp, dp]
+    L.vap_route_eval.argtypes = [vp, C.c_int, C.c_int, dp, dp]
+    L.vap_route_lookup.argtypes = [vp, C.c_int, C.c_int, dp, dp]
+    L.vap_route_sample_count.argtypes = [vp, C.c_double, ip]
+    L.vap_route_forward_backward.argtypes = [vp, C.POINTER(Constraints), C.c_double, C.c_double, C.c_double,
+                                             C.c_int, ip, dp, dp, dp, dp, dp, dp]
+    L.vap_route_motion_profile.argtypes = [vp, C.POINTER(Constraints), C.c_double, C.c_double, C.c_long, dp, lp,
+                                           lp, ip, lp, ip]
     for name in EXPORTS:
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ("vap_version", "vap_device_count"):

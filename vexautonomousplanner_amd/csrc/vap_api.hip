@@ -3,22 +3,16 @@
 // Host-side runtime: context (device + stream + scratch arena + stage timers) and the entry points
 // that sequence the kernels of vap_kernels.hip.  There is deliberately no CPU implementation behind
 // any entry point: without a HIP device every call fails with VAP_ERR_NO_DEVICE.
-#include "../../include/vap.h"
-
-#include <hip/hip_runtime.h>
-
-#include <cstdarg>
-#include <cstdio>
 #include <cstring>
-#include <string>
 
+#include "vap_internal.h"
 #include "vap_kernels.h"
 
 namespace {
-
 thread_local std::string g_last_error;
+}  // namespace
 
-int fail(int status, const char *fmt, ...)
+int vap_fail(int status, const char *fmt, ...)
 {
     char buf[512];
     va_list ap;
@@ -29,53 +23,12 @@ int fail(int status, const char *fmt, ...)
     return status;
 }
 
-#define HIP_TRY(expr)                                                                              \
-    do {                                                                                           \
-        hipError_t e_ = (expr);                                                                    \
-        if (e_ != hipSuccess)                                                                      \
-            return fail(VAP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-    } while (0)
-
-struct Buffer {
-    void *ptr = nullptr;
-    size_t cap = 0;
-};
-
-}  // namespace
-
-struct vap_ctx {
-    int device = 0;
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
-    bool timing = false;
-    int velocity_kernel = 0;  // VAP_OPT_VELOCITY_KERNEL
-    hipEvent_t ev[VAP_T_COUNT + 1] = {};
-    float ms[VAP_T_COUNT] = {};
-    // scratch arena (grow-only, reused across calls)
-    Buffer seg, power, lut, slopes, aux, meta, dth, flags, io[8], small_in, small_out, small_seg, small_lut;
-    Buffer ufwd, lstate, lcount;   // long-row velocity pass
-
-    int ensure(Buffer &b, size_t bytes)
-    {
-        if (bytes <= b.cap) return VAP_OK;
-        if (b.ptr) {
-            HIP_TRY(hipStreamSynchronize(stream));
-            HIP_TRY(hipFree(b.ptr));
-            b.ptr = nullptr;
-            b.cap = 0;
-        }
-        size_t want = bytes + bytes / 8 + 256;
-        HIP_TRY(hipMalloc(&b.ptr, want));
-        b.cap = want;
-        return VAP_OK;
-    }
-};
-
-#define VAP_TRY(expr)            \
-    do {                         \
-        int s_ = (expr);         \
-        if (s_ != VAP_OK) return s_; \
-    } while (0)
+int vap_set_device(vap_ctx *ctx)
+{
+    if (!ctx) return vap_fail(VAP_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return VAP_OK;
+}
 
 namespace {
 
@@ -91,21 +44,14 @@ struct StageTimer {
     }
 };
 
-int set_device(vap_ctx *ctx)
-{
-    if (!ctx) return fail(VAP_ERR_INVALID, "null context");
-    HIP_TRY(hipSetDevice(ctx->device));
-    return VAP_OK;
-}
-
 size_t esz(vap_dtype dt) { return dt == VAP_F64 ? 8 : 4; }
 
 int check_shape(int B, int W, int S)
 {
-    if (B < 1) return fail(VAP_ERR_INVALID, "batch must be >= 1 (got %d)", B);
-    if (W < 2) return fail(VAP_ERR_INVALID, "a path needs at least 2 waypoints (got %d)", W);  // SM:50-51
-    if (W > vap::kMaxWaypoints) return fail(VAP_ERR_UNSUPPORTED, "W=%d exceeds %d", W, vap::kMaxWaypoints);
-    if (S < 2) return fail(VAP_ERR_INVALID, "sample capacity must be >= 2 (got %d)", S);
+    if (B < 1) return vap_fail(VAP_ERR_INVALID, "batch must be >= 1 (got %d)", B);
+    if (W < 2) return vap_fail(VAP_ERR_INVALID, "a path needs at least 2 waypoints (got %d)", W);  // SM:50-51
+    if (W > vap::kMaxWaypoints) return vap_fail(VAP_ERR_UNSUPPORTED, "W=%d exceeds %d", W, vap::kMaxWaypoints);
+    if (S < 2) return vap_fail(VAP_ERR_INVALID, "sample capacity must be >= 2 (got %d)", S);
     return VAP_OK;
 }
 
@@ -117,7 +63,7 @@ int run_velocity(vap_ctx *ctx, bool f64, int B, int S, const double cc[6], doubl
     int mode = ctx->velocity_kernel;
     if (mode == VAP_VELOCITY_AUTO) mode = vcap ? VAP_VELOCITY_SEQ_FAST : VAP_VELOCITY_RELAX;
     if (mode == VAP_VELOCITY_RELAX) {
-        if (vcap) return fail(VAP_ERR_UNSUPPORTED, "relaxation kernel: per-sample caps are not supported yet");
+        if (vcap) return vap_fail(VAP_ERR_UNSUPPORTED, "relaxation kernel: per-sample caps are not supported yet");
         if (S <= vap::velocity_relax_max_samples(f64)) {
             HIP_TRY(vap::launch_velocity_relax(ctx->stream, f64, B, S, cc, sv, ev, meta, curv, dth, vel, flags));
         } else {
@@ -166,24 +112,24 @@ int vap_device_count(void)
 
 int vap_ctx_create(int device, vap_ctx **out)
 {
-    if (!out) return fail(VAP_ERR_INVALID, "null out pointer");
+    if (!out) return vap_fail(VAP_ERR_INVALID, "null out pointer");
     *out = nullptr;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n < 1)
-        return fail(VAP_ERR_NO_DEVICE, "no HIP device visible: libvap has no CPU path");
-    if (device < 0 || device >= n) return fail(VAP_ERR_INVALID, "device %d out of range [0,%d)", device, n);
+        return vap_fail(VAP_ERR_NO_DEVICE, "no HIP device visible: libvap has no CPU path");
+    if (device < 0 || device >= n) return vap_fail(VAP_ERR_INVALID, "device %d out of range [0,%d)", device, n);
     HIP_TRY(hipSetDevice(device));
     vap_ctx *c = new vap_ctx();
     c->device = device;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
-        return fail(VAP_ERR_HIP, "hipStreamCreate failed");
+        return vap_fail(VAP_ERR_HIP, "hipStreamCreate failed");
     }
     c->stream = c->own_stream;
     for (auto &e : c->ev) {
         if (hipEventCreate(&e) != hipSuccess) {
             delete c;
-            return fail(VAP_ERR_HIP, "hipEventCreate failed");
+            return vap_fail(VAP_ERR_HIP, "hipEventCreate failed");
         }
     }
     *out = c;
@@ -195,11 +141,11 @@ int vap_ctx_destroy(vap_ctx *ctx)
     if (!ctx) return VAP_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    Buffer *bufs[] = {&ctx->ufwd, &ctx->lstate, &ctx->lcount, &ctx->seg, &ctx->power, &ctx->lut, &ctx->slopes, &ctx->aux, &ctx->meta, &ctx->dth, &ctx->flags, &ctx->small_in,
+    VapBuffer *bufs[] = {&ctx->ufwd, &ctx->lstate, &ctx->lcount, &ctx->seg, &ctx->power, &ctx->lut, &ctx->slopes, &ctx->aux, &ctx->meta, &ctx->dth, &ctx->flags, &ctx->small_in,
                       &ctx->small_out, &ctx->small_seg, &ctx->small_lut};
-    for (Buffer *b : bufs)
+    for (VapBuffer *b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
-    for (Buffer &b : ctx->io)
+    for (VapBuffer &b : ctx->io)
         if (b.ptr) (void)hipFree(b.ptr);
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
@@ -210,39 +156,39 @@ int vap_ctx_destroy(vap_ctx *ctx)
 
 int vap_ctx_set_stream(vap_ctx *ctx, void *hip_stream)
 {
-    if (!ctx) return fail(VAP_ERR_INVALID, "null context");
+    if (!ctx) return vap_fail(VAP_ERR_INVALID, "null context");
     ctx->stream = hip_stream == VAP_STREAM_OWN ? ctx->own_stream : (hipStream_t)hip_stream;
     return VAP_OK;
 }
 
 int vap_ctx_synchronize(vap_ctx *ctx)
 {
-    VAP_TRY(set_device(ctx));
+    VAP_TRY(vap_set_device(ctx));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return VAP_OK;
 }
 
 int vap_ctx_set_option(vap_ctx *ctx, int option, int value)
 {
-    if (!ctx) return fail(VAP_ERR_INVALID, "null context");
+    if (!ctx) return vap_fail(VAP_ERR_INVALID, "null context");
     if (option == VAP_OPT_VELOCITY_KERNEL && value >= VAP_VELOCITY_AUTO && value <= VAP_VELOCITY_RELAX) {
         ctx->velocity_kernel = value;
         return VAP_OK;
     }
-    return fail(VAP_ERR_INVALID, "unknown option %d / value %d", option, value);
+    return vap_fail(VAP_ERR_INVALID, "unknown option %d / value %d", option, value);
 }
 
 int vap_ctx_set_timing(vap_ctx *ctx, int enabled)
 {
-    if (!ctx) return fail(VAP_ERR_INVALID, "null context");
+    if (!ctx) return vap_fail(VAP_ERR_INVALID, "null context");
     ctx->timing = enabled != 0;
     return VAP_OK;
 }
 
 int vap_last_timing(vap_ctx *ctx, float ms[VAP_T_COUNT])
 {
-    VAP_TRY(set_device(ctx));
-    if (!ms) return fail(VAP_ERR_INVALID, "null output");
+    VAP_TRY(vap_set_device(ctx));
+    if (!ms) return vap_fail(VAP_ERR_INVALID, "null output");
     for (int i = 0; i < VAP_T_COUNT; i++) ms[i] = 0.f;
     if (!ctx->timing) return VAP_OK;
     HIP_TRY(hipEventSynchronize(ctx->ev[VAP_T_VELOCITY + 1]));
@@ -261,9 +207,9 @@ int vap_fit(vap_ctx *ctx, vap_dtype dt, int B, int W, const void *d_waypoints, c
             const double *d_tangent_out, double *d_segments, double *d_segment_lengths, double *d_meta,
             uint32_t *d_flags)
 {
-    VAP_TRY(set_device(ctx));
+    VAP_TRY(vap_set_device(ctx));
     VAP_TRY(check_shape(B, W, 2));
-    if (!d_waypoints || !d_segments || !d_meta) return fail(VAP_ERR_INVALID, "null buffer");
+    if (!d_waypoints || !d_segments || !d_meta) return vap_fail(VAP_ERR_INVALID, "null buffer");
     HIP_TRY(vap::launch_fit(ctx->stream, dt == VAP_F64, B, W, d_waypoints, d_tangent_in, d_tangent_out,
                             d_segments, nullptr, d_segment_lengths, d_meta, d_flags));
     return VAP_OK;
@@ -272,9 +218,9 @@ int vap_fit(vap_ctx *ctx, vap_dtype dt, int B, int W, const void *d_waypoints, c
 int vap_build_lut(vap_ctx *ctx, int B, int W, const double *d_segments, double *d_lut, double *d_meta,
                   uint32_t *d_flags)
 {
-    VAP_TRY(set_device(ctx));
+    VAP_TRY(vap_set_device(ctx));
     VAP_TRY(check_shape(B, W, 2));
-    if (!d_segments || !d_lut || !d_meta) return fail(VAP_ERR_INVALID, "null buffer");
+    if (!d_segments || !d_lut || !d_meta) return vap_fail(VAP_ERR_INVALID, "null buffer");
     HIP_TRY(vap::launch_lut(ctx->stream, B, W, d_segments, d_lut, nullptr, d_meta, d_flags));
     return VAP_OK;
 }
@@ -283,9 +229,9 @@ int vap_sample(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd, const
                const double *d_lut, double *d_meta, void *d_x, void *d_y, void *d_heading, void *d_curvature,
                void *d_dtheta, uint32_t *d_flags)
 {
-    VAP_TRY(set_device(ctx));
+    VAP_TRY(vap_set_device(ctx));
     VAP_TRY(check_shape(B, W, S));
-    if (!d_segments || !d_lut || !d_meta) return fail(VAP_ERR_INVALID, "null buffer");
+    if (!d_segments || !d_lut || !d_meta) return vap_fail(VAP_ERR_INVALID, "null buffer");
     const size_t n_seg = (size_t)B * (W - 1);
     VAP_TRY(ctx->ensure(ctx->power, n_seg * 30 * sizeof(double)));
     VAP_TRY(ctx->ensure(ctx->slopes, (size_t)B * VAP_LUT_SAMPLES * sizeof(double)));
@@ -303,9 +249,9 @@ int vap_velocity_pass(vap_ctx *ctx, vap_dtype dt, int B, int S, const vap_constr
                       double end_vel, const double *d_meta, const void *d_curvature, const void *d_dtheta,
                       const void *d_vcap, void *d_velocity, uint32_t *d_flags)
 {
-    VAP_TRY(set_device(ctx));
+    VAP_TRY(vap_set_device(ctx));
     VAP_TRY(check_shape(B, 2, S));
-    if (!c || !d_meta || !d_curvature || !d_dtheta || !d_velocity) return fail(VAP_ERR_INVALID, "null buffer");
+    if (!c || !d_meta || !d_curvature || !d_dtheta || !d_velocity) return vap_fail(VAP_ERR_INVALID, "null buffer");
     const double cc[6] = {c->max_vel, c->max_acc, c->max_dec, c->friction_coef, c->max_jerk, c->track_width};
     VAP_TRY(run_velocity(ctx, dt == VAP_F64, B, S, cc, start_vel, end_vel, d_meta, d_curvature, d_dtheta, d_vcap,
                          d_velocity, d_flags));
@@ -316,9 +262,9 @@ int vap_profile_batch(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd
                       const vap_constraints *c, double start_vel, double end_vel, void *d_x, void *d_y,
                       void *d_heading, void *d_curvature, void *d_velocity, double *d_meta, uint32_t *d_flags)
 {
-    VAP_TRY(set_device(ctx));
+    VAP_TRY(vap_set_device(ctx));
     VAP_TRY(check_shape(B, W, S));
-    if (!d_waypoints || !c || !d_velocity) return fail(VAP_ERR_INVALID, "null buffer");
+    if (!d_waypoints || !c || !d_velocity) return vap_fail(VAP_ERR_INVALID, "null buffer");
     const bool f64 = dt == VAP_F64;
     const size_t n_seg = (size_t)B * (W - 1), n_pts = (size_t)B * S;
     VAP_TRY(ctx->ensure(ctx->seg, n_seg * 12 * sizeof(double)));
@@ -366,9 +312,9 @@ int vap_profile_batch_host(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, doub
                            void *h_heading, void *h_curvature, void *h_velocity, double *h_meta,
                            uint32_t *h_flags)
 {
-    VAP_TRY(set_device(ctx));
+    VAP_TRY(vap_set_device(ctx));
     VAP_TRY(check_shape(B, W, S));
-    if (!h_waypoints || !c || !h_velocity) return fail(VAP_ERR_INVALID, "null buffer");
+    if (!h_waypoints || !c || !h_velocity) return vap_fail(VAP_ERR_INVALID, "null buffer");
     const size_t n_pts = (size_t)B * S, e = esz(dt);
     VAP_TRY(ctx->ensure(ctx->io[0], (size_t)B * W * 2 * e));
     void *houts[5] = {h_x, h_y, h_heading, h_curvature, h_velocity};
@@ -398,9 +344,9 @@ int vap_profile_batch_host(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, doub
 int vap_eval_host(vap_ctx *ctx, int W, const double *h_segments, double param_last, int order, int n,
                   const double *h_t, double *h_out)
 {
-    VAP_TRY(set_device(ctx));
-    if (W < 2 || !h_segments) return fail(VAP_ERR_UNFITTED, "Spline has not been fitted yet");  // QHS:222-223
-    if (order < 0 || order > 2 || n < 0 || (n > 0 && (!h_t || !h_out))) return fail(VAP_ERR_INVALID, "bad argument");
+    VAP_TRY(vap_set_device(ctx));
+    if (W < 2 || !h_segments) return vap_fail(VAP_ERR_UNFITTED, "Spline has not been fitted yet");  // QHS:222-223
+    if (order < 0 || order > 2 || n < 0 || (n > 0 && (!h_t || !h_out))) return vap_fail(VAP_ERR_INVALID, "bad argument");
     if (n == 0) return VAP_OK;
     const size_t sb = (size_t)(W - 1) * 12 * sizeof(double);
     VAP_TRY(ctx->ensure(ctx->small_seg, sb));
@@ -419,9 +365,9 @@ int vap_eval_host(vap_ctx *ctx, int W, const double *h_segments, double param_la
 int vap_lookup_host(vap_ctx *ctx, int W, const double *h_segments, double param_last, const double *h_lut,
                     int what, int n, const double *h_in, double *h_out)
 {
-    VAP_TRY(set_device(ctx));
-    if (W < 2 || !h_segments || !h_lut) return fail(VAP_ERR_UNFITTED, "No splines have been initialized");
-    if (what < 0 || what > 2 || n < 0 || (n > 0 && (!h_in || !h_out))) return fail(VAP_ERR_INVALID, "bad argument");
+    VAP_TRY(vap_set_device(ctx));
+    if (W < 2 || !h_segments || !h_lut) return vap_fail(VAP_ERR_UNFITTED, "No splines have been initialized");
+    if (what < 0 || what > 2 || n < 0 || (n > 0 && (!h_in || !h_out))) return vap_fail(VAP_ERR_INVALID, "bad argument");
     if (n == 0) return VAP_OK;
     const size_t sb = (size_t)(W - 1) * 12 * sizeof(double);
     VAP_TRY(ctx->ensure(ctx->small_seg, sb));

@@ -1,0 +1,59 @@
+// vap_internal.h — context and error plumbing shared by the C-ABI translation units.
+#pragma once
+#include "../../include/vap.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+
+int vap_fail(int status, const char *fmt, ...);
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return vap_fail(VAP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+#define VAP_TRY(expr)            \
+    do {                         \
+        int s_ = (expr);         \
+        if (s_ != VAP_OK) return s_; \
+    } while (0)
+
+struct VapBuffer {
+    void *ptr = nullptr;
+    size_t cap = 0;
+};
+
+struct vap_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    bool timing = false;
+    int velocity_kernel = 0;  // VAP_OPT_VELOCITY_KERNEL
+    hipEvent_t ev[VAP_T_COUNT + 1] = {};
+    float ms[VAP_T_COUNT] = {};
+    // scratch arena (grow-only, reused across calls)
+    VapBuffer seg, power, lut, slopes, aux, meta, dth, flags, io[8], small_in, small_out, small_seg, small_lut;
+    VapBuffer ufwd, lstate, lcount;   // long-row velocity pass
+
+    int ensure(VapBuffer &b, size_t bytes)
+    {
+        if (bytes <= b.cap) return VAP_OK;
+        if (b.ptr) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            HIP_TRY(hipFree(b.ptr));
+            b.ptr = nullptr;
+            b.cap = 0;
+        }
+        size_t want = bytes + bytes / 8 + 256;
+        HIP_TRY(hipMalloc(&b.ptr, want));
+        b.cap = want;
+        return VAP_OK;
+    }
+};
+
+int vap_set_device(vap_ctx *ctx);

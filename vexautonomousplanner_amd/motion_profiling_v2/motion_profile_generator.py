@@ -2,11 +2,10 @@
 (motion_profiling_v2/motion_profile_generator.py:14-646), the heavy parts on the device.
 
   Constraints                -> same dataclass, same helper methods                      MPG:14-67
-  forward_backward_pass      -> K3+K4 sampling and K5 velocity pass (vap_sample, vap_velocity_pass)  MPG:70-316
-  generate_motion_profile    -> rebuild_tables + forward_backward_pass on the device, then the
-                                time-domain resample                MPG:389-628
-Plain nodes only for now: per-node stop / velocity / acceleration limits and action points
-(MPG:100-163) are SURVEY §8(f) rank 2.
+  forward_backward_pass      -> vap_route_forward_backward: sampling, node / action-point limits,
+                                boundary_map, forward and backward sweeps                 MPG:70-316
+  generate_motion_profile    -> vap_route_motion_profile: the above plus the time-domain resample
+                                with turn / wait insertion                                MPG:389-628
 """
 import math
 from dataclasses import dataclass
@@ -54,19 +53,9 @@ class Constraints:
         return linear_vel - half, linear_vel + half
 
 
-def _plain_route(spline_manager) -> bool:
-    for n in spline_manager.nodes:
-        if n.stop or n.max_velocity > 0 or n.max_acceleration > 0:
-            return False
-    return len(spline_manager.action_points) == 0
-
-
 def forward_backward_pass(spline_manager, constraints: Constraints, delta_dist: float,
                           start_vel: float = 0.01, end_vel: float = 0.01) -> List[float]:
     """MPG:70-316: distance-grid sampling + forward/backward acceleration-limited pass, on the GPU."""
-    if not _plain_route(spline_manager):
-        raise NotImplementedError("per-node / action-point limits (MPG:100-163) are SURVEY §8(f) rank 2: "
-                                  "not on the device path yet")
     if spline_manager.lookup_table is None:
         spline_manager.build_lookup_table()
     out, _ = spline_manager._dev().forward_backward(constraints, delta_dist, start_vel, end_vel)
@@ -95,6 +84,11 @@ def motion_profile_angle(angle, constraints: Constraints, dt: float = 0.01):
 
 
 def generate_motion_profile(spline_manager, constraints: Constraints, dt: float = 0.01, dd: float = 0.005):
-    """MPG:389-628.  The distance-domain part runs on the device; the time-domain resample is the
-    next row of the scope table."""
-    raise NotImplementedError("time-domain resample (MPG:413-628): SURVEY §8(f) rank 1, next to be built")
+    """MPG:389-628 on the device.  Returns the reference's 9-tuple (times, positions, linear_vels,
+    accelerations, headings, angular_vels, nodes_map, actions_map, coords) as Python lists."""
+    spline_manager.rebuild_tables()
+    rows, nodes_map, actions_map = spline_manager._dev().motion_profile(constraints, dt, dd)
+    cols = [[float(v) for v in rows[:, i]] for i in range(6)]
+    coords = [rows[i, 6:8].copy() for i in range(len(rows))]
+    return (cols[0], cols[1], cols[2], cols[3], cols[4], cols[5], [int(v) for v in nodes_map],
+            [int(v) for v in actions_map], coords)

@@ -85,6 +85,28 @@ class QuinticHermiteSpline(Spline):
         self.segment_lengths = [float(v) for v in dev.segment_lengths]
         return True
 
+    @classmethod
+    def _from_route(cls, control_points, segments, segment_lengths, param_last):
+        """One spline of a route the manager fitted on the device (vap_route_create)."""
+        from .._device_path import DevicePath
+        self = cls()
+        k = len(control_points)
+        self.control_points = np.array(control_points, dtype=float)
+        self.set_tangents = [[None, None]] * k
+        dev = DevicePath.__new__(DevicePath)
+        DevicePath.__init__(dev)
+        dev.W = k
+        dev.segments = np.ascontiguousarray(segments)
+        dev.segment_lengths = np.ascontiguousarray(segment_lengths)
+        dev.param_last = float(param_last)
+        self._dev = dev
+        cum = np.concatenate(([0.0], np.cumsum(dev.segment_lengths)))
+        self.parameters = (cum * (k - 1) / cum[-1]) if cum[-1] > 0 else np.linspace(0, k - 1, k)
+        self.parameters[-1] = dev.param_last
+        self.segments = [dev.segments[i] for i in range(k - 1)]
+        self.segment_lengths = [float(v) for v in dev.segment_lengths]
+        return self
+
     # -- evaluation -------------------------------------------------------------------------------
     def _require_fit(self):
         if not self.segments:

@@ -2,19 +2,18 @@
 backed by the HIP kernels of libvap.so.
 
 What runs where (SM = the reference's splines/spline_manager.py):
-  build_path                      -> K1 fit on the device (vap_fit)                          SM:42-172
-  rebuild_tables / build_lookup_table -> K2 arc-length table on the device (vap_build_lut)   SM:426-475, 582-594
+  build_path                      -> vap_route_create: splits at reverse / turn nodes, split tangents,
+                                     per-spline fit and arc-length tables, all on the device   SM:42-172, 426-475
   precompute_path_properties      -> nothing is materialised: get_curvature / get_heading evaluate
-                                     the table entry the reference's step lookup would read  SM:477-580
-  get_*_at_parameter, distance_to_time, get_curvature, get_heading -> vap_eval_host / vap_lookup_host
-Paths with reverse or turn nodes (several splines, SM:84-158) are SURVEY §8(f) rank 2 and raise
-NotImplementedError for now.
+                                     the table entry the reference's step lookup would read    SM:477-580
+  get_*_at_parameter, distance_to_time, get_curvature, get_heading -> vap_route_eval / vap_route_lookup
 """
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
+from .._device_path import DeviceRoute
 from .quintic_hermite_spline import QuinticHermiteSpline
 
 
@@ -41,25 +40,17 @@ class QuinticHermiteSplineManager:
         if len(points) != len(nodes) or len(points) < 2:
             return False
         points = np.asarray(points, dtype=float)
-        for i in range(1, len(points)):
-            if nodes[i].is_reverse_node or nodes[i].turn != 0:
-                raise NotImplementedError("reverse / turn nodes split the path into several splines "
-                                          "(SURVEY §8(f) rank 2): not on the device path yet")
         self.splines = []
         self.nodes = nodes
         self.action_points = action_points
-        tangents = []
-        for node in nodes:
-            if node.tangent is not None:
-                tangents.append([np.asarray(node.tangent) * node.incoming_magnitude,
-                                 np.asarray(node.tangent) * node.outgoing_magnitude])
-            else:
-                tangents.append([None, None])
-        spline = QuinticHermiteSpline()
-        spline.set_all_tangents(tangents)
-        if not spline.fit(points[:, 0], points[:, 1]):
-            return False
-        self.splines.append(spline)
+        self._route = DeviceRoute(points, nodes, action_points)   # raises IndexError where the reference does
+        r = self._route
+        for si in range(r.n_splines):
+            a, k = int(r.sp_start[si]), int(r.sp_npts[si])
+            seg0 = a   # splines share their split node, so segment i always starts at node i
+            self.splines.append(QuinticHermiteSpline._from_route(
+                points[a:a + k], r.segments[seg0:seg0 + k - 1], r.segment_lengths[seg0:seg0 + k - 1],
+                float(r.sp_param_last[si])))
         self.arc_length = None
         self.lookup_table = None
         return True
@@ -80,28 +71,25 @@ class QuinticHermiteSplineManager:
         raise ValueError("Failed to map parameter to spline segment")
 
     def _dev(self):
-        return self.splines[0]._dev
+        return self._route
 
     # -- evaluators (SM:204-241) ----------------------------------------------------------------------
     def get_point_at_parameter(self, t: float) -> np.ndarray:
         self._require()
-        i, lt = self._map_parameter_to_spline(t)
-        return self.splines[i].get_point(lt)
+        return self._route.eval(0, t)[0]
 
     def get_derivative_at_parameter(self, t: float) -> np.ndarray:
         self._require()
-        i, lt = self._map_parameter_to_spline(t)
-        return self.splines[i].get_derivative(lt)
+        return self._route.eval(1, t)[0]
 
     def get_second_derivative_at_parameter(self, t: float) -> np.ndarray:
         self._require()
-        i, lt = self._map_parameter_to_spline(t)
-        return self.splines[i].get_second_derivative(lt)
+        return self._route.eval(2, t)[0]
 
     def get_points_at_parameters(self, ts) -> np.ndarray:
         """Vector form (one launch) of get_point_at_parameter — what a redraw wants (gui/path.py:370-373)."""
         self._require()
-        return self.splines[0].get_points(ts)
+        return self._route.eval(0, ts)
 
     def get_magnitudes_at_parameter(self, idx):
         """SM:174-202."""
@@ -132,12 +120,9 @@ class QuinticHermiteSplineManager:
             raise ValueError("No splines initialized")
         if min_samples != 1000:
             raise NotImplementedError("the device table has the reference's default 1000 samples")
-        dev = self._dev()
-        dev.build_lut()
-        n = len(dev.lut)
-        params = np.arange(n) * (dev.param_last / (n - 1))
-        params[-1] = dev.param_last
-        self.lookup_table = PathLookupTable(distances=dev.lut, parameters=params, total_length=dev.total)
+        r = self._route   # the table was built on the device together with the fit
+        self.lookup_table = PathLookupTable(distances=r.lut_distances, parameters=r.lut_parameters,
+                                            total_length=r.total)
 
     def precompute_path_properties(self, samples_per_node: int = 1000) -> None:
         """The reference fills 1000*len(nodes) curvature/heading entries here (SM:477-548); the device
