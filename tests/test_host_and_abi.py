@@ -119,3 +119,39 @@ def test_turn_profile_matches_oracle_time_domain_rows():
     rows = slice(start, start + len(ws))
     assert np.all(lin[rows] == 0)
     np.testing.assert_allclose(g["profile_angular_vels"][rows], ws, rtol=1e-12, atol=1e-12)
+
+
+def test_trajectory_file_formats(tmp_path):
+    """row layout, insertion of action rows, .txt and routes.h text."""
+    from vexautonomousplanner_amd import trajectory_io as tio
+    g = gu.load("feat_action")
+    T = len(g["profile_times"])
+    nodes_map = [int(v) for v in g["profile_nodes_map"]] + [T]          # gui/path.py:342
+    actions_map = [int(v) for v in g["profile_actions_map"]]
+    prof = (list(g["profile_times"]), list(g["profile_positions"]), list(g["profile_linear_vels"]),
+            list(g["profile_accelerations"]), list(g["profile_headings"]), list(g["profile_angular_vels"]),
+            nodes_map, actions_map, [row for row in g["profile_coords"]])
+    node_vals = [[i, 0] for i in range(len(nodes_map))]
+    ap_vals = [[9, j] for j in range(len(actions_map))]
+    rows = tio.trajectory_rows(prof, node_vals, ap_vals)
+    assert len(rows) == T + len(nodes_map) + len(actions_map)
+    assert rows[0] == [1, 0, 0]                                          # first node's actions lead the file
+    assert rows[1][0] == 0 and rows[1][1] == prof[0][0]
+    assert rows[1][2] == prof[8][0][0] * 12 and rows[1][3] == prof[8][0][1] * -12
+    assert rows[1][5] == prof[2][0] * 12 and rows[1][6] == prof[5][0]
+    assert rows[-1] == [1, len(nodes_map) - 1, 0]                        # last node after the last step
+    headers = [i for i, r in enumerate(rows) if r[0] == 1]
+    assert len(headers) == len(nodes_map) + len(actions_map)
+    txt = tio.format_txt(rows[:2])
+    assert txt.splitlines()[0] == "1 0 0 " and txt.endswith(" \n")
+    p = tmp_path / "routes.h"
+    tio.update_routes_header(str(p), "alpha", rows[:3])
+    tio.update_routes_header(str(p), "beta", [[1, 2], [0, 0.5, 1.0, 2.0, 3.0, 4.0, 5.0]])
+    tio.update_routes_header(str(p), "alpha", rows[:2])
+    text = p.read_text()
+    assert text.count("std::vector<std::vector<double>> alpha =") == 1
+    assert "std::vector<std::vector<double>> beta = {{1, 2}, {0, 0.5, 1.0, 2.0, 3.0, 4.0, 5.0}};" in text
+    assert text.strip().endswith("#endif") and text.index("beta") < text.index("#endif")
+    js = tio.route_json([[1.5, -2.0, 1, 0, 0, 0, 0, 0, None, None, None]], [[0.0, 1.0, 2.5, 0, 0]])
+    assert js == "[[[1.5,-2.0,1,0,0,0,0,0,null,null,null]],[[0.0,1.0,2.5,0,0]]]"
+    assert tio.parse_route_json(js)[1][0][2] == 2.5
