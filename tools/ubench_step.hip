@@ -42,6 +42,43 @@ __global__ void k(const float *in, float *out, long long *cyc, int iters, float 
                 float a = __builtin_amdgcn_fmed3f(aw, 0.f, AA);
                 wp = w;
                 u = fminf(fminf(16.0f, u + a), cc);
+            } else if (FORM == 3) {  // production step, compiler order
+                float w = u * q[s];
+                float d = fmaf(u, q[s], -wp);
+                float x = fmaf(-fabsf(d), g[s], u + amaxp);
+                wp = w;
+                u = fminf(fminf(__builtin_amdgcn_fmed3f(x, u, u + opaque(A[s])), opaque(cap[s])), 1e30f);
+            } else if (FORM == 4) {  // production step, pinned order: chain op, then the adds in its shadow
+                float d = fmaf(u, q[s], -wp);
+                __builtin_amdgcn_sched_barrier(0);
+                float uP = u + amaxp;
+                __builtin_amdgcn_sched_barrier(0);
+                float uA = u + opaque(A[s]);
+                __builtin_amdgcn_sched_barrier(0);
+                float x = fmaf(-fabsf(d), g[s], uP);
+                __builtin_amdgcn_sched_barrier(0);
+                float w = u * q[s];
+                __builtin_amdgcn_sched_barrier(0);
+                float m = __builtin_amdgcn_fmed3f(x, u, uA);
+                __builtin_amdgcn_sched_barrier(0);
+                wp = w;
+                u = fminf(fminf(m, opaque(cap[s])), 1e30f);
+                __builtin_amdgcn_sched_barrier(0);
+            } else if (FORM == 5) {  // 3-op chain: clamp window pre-min'ed with the cap
+                float d = fmaf(u, q[s], -wp);
+                __builtin_amdgcn_sched_barrier(0);
+                float uP = u + amaxp;
+                __builtin_amdgcn_sched_barrier(0);
+                float hi = fminf(u + opaque(A[s]), opaque(cap[s]));
+                __builtin_amdgcn_sched_barrier(0);
+                float x = fmaf(-fabsf(d), g[s], uP);
+                __builtin_amdgcn_sched_barrier(0);
+                float lo = fminf(u, cap[s]);
+                float w = u * q[s];
+                __builtin_amdgcn_sched_barrier(0);
+                wp = w;
+                u = __builtin_amdgcn_fmed3f(x, lo, hi);
+                __builtin_amdgcn_sched_barrier(0);
             } else {  // pure dependent fma chain of 6
                 u = fmaf(u, q[s], wp); u = fmaf(u, g[s], wp); u = fmaf(u, q[s], wp);
                 u = fmaf(u, g[s], wp); u = fmaf(u, q[s], wp); u = fmaf(u, g[s], wp);
@@ -69,13 +106,16 @@ int main()
     hipMalloc(&dout, 4096 * 4 * 64);
     hipMalloc(&dc, 4096 * 8);
     hipMemcpy(din, h.data(), h.size() * 4, hipMemcpyHostToDevice);
-    for (int form = 0; form < 3; form++)
-        for (int waves_per_block : {1, 4, 8, 16}) {
+    for (int form = 0; form < 6; form++)
+        for (int waves_per_block : {1, 8}) {
             int blocks = 256;
             for (int rep = 0; rep < 2; rep++) {
                 if (form == 0) hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(64 * waves_per_block), 0, 0, din, dout, dc, iters, 1e-3f, 4.f);
                 if (form == 1) hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(64 * waves_per_block), 0, 0, din, dout, dc, iters, 1e-3f, 4.f);
                 if (form == 2) hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(64 * waves_per_block), 0, 0, din, dout, dc, iters, 1e-3f, 4.f);
+                if (form == 3) hipLaunchKernelGGL(k<3>, dim3(blocks), dim3(64 * waves_per_block), 0, 0, din, dout, dc, iters, 1e-3f, 4.f);
+                if (form == 4) hipLaunchKernelGGL(k<4>, dim3(blocks), dim3(64 * waves_per_block), 0, 0, din, dout, dc, iters, 1e-3f, 4.f);
+                if (form == 5) hipLaunchKernelGGL(k<5>, dim3(blocks), dim3(64 * waves_per_block), 0, 0, din, dout, dc, iters, 1e-3f, 4.f);
                 hipDeviceSynchronize();
             }
             long long c[4];

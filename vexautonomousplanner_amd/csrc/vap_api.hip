@@ -233,7 +233,7 @@ int vap_sample(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd, const
     VAP_TRY(check_shape(B, W, S));
     if (!d_segments || !d_lut || !d_meta) return vap_fail(VAP_ERR_INVALID, "null buffer");
     const size_t n_seg = (size_t)B * (W - 1);
-    VAP_TRY(ctx->ensure(ctx->power, n_seg * 30 * sizeof(double)));
+    VAP_TRY(ctx->ensure(ctx->power, n_seg * vap::kCoefBlockDoubles * sizeof(double)));
     VAP_TRY(ctx->ensure(ctx->slopes, (size_t)B * VAP_LUT_SAMPLES * sizeof(double)));
     VAP_TRY(ctx->ensure(ctx->aux, (size_t)B * 4 * sizeof(double)));
     HIP_TRY(vap::launch_power(ctx->stream, (int)n_seg, d_segments, (double *)ctx->power.ptr));
@@ -268,7 +268,7 @@ int vap_profile_batch(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd
     const bool f64 = dt == VAP_F64;
     const size_t n_seg = (size_t)B * (W - 1), n_pts = (size_t)B * S;
     VAP_TRY(ctx->ensure(ctx->seg, n_seg * 12 * sizeof(double)));
-    VAP_TRY(ctx->ensure(ctx->power, n_seg * 30 * sizeof(double)));
+    VAP_TRY(ctx->ensure(ctx->power, n_seg * vap::kCoefBlockDoubles * sizeof(double)));
     VAP_TRY(ctx->ensure(ctx->lut, (size_t)B * VAP_LUT_SAMPLES * sizeof(double)));
     VAP_TRY(ctx->ensure(ctx->slopes, (size_t)B * VAP_LUT_SAMPLES * sizeof(double)));
     VAP_TRY(ctx->ensure(ctx->aux, (size_t)B * 4 * sizeof(double)));

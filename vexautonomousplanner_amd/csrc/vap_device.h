@@ -122,22 +122,31 @@ __device__ __forceinline__ void hermite_to_power(double r0, double r1, double r2
     c[5] = 6 * d - 3 * r2 - 3 * r3 - 0.5 * r4 + 0.5 * r5;
 }
 
-// Per-segment coefficient block used by the sampling kernel (fp64, kCoefDoubles values):
-//   [0..5] x: c0..c5   [6..11] y: c0..c5            P   = sum c_j t^j
-//   [12..16] x: j*c_j (j=1..5)   [17..21] y          P'
-//   [22..25] x: j(j-1)*c_j (j=2..5)   [26..29] y     P''
-constexpr int kCoefDoubles = 30;
+// Per-segment coefficient block used by the sampling kernel (kCoefDoubles doubles):
+//   [0..4]   x: j*c_j (j=1..5)        [5..9]   y          P'   (fp64)
+//   [10..13] x: j(j-1)*c_j (j=2..5)   [14..17] y          P''  (fp64)
+//   [18..23] x: c0..c5                [24..29] y          P    (fp64)
+//   [30..35] the same 12 position coefficients as fp32 (x then y), for the fp32 output mode
+constexpr int kCoefDoubles = 36;
+constexpr int kCoefD1 = 0, kCoefD2 = 10, kCoefP = 18, kCoefPf = 30;
 __device__ __forceinline__ void make_coef_block(const double r[12], double *__restrict__ o)
 {
     double cx[6], cy[6];
     hermite_to_power(r[0], r[2], r[4], r[6], r[8], r[10], cx);
     hermite_to_power(r[1], r[3], r[5], r[7], r[9], r[11], cy);
 #pragma unroll
-    for (int k = 0; k < 6; k++) { o[k] = cx[k]; o[6 + k] = cy[k]; }
+    for (int k = 1; k < 6; k++) { o[kCoefD1 + k - 1] = (double)k * cx[k]; o[kCoefD1 + 5 + k - 1] = (double)k * cy[k]; }
 #pragma unroll
-    for (int k = 1; k < 6; k++) { o[12 + k - 1] = (double)k * cx[k]; o[17 + k - 1] = (double)k * cy[k]; }
+    for (int k = 2; k < 6; k++) { o[kCoefD2 + k - 2] = (double)(k * (k - 1)) * cx[k]; o[kCoefD2 + 4 + k - 2] = (double)(k * (k - 1)) * cy[k]; }
 #pragma unroll
-    for (int k = 2; k < 6; k++) { o[22 + k - 2] = (double)(k * (k - 1)) * cx[k]; o[26 + k - 2] = (double)(k * (k - 1)) * cy[k]; }
+    for (int k = 0; k < 6; k++) { o[kCoefP + k] = cx[k]; o[kCoefP + 6 + k] = cy[k]; }
+    float *f = reinterpret_cast<float *>(o + kCoefPf);
+#pragma unroll
+    for (int k = 0; k < 6; k++) { f[k] = (float)cx[k]; f[6 + k] = (float)cy[k]; }
+}
+__device__ __forceinline__ float horner5f(const float *__restrict__ c, float t)
+{
+    return fmaf(fmaf(fmaf(fmaf(fmaf(c[5], t, c[4]), t, c[3]), t, c[2]), t, c[1]), t, c[0]);
 }
 __device__ __forceinline__ double horner5(const double *__restrict__ c, double t)   // c[0..5]
 {
@@ -257,6 +266,28 @@ __device__ __forceinline__ float atan2_f32(float y, float x)
     r = ay > ax ? 1.57079632679489662f - r : r;
     r = x < 0.0f ? 3.14159265358979324f - r : r;
     return copysignf(r, y);
+}
+
+// |heading[k+1]-heading[k]| from the two fp64 derivative vectors and the two fp32 headings: the angle
+// between the vectors (small-angle accurate) plus the 2*pi multiple that the raw difference of the
+// reference's un-unwrapped atan2 values carries.  Consecutive samples are almost always within the
+// series' range (|tan| < 0.41, same half-plane); the general atan2 handles the rest.
+__device__ __forceinline__ float dtheta_f32(double ax, double ay, double bx, double by, float tha, float thb)
+{
+    const float cr = (float)fma(ax, by, -(ay * bx));
+    const float dt = (float)fma(ax, bx, ay * by);
+    float dl;
+    const float z = cr * __builtin_amdgcn_rcpf(dt);
+    if (dt > 0.0f && fabsf(z) < 0.41421356237f) {
+        const float z2 = z * z;
+        const float p = fmaf(fmaf(fmaf(8.05374449538e-2f, z2, -1.38776856032e-1f), z2, 1.99777106478e-1f), z2,
+                             -3.33329491539e-1f);
+        dl = fmaf(p * z2, z, z);
+    } else {
+        dl = atan2_f32(cr, dt);
+    }
+    const float n = rintf(((thb - tha) - dl) * 0.15915494309189535f);
+    return fabsf(fmaf(n, 6.283185307179586f, dl));
 }
 
 // Python's min(a, b): keeps a unless b < a (a NaN in b is skipped).

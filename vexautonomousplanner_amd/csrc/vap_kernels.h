@@ -13,7 +13,8 @@ constexpr int kSampleThreads = 256;
 constexpr int kSPT = 4;                                   // consecutive samples per thread (one 16-byte store)
 constexpr int kSampleChunk = kSampleThreads * kSPT;       // samples evaluated per workgroup
 constexpr int kSampleTile = kSampleChunk - kSPT;          // samples written: the last thread only feeds its neighbour
-constexpr int kLdsCoefSegments = 136;                     // segments whose coefficient blocks are staged in LDS
+constexpr int kCoefBlockDoubles = 36;                      // doubles per segment coefficient block (scratch sizing)
+constexpr int kLdsCoefSegments = 112;                     // segments whose coefficient blocks are staged in LDS
 constexpr int kMaxWaypoints = 2048;              // k_fit LDS: 7*W doubles
 
 hipError_t launch_fit(hipStream_t st, bool f64, int B, int W, const void *wp, const double *tin,

@@ -18,6 +18,8 @@
 
 namespace vap {
 
+static_assert(kCoefBlockDoubles == kCoefDoubles, "scratch sizing and block layout disagree");
+
 // Cooperative copy of n doubles from HBM/L2 into LDS: up to ITER loads per thread are issued before
 // the first LDS write, so a workgroup pays the memory latency once instead of once per element.
 template <int ITER>
@@ -404,8 +406,8 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int 
             int sg;
             normalize_inside(tp, G, lt, sg);
             const double *c = coef + sg * kCoefDoubles;
-            const double ex = horner4(c + 12, lt), ey = horner4(c + 17, lt);     // P'
-            const double fx = horner3(c + 22, lt), fy = horner3(c + 26, lt);     // P''
+            const double ex = horner4(c + kCoefD1, lt), ey = horner4(c + kCoefD1 + 5, lt);     // P'
+            const double fx = horner3(c + kCoefD2, lt), fy = horner3(c + kCoefD2 + 4, lt);     // P''
             const double ss = fma(ex, ex, ey * ey);                               // SM:517
             const double num = fma(ex, fy, -(ey * fx));                           // SM:523
             vk[i] = (OT)((ss >= 1e-10) ? curvature_of(num, ss) : 0.0);            // SM:526-527
@@ -416,8 +418,15 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int 
             // SM:204-215 get_point_at_parameter(t) at the sample's own parameter
             normalize_inside(t, G, lt, sg);
             c = coef + sg * kCoefDoubles;
-            vx[i] = (OT)horner5(c, lt);
-            vy[i] = (OT)horner5(c + 6, lt);
+            if constexpr (sizeof(OT) == 4) {
+                const float *cf = reinterpret_cast<const float *>(c + kCoefPf);
+                const float ltf = (float)lt;
+                vx[i] = horner5f(cf, ltf);
+                vy[i] = horner5f(cf + 6, ltf);
+            } else {
+                vx[i] = horner5(c + kCoefP, lt);
+                vy[i] = horner5(c + kCoefP + 6, lt);
+            }
             vd[i] = (OT)0;
         }
         const int pb = tl & 1;
@@ -439,22 +448,15 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int 
                     if constexpr (sizeof(OT) == 8) {
                         vd[i] = fabs(nth - vh[i]);
                     } else {
-                        if (nj != jjv[i]) {
-                            // small-angle accurate: angle between the two fp64 derivative vectors, then
-                            // the 2*pi multiple that the raw difference of the two atan2 values carries
-                            const float cr = (float)fma(d1x[i], ny, -(d1y[i] * nx));
-                            const float dt = (float)fma(d1x[i], nx, d1y[i] * ny);
-                            const float dl = atan2_f32(cr, dt);
-                            const float raw = nth - vh[i];
-                            const float n = rintf((raw - dl) * 0.15915494309189535f);
-                            vd[i] = fabsf(fmaf(n, 6.283185307179586f, dl));
-                        }
+                        if (nj != jjv[i]) vd[i] = dtheta_f32(d1x[i], d1y[i], nx, ny, vh[i], nth);
                     }
                 }
             }
+            if (k0 + kSampleChunk > N) {   // only the path's last tile has samples to blank
 #pragma unroll
-            for (int i = 0; i < kSPT; i++)
-                if (kbase + i >= N) vx[i] = vy[i] = vh[i] = vk[i] = vd[i] = (OT)0;
+                for (int i = 0; i < kSPT; i++)
+                    if (kbase + i >= N) vx[i] = vy[i] = vh[i] = vk[i] = vd[i] = (OT)0;
+            }
             store_vec(ox, vx); store_vec(oy, vy); store_vec(oh, vh); store_vec(ok, vk); store_vec(odth, vd);
         }
     }
