@@ -155,12 +155,15 @@ __global__ __launch_bounds__(256) void k_fit(int W, const IT *__restrict__ waypo
 template <bool SEG_LDS>
 __global__ __launch_bounds__(256) void k_lut(int W, const double *__restrict__ segments,
                                              double *__restrict__ lut, double *__restrict__ slopes,
-                                             double *__restrict__ meta, uint32_t *__restrict__ flags)
+                                             double *__restrict__ meta, uint32_t *__restrict__ flags,
+                                             long long *__restrict__ stats)
 {
+    const long long tl0 = stats ? __builtin_amdgcn_s_memtime() : 0;
     extern __shared__ __attribute__((aligned(16))) double s_seg[];   // G * 12 when SEG_LDS
-    constexpr int kPad = (kLutN + 15) / 16 * 16;   // the sequential sum walks whole groups of 16
-    __shared__ double mag[kPad];
-    __shared__ double cum[kPad];
+    constexpr int kPad = (kLutN + 31) / 32 * 32;   // the sequential sum walks whole groups of 32
+    // one array: magnitudes, then (in place) trapezoid increments, then cumulative distances
+    __shared__ __attribute__((aligned(16))) double cum[kPad];
+    double *mag = cum;
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int G = W - 1;
     const double t_max = meta[(size_t)b * kMetaStride + 0];
@@ -180,32 +183,65 @@ __global__ __launch_bounds__(256) void k_lut(int W, const double *__restrict__ s
         mag[j] = sqrt(dx * dx + dy * dy);  // np.linalg.norm(derivatives, axis=1), SM:448
     }
     __syncthreads();
+    const long long tl1 = stats ? __builtin_amdgcn_s_memtime() : 0;
     // trapezoid increments in parallel (SM:452-454: (m[j-1] + m[j]) * 0.5 * dt, that association) ...
     const double dt = linspace_at(t_max, kLutN, 1) - linspace_at(t_max, kLutN, 0);  // SM:444
-    for (int j = tid; j < kPad; j += nt) cum[j] = (j > 0 && j < kLutN) ? (mag[j - 1] + mag[j]) * 0.5 * dt : 0.0;
-    __syncthreads();
-    // ... and np.cumsum's strictly left-to-right sum by one lane: 999 dependent adds, operands
-    // fetched 16 at a time so the LDS latency stays off the chain
-    if (tid == 0) {
-        double acc = 0.0;   // cum[0] = 0: the first add is the exact 0 + 0 of partial_distances[0]
-#pragma unroll 1
-        for (int j0 = 0; j0 < kPad; j0 += 16) {
-            double inc[16];
+    {
+        constexpr int kPer = kPad / 128 + 1;   // increments per thread for the smallest launch (128 threads)
+        double inc[kPer];
 #pragma unroll
-            for (int k = 0; k < 16; k++) inc[k] = cum[j0 + k];
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                acc += inc[k];
-                inc[k] = acc + 0.0;                    // + current_dist (single spline), SM:457
-            }
-#pragma unroll
-            for (int k = 0; k < 16; k++) cum[j0 + k] = inc[k];
+        for (int it = 0; it < kPer; it++) {
+            const int j = tid + it * nt;
+            inc[it] = (j > 0 && j < kLutN) ? (mag[j - 1] + mag[j]) * 0.5 * dt : 0.0;
         }
-        const double total = cum[kLutN - 1];
-        meta[(size_t)b * kMetaStride + 1] = total;
-        if (flags && !(total > 0.0 && isfinite(total))) atomicOr(&flags[b], VAP_FLAG_DEGENERATE_BIT);
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < kPer; it++) {
+            const int j = tid + it * nt;
+            if (j < kPad) cum[j] = inc[it];
+        }
     }
     __syncthreads();
+    // ... and np.cumsum's strictly left-to-right sum.  Lane 0 walks the whole chain but keeps only the
+    // running sum at every 32nd element (no stores on the chain); then lane g replays group g from its
+    // exact starting sum — the same adds in the same order, so every prefix is bit-identical to the
+    // one-lane result — and stores it.
+    __shared__ double s_start[kPad / 32];
+    if (tid == 0) {
+        double acc = 0.0;   // cum[0] = 0: the first add is the exact 0 + 0 of partial_distances[0]
+        // (+ current_dist of SM:457 is + 0.0 for a single spline: a no-op on these non-negative sums)
+        const double2 *cum2 = reinterpret_cast<const double2 *>(cum);
+#pragma unroll 1
+        for (int g0 = 0; g0 < kPad / 32; g0++) {
+            s_start[g0] = acc;
+            double2 v[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] = cum2[g0 * 16 + k];
+#pragma unroll
+            for (int k = 0; k < 16; k++) { acc += v[k].x; acc += v[k].y; }
+        }
+        meta[(size_t)b * kMetaStride + 1] = acc;   // elements past kLutN-1 are zero increments
+        if (flags && !(acc > 0.0 && isfinite(acc))) atomicOr(&flags[b], VAP_FLAG_DEGENERATE_BIT);
+    }
+    __syncthreads();
+    if (tid < kPad / 32) {
+        double acc = s_start[tid];
+        double2 *cum2 = reinterpret_cast<double2 *>(cum) + tid * 16;
+        double2 v[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = cum2[k];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            acc += v[k].x;
+            v[k].x = acc;
+            acc += v[k].y;
+            v[k].y = acc;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) cum2[k] = v[k];
+    }
+    __syncthreads();
+    const long long tl2 = stats ? __builtin_amdgcn_s_memtime() : 0;
     const double lstep = t_max / (double)(kLutN - 1);
     for (int j = tid; j < kLutN; j += nt) {
         lut[(size_t)b * kLutN + j] = cum[j];
@@ -218,6 +254,11 @@ __global__ __launch_bounds__(256) void k_lut(int W, const double *__restrict__ s
             }
             slopes[(size_t)b * kLutN + j] = w;
         }
+    }
+    if (stats && tid == 0) {
+        stats[(size_t)b * 4 + 0] = tl1 - tl0;
+        stats[(size_t)b * 4 + 1] = tl2 - tl1;
+        stats[(size_t)b * 4 + 2] = __builtin_amdgcn_s_memtime() - tl2;
     }
 }
 
@@ -1151,8 +1192,22 @@ hipError_t launch_fit(hipStream_t st, bool f64, int B, int W, const void *wp, co
 hipError_t launch_lut(hipStream_t st, int B, int W, const double *seg, double *lut, double *slopes, double *meta,
                       uint32_t *flags)
 {
-    if (W - 1 <= 512) hipLaunchKernelGGL(k_lut<true>, dim3(B), dim3(256), sizeof(double) * 12 * (W - 1), st, W, seg, lut, slopes, meta, flags);
-    else hipLaunchKernelGGL(k_lut<false>, dim3(B), dim3(256), 0, st, W, seg, lut, slopes, meta, flags);
+    static const bool want_stats = getenv("VAP_LUT_STATS") != nullptr;
+    long long *stats = nullptr;
+    if (want_stats) (void)hipMalloc(&stats, (size_t)B * 4 * sizeof(long long));
+    // 128 threads: the sequential sum keeps one lane busy, so residency (16 workgroups per CU) is what hides it
+    if (W - 1 <= 512) hipLaunchKernelGGL(k_lut<true>, dim3(B), dim3(128), sizeof(double) * 12 * (W - 1), st, W, seg, lut, slopes, meta, flags, stats);
+    else hipLaunchKernelGGL(k_lut<false>, dim3(B), dim3(128), 0, st, W, seg, lut, slopes, meta, flags, stats);
+    if (stats) {
+        std::vector<long long> h((size_t)B * 4);
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(h.data(), stats, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+        (void)hipFree(stats);
+        double sum[3] = {0, 0, 0};
+        for (int b = 0; b < B; b++)
+            for (int k = 0; k < 3; k++) sum[k] += (double)h[(size_t)b * 4 + k];
+        fprintf(stderr, "[lut] mean ticks: magnitudes %.0f  increments+sum %.0f  store+slopes %.0f\n", sum[0] / B, sum[1] / B, sum[2] / B);
+    }
     return hipGetLastError();
 }
 
