@@ -85,9 +85,12 @@ int vap_ctx_synchronize(vap_ctx *ctx);
 /* Tuning / test knobs.  VAP_OPT_VELOCITY_KERNEL selects the K5 implementation: AUTO (default) picks
  * the register-resident relaxation kernel when the row fits and the sequential sweep otherwise;
  * SEQ_LITERAL is the statement-by-statement form of MPG:188-311, SEQ_FAST the same sweep with the
- * collapsed limits (bit-identical to RELAX). */
+ * collapsed limits (bit-identical to RELAX).  RELAX_BLOCK is the workgroup-per-path kernel RELAX uses;
+ * RELAX_WAVE (fp32) walks each path with one wave in stream-ordered windows — exact as well, kept for
+ * experiments (slower on MI355X for the sizes measured). */
 enum { VAP_OPT_VELOCITY_KERNEL = 0 };
-enum { VAP_VELOCITY_AUTO = 0, VAP_VELOCITY_SEQ_LITERAL = 1, VAP_VELOCITY_SEQ_FAST = 2, VAP_VELOCITY_RELAX = 3 };
+enum { VAP_VELOCITY_AUTO = 0, VAP_VELOCITY_SEQ_LITERAL = 1, VAP_VELOCITY_SEQ_FAST = 2, VAP_VELOCITY_RELAX = 3,
+       VAP_VELOCITY_RELAX_BLOCK = 4 /* workgroup per path */, VAP_VELOCITY_RELAX_WAVE = 5 /* wave per path, fp32 */ };
 int vap_ctx_set_option(vap_ctx *ctx, int option, int value);
 /* Enable/disable per-stage hipEvent timing (replaces the reference's time.time() log lines,
  * SM:587-594, MPG:398-411).  Off by default. */

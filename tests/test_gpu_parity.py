@@ -217,3 +217,33 @@ def test_long_row_relaxation_is_bit_identical_to_sequential_sweep(torch_mod, B, 
         assert np.all(r["flags"] == 0), which
         outs[which] = r["velocity"]
     assert np.array_equal(outs["relax"], outs["seq_fast"])
+
+
+@pytest.mark.parametrize("B,W,S,seed", [(8, 32, 10000, 3), (5, 8, 2561, 5), (3, 16, 7001, 13), (4, 32, 4097, 12),
+                                        (2, 3, 8000, 32), (6, 8, 1024, 77)])
+def test_wave_per_path_relaxation_is_bit_identical(torch_mod, B, W, S, seed):
+    """K5b' (one wave per path, sequential windows) against the block kernel and the sequential sweep."""
+    from vexautonomousplanner_amd.batch import BatchedTrajectoryGenerator
+    from vexautonomousplanner_amd.synth import make_waypoints
+    wp = make_waypoints(B, W, seed).astype(np.float64)
+    outs = {}
+    for which in ("relax_wave", "relax_block", "seq_fast"):
+        gen = BatchedTrajectoryGenerator(0, "f32", velocity_kernel=which)
+        r = run_gpu(torch_mod, gen, wp, samples=S)
+        assert np.all(r["flags"] == 0), which
+        outs[which] = r["velocity"]
+    assert np.array_equal(outs["relax_wave"], outs["seq_fast"])
+    assert np.array_equal(outs["relax_block"], outs["seq_fast"])
+
+
+def test_wave_per_path_ragged_rows(torch_mod):
+    from vexautonomousplanner_amd.batch import BatchedTrajectoryGenerator
+    from vexautonomousplanner_amd.synth import make_waypoints
+    wp = make_waypoints(6, 8, 21).astype(np.float64)
+    outs = {}
+    for which in ("relax_wave", "seq_fast"):
+        gen = BatchedTrajectoryGenerator(0, "f32", velocity_kernel=which)
+        r = run_gpu(torch_mod, gen, wp, dd=0.002, capacity=4000)
+        assert np.all(r["flags"] == 0)
+        outs[which] = r["velocity"]
+    assert np.array_equal(outs["relax_wave"], outs["seq_fast"])

@@ -38,9 +38,10 @@ class BatchedTrajectoryGenerator:
         self.set_velocity_kernel(velocity_kernel)
 
     def set_velocity_kernel(self, which):
-        """"auto" | "seq_literal" | "seq_fast" | "relax" (VAP_OPT_VELOCITY_KERNEL)."""
+        """"auto" | "seq_literal" | "seq_fast" | "relax" | "relax_block" | "relax_wave" (VAP_OPT_VELOCITY_KERNEL)."""
         table = {"auto": _lib.VELOCITY_AUTO, "seq_literal": _lib.VELOCITY_SEQ_LITERAL,
-                 "seq_fast": _lib.VELOCITY_SEQ_FAST, "relax": _lib.VELOCITY_RELAX}
+                 "seq_fast": _lib.VELOCITY_SEQ_FAST, "relax": _lib.VELOCITY_RELAX,
+                 "relax_block": _lib.VELOCITY_RELAX_BLOCK, "relax_wave": _lib.VELOCITY_RELAX_WAVE}
         self.ctx.set_option(_lib.OPT_VELOCITY_KERNEL, table[which])
 
     def profile(self, waypoints, constraints=DEFAULT_CONSTRAINTS, samples=None, dd=None,

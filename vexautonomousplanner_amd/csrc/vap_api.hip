@@ -3,6 +3,7 @@
 // Host-side runtime: context (device + stream + scratch arena + stage timers) and the entry points
 // that sequence the kernels of vap_kernels.hip.  There is deliberately no CPU implementation behind
 // any entry point: without a HIP device every call fails with VAP_ERR_NO_DEVICE.
+#include <cstdlib>
 #include <cstring>
 
 #include "vap_internal.h"
@@ -62,9 +63,24 @@ int run_velocity(vap_ctx *ctx, bool f64, int B, int S, const double cc[6], doubl
 {
     int mode = ctx->velocity_kernel;
     if (mode == VAP_VELOCITY_AUTO) mode = vcap ? VAP_VELOCITY_SEQ_FAST : VAP_VELOCITY_RELAX;
+    const int forced = mode;
+    if (mode == VAP_VELOCITY_RELAX_BLOCK || mode == VAP_VELOCITY_RELAX_WAVE) mode = VAP_VELOCITY_RELAX;
     if (mode == VAP_VELOCITY_RELAX) {
         if (vcap) return vap_fail(VAP_ERR_UNSUPPORTED, "relaxation kernel: per-sample caps are not supported yet");
-        if (S <= vap::velocity_relax_max_samples(f64)) {
+        if (forced == VAP_VELOCITY_RELAX_WAVE && (f64 || S > vap::velocity_relax_max_samples(f64)))
+            return vap_fail(VAP_ERR_UNSUPPORTED, "wave-per-path kernel: fp32 rows up to %d samples", vap::velocity_relax_max_samples(false));
+        // One wave per path (sequential windows) keeps 8 paths resident per CU instead of 2, but measured
+        // 2x slower than the workgroup-per-path kernel on config 3 (every wave is then busy every round and
+        // two latency-bound waves per SIMD slow each other down): kept selectable, not the default.
+        const bool use_wave = forced == VAP_VELOCITY_RELAX_WAVE;
+        if (use_wave && S <= vap::velocity_relax_max_samples(f64)) {
+            // many paths: one wave per path keeps 8 paths resident per CU
+            VAP_TRY(ctx->ensure(ctx->ufwd, (size_t)B * S * 4));
+            VAP_TRY(ctx->ensure(ctx->lstate, vap::velocity_windows_state_bytes(B, S)));
+            VAP_TRY(ctx->ensure(ctx->lcount, sizeof(int) * ((size_t)B + 64)));
+            HIP_TRY(vap::launch_velocity_windows(ctx->stream, B, S, cc, sv, ev, meta, curv, dth, vel, flags, ctx->ufwd.ptr,
+                                                 ctx->lstate.ptr, (int *)ctx->lcount.ptr));
+        } else if (S <= vap::velocity_relax_max_samples(f64)) {
             HIP_TRY(vap::launch_velocity_relax(ctx->stream, f64, B, S, cc, sv, ev, meta, curv, dth, vel, flags));
         } else {
             // long rows: two-level relaxation (host-synchronised super-rounds)
@@ -171,7 +187,7 @@ int vap_ctx_synchronize(vap_ctx *ctx)
 int vap_ctx_set_option(vap_ctx *ctx, int option, int value)
 {
     if (!ctx) return vap_fail(VAP_ERR_INVALID, "null context");
-    if (option == VAP_OPT_VELOCITY_KERNEL && value >= VAP_VELOCITY_AUTO && value <= VAP_VELOCITY_RELAX) {
+    if (option == VAP_OPT_VELOCITY_KERNEL && value >= VAP_VELOCITY_AUTO && value <= VAP_VELOCITY_RELAX_WAVE) {
         ctx->velocity_kernel = value;
         return VAP_OK;
     }

@@ -39,6 +39,11 @@ size_t velocity_long_counter_bytes(bool f64, int B, int S);
 hipError_t launch_velocity_long(hipStream_t st, bool f64, int B, int S, const double c[6], double sv, double ev,
                                 const double *meta, const void *curv, const void *dth, void *vel, uint32_t *flags,
                                 void *ufwd, void *state, int *counters);
+// fp32, one wave per path, one launch per window of 2560 samples and direction (no host synchronisation)
+size_t velocity_windows_state_bytes(int B, int S);
+hipError_t launch_velocity_windows(hipStream_t st, int B, int S, const double c[6], double sv, double ev,
+                                   const double *meta, const void *curv, const void *dth, void *vel, uint32_t *flags,
+                                   void *ufwd, void *state, int *counters);
 hipError_t launch_power(hipStream_t st, int n_seg, const double *seg, double *pw);
 hipError_t launch_eval(hipStream_t st, int W, const double *seg, double t_max, int order, int n, const double *t,
                        double *out);

@@ -908,7 +908,7 @@ __global__ void k_dup_scan(int B, int S, const double *__restrict__ meta, const 
 }
 
 template <typename R, int L, int MAXT, int MINW, bool BWD>
-__global__ __launch_bounds__(MAXT, MINW) void k_velocity_long(int S, int nsc, int round, VelConsts<R> c, R start_u,
+__global__ __launch_bounds__(MAXT, MINW) void k_velocity_long(int S, int nsc, int round, int seq_sc, VelConsts<R> c, R start_u,
                                                               R end_u, const double *__restrict__ meta,
                                                               const R *__restrict__ curv,
                                                               const R *__restrict__ dtheta, R *__restrict__ ufwd,
@@ -923,7 +923,10 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_long(int S, int nsc, in
     __shared__ int s_any[3];
     constexpr int T = MAXT;
     constexpr int SC = T * L;
-    const int sc = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    // seq_sc >= 0: "sequential windows" mode — this launch handles super-chunk seq_sc of every path and
+    // its incoming interface state (published by the previous launch) is final, so it is evaluated once.
+    const bool seq = seq_sc >= 0;
+    const int sc = seq ? seq_sc : blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int B = gridDim.y;
     const double *m = meta + (size_t)b * kMetaStride;
     const R twodd = (R)2 * (R)m[2];
@@ -938,14 +941,15 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_long(int S, int nsc, in
     const int lo = tid * L;
     // interface arrays
     const size_t ifs = (size_t)(nsc + 1) * 2;                          // per path
-    R *bnd_prev = bnd + ((size_t)((round + 1) & 1) * B + b) * ifs;
-    R *bnd_cur = bnd + ((size_t)(round & 1) * B + b) * ifs;
+    R *bnd_prev = bnd + ((size_t)(seq ? 0 : ((round + 1) & 1)) * B + b) * ifs;
+    R *bnd_cur = bnd + ((size_t)(seq ? 0 : (round & 1)) * B + b) * ifs;
     R *my_used = used + ((size_t)b * nsc + sc) * 2;
     R *my_out = outst + ((size_t)b * nsc + sc) * 2;
     const int if_in = BWD ? sc + 1 : sc, if_out = BWD ? sc : sc + 1;
     const bool exact_in = BWD ? (sc == last_sc) : (sc == 0);
     R in0_u = exact_in ? (BWD ? end_u : start_u) : (R)0, in0_w = (R)0;
-    if (round > 0) {
+    if (seq && !exact_in) { in0_u = bnd_prev[if_in * 2]; in0_w = bnd_prev[if_in * 2 + 1]; }
+    if (!seq && round > 0) {
         if (!exact_in) { in0_u = bnd_prev[if_in * 2]; in0_w = bnd_prev[if_in * 2 + 1]; }
         if (exact_in || (same_bits(in0_u, my_used[0]) && same_bits(in0_w, my_used[1]))) {
             // nothing new came in: republish the last outgoing state for the next super-round
@@ -1012,14 +1016,14 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_long(int S, int nsc, in
     const bool bwd_has_end = BWD && sc == last_sc;
     if constexpr (!BWD) {
         if (tid == 0) {
-            if (!exact_in && round == 0) { in0_u = cp[0]; in0_w = in0_u * q[0]; }
+            if (!exact_in && round == 0 && !seq) { in0_u = cp[0]; in0_w = in0_u * q[0]; }
             in_u = in0_u; in_w = in0_w;
         } else { in_u = cp[0]; in_w = in_u * q[0]; }
     } else {
         const bool tail = bwd_has_end ? tid >= local_last : false;
         if (tail) { in_u = end_u; in_w = (R)0; }
         else if (tid == T - 1) {
-            if (round == 0) { in0_u = u[L - 1]; in0_w = in0_u * q[L - 1]; }
+            if (round == 0 && !seq) { in0_u = u[L - 1]; in0_w = in0_u * q[L - 1]; }
             in_u = in0_u; in_w = in0_w;
         } else { in_u = u[L - 1]; in_w = in_u * q[L - 1]; }
     }
@@ -1085,14 +1089,14 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_long(int S, int nsc, in
     const int owner = BWD ? 0 : T - 1;
     if (tid == owner) {
         const R ou = BWD ? out_u : s_u[pbl][T], ow = BWD ? out_w : s_w[pbl][T];
-        const bool diff = round == 0 || !(same_bits(ou, bnd_prev[if_out * 2]) && same_bits(ow, bnd_prev[if_out * 2 + 1]));
+        const bool diff = !seq && (round == 0 || !(same_bits(ou, bnd_prev[if_out * 2]) && same_bits(ow, bnd_prev[if_out * 2 + 1])));
         bnd_cur[if_out * 2] = ou;
         bnd_cur[if_out * 2 + 1] = ow;
         my_out[0] = ou;
         my_out[1] = ow;
         // a guessed incoming state (super-round 0) is recorded as "never": the next super-round
         // re-evaluates with whatever the neighbour published
-        const bool guessed = round == 0 && !exact_in;
+        const bool guessed = round == 0 && !exact_in && !seq;
         my_used[0] = guessed ? (R)NAN : in0_u;
         my_used[1] = guessed ? (R)NAN : in0_w;
         if (diff) atomicAdd(changed, 1);
@@ -1374,11 +1378,11 @@ static hipError_t velocity_long_t(hipStream_t st, int B, int S, const double c[6
             int *ch = changed + dir * (nsc + 2) + round;
             if (dir == 0)
                 hipLaunchKernelGGL((k_velocity_long<R, L, MAXT, MINW, false>), dim3(nsc, B), dim3(MAXT), lds, st, S, nsc,
-                                   round, make_consts<R>(c), s * s, e * e, meta, (const R *)curv, (const R *)dth,
+                                   round, -1, make_consts<R>(c), s * s, e * e, meta, (const R *)curv, (const R *)dth,
                                    (R *)ufwd, (R *)vel, bnd, used, outst, dup, ch, flags);
             else
                 hipLaunchKernelGGL((k_velocity_long<R, L, MAXT, MINW, true>), dim3(nsc, B), dim3(MAXT), lds, st, S, nsc,
-                                   round, make_consts<R>(c), s * s, e * e, meta, (const R *)curv, (const R *)dth,
+                                   round, -1, make_consts<R>(c), s * s, e * e, meta, (const R *)curv, (const R *)dth,
                                    (R *)ufwd, (R *)vel, bnd, used, outst, dup, ch, flags);
             if ((err = hipGetLastError()) != hipSuccess) return err;
             // super-round convergence is decided on the host: one 4-byte read per super-round
@@ -1410,6 +1414,44 @@ hipError_t launch_velocity_long(hipStream_t st, bool f64, int B, int S, const do
 {
     if (f64) return velocity_long_t<double, 16, 512, 2>(st, B, S, c, sv, ev, meta, curv, dth, vel, flags, ufwd, state, counters);
     return velocity_long_t<float, 40, 256, 2>(st, B, S, c, sv, ev, meta, curv, dth, vel, flags, ufwd, state, counters);
+}
+
+// K5b': many paths, fp32: one wave per path walks the row in windows of 64*L samples, one launch per
+// window and direction (stream-ordered, no host synchronisation).  A window's incoming interface state
+// is final when its launch starts, so every window is relaxed exactly once; a row of 5 registers per
+// sample no longer has to stay resident, so eight paths share a CU instead of two.
+size_t velocity_windows_state_bytes(int B, int S)
+{
+    const int nsc = (S + 64 * 40 - 1) / (64 * 40);
+    return 4 * ((size_t)2 * B * (nsc + 1) * 2 + (size_t)2 * B * nsc * 2) + 64;
+}
+
+hipError_t launch_velocity_windows(hipStream_t st, int B, int S, const double c[6], double sv, double ev,
+                                   const double *meta, const void *curv, const void *dth, void *vel, uint32_t *flags,
+                                   void *ufwd, void *state, int *counters)
+{
+    using R = float;
+    constexpr int L = 40, T = 64, SC = T * L;
+    const int nsc = (S + SC - 1) / SC;
+    const R s = (R)sv, e = (R)ev;
+    const size_t lds = sizeof(R) * ((size_t)T * L + T + 8);
+    R *bnd = (R *)state;
+    R *used = bnd + (size_t)2 * B * (nsc + 1) * 2;
+    R *outst = used + (size_t)B * nsc * 2;
+    int *dup = counters, *changed = counters + B;
+    hipError_t err;
+    if ((err = hipMemsetAsync(counters, 0, sizeof(int) * ((size_t)B + 8), st)) != hipSuccess) return err;
+    hipLaunchKernelGGL(k_dup_scan, dim3(8, B), dim3(256), 0, st, B, S, meta, (const float *)curv, nullptr, (const float *)dth,
+                       nullptr, dup);
+    for (int sc = 0; sc < nsc; sc++)
+        hipLaunchKernelGGL((k_velocity_long<R, L, T, 2, false>), dim3(1, B), dim3(T), lds, st, S, nsc, 0, sc,
+                           make_consts<R>(c), s * s, e * e, meta, (const R *)curv, (const R *)dth, (R *)ufwd, (R *)vel, bnd,
+                           used, outst, dup, changed, flags);
+    for (int sc = nsc - 1; sc >= 0; sc--)
+        hipLaunchKernelGGL((k_velocity_long<R, L, T, 2, true>), dim3(1, B), dim3(T), lds, st, S, nsc, 0, sc,
+                           make_consts<R>(c), s * s, e * e, meta, (const R *)curv, (const R *)dth, (R *)ufwd, (R *)vel, bnd,
+                           used, outst, dup, changed, flags);
+    return hipGetLastError();
 }
 
 hipError_t launch_power(hipStream_t st, int n_seg, const double *seg, double *pw)
