@@ -752,7 +752,7 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
         }
         if (need) s_any[rounds % 3] = 1;
         rounds++;
-        if (rounds > T + 3) {
+        if (rounds > 2 * T + 8) {
             if (tid == 0 && flags) atomicOr(&flags[b], VAP_FLAG_NOCONVERGE_BIT);
             break;
         }
@@ -824,7 +824,7 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
         }
         if (need) s_any[rounds % 3] = 1;
         rounds++;
-        if (rounds > T + 3) {
+        if (rounds > 2 * T + 8) {
             if (tid == 0 && flags) atomicOr(&flags[b], VAP_FLAG_NOCONVERGE_BIT);
             break;
         }
@@ -1068,7 +1068,7 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_long(int S, int nsc, in
         }
         if (need) s_any[rounds % 3] = 1;
         rounds++;
-        if (rounds > T + 3) {
+        if (rounds > 2 * T + 8) {
             if (tid == 0 && flags) atomicOr(&flags[b], VAP_FLAG_NOCONVERGE_BIT);
             break;
         }
@@ -1297,7 +1297,7 @@ hipError_t launch_velocity_seq(hipStream_t st, bool f64, bool fast, int B, int S
 }
 
 // Largest sample capacity the register-resident relaxation kernel covers.
-int velocity_relax_max_samples(bool f64) { return f64 ? 512 * 16 : 512 * 40; }
+int velocity_relax_max_samples(bool f64) { return f64 ? 512 * 20 : 512 * 40; }
 
 template <typename R, int L, int MAXT, int MINW>
 static void launch_relax_t(hipStream_t st, int B, int S, const double c[6], double sv, double ev,
@@ -1335,15 +1335,18 @@ hipError_t launch_velocity_relax(hipStream_t st, bool f64, int B, int S, const d
                                  uint32_t *flags)
 {
 #define VAP_RELAX(R_, L_, MAXT_, W_) launch_relax_t<R_, L_, MAXT_, W_>(st, B, S, c, sv, ev, meta, curv, dth, vel, flags)
+    // chunk length: the longest instantiated L whose thread count still covers the row — fewer, longer
+    // chunks mean fewer rounds (rounds ~ longest unclamped run / L) and fewer waves to synchronise
     if (f64) {
-        if (S <= 256 * 4) VAP_RELAX(double, 4, 256, 4);
-        else VAP_RELAX(double, 16, 512, 2);
+        if (S <= 64 * 4) VAP_RELAX(double, 4, 256, 4);
+        else if (S <= 512 * 8) VAP_RELAX(double, 8, 512, 4);
+        else VAP_RELAX(double, 20, 512, 2);
         return hipGetLastError();
     }
     // developer knob (tuning only): VAP_RELAX_CFG=<L>, one of the instantiated chunk lengths
     static const char *cfg = getenv("VAP_RELAX_CFG");
     int L = cfg ? atoi(cfg) : 0;
-    if (L == 0) L = S <= 256 * 4 ? 4 : (S <= 256 * 16 ? 16 : 40);
+    if (L == 0) L = S <= 64 * 4 ? 4 : (S <= 256 * 16 ? 16 : 40);
     if (L == 4 && S <= 1024 * 4) VAP_RELAX(float, 4, 1024, 8);
     else if (L == 10 && S <= 1024 * 10) VAP_RELAX(float, 10, 1024, 4);
     else if (L == 16 && S <= 512 * 16) VAP_RELAX(float, 16, 512, 4);
