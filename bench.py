@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=("f32", "f64"))
     ap.add_argument("--paths-per-gpu", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="process-group backend; gloo + --share-device rehearses the multi-rank path on a 1-GPU box")
+    ap.add_argument("--share-device", action="store_true", help="(rehearsal) every rank uses cuda:0")
     args = ap.parse_args()
 
     import torch
@@ -96,11 +99,16 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     wl = dict(WORKLOADS[args.workload])
     if args.paths_per_gpu:

@@ -13,6 +13,11 @@ import torch
 import torch.distributed as dist
 
 
+def _comm_device(t: torch.Tensor) -> torch.device:
+    """gloo moves host memory; RCCL moves device memory."""
+    return torch.device("cpu") if dist.get_backend() == "gloo" else t.device
+
+
 def world() -> Tuple[int, int]:
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
@@ -32,7 +37,9 @@ def broadcast_constraints(constraints, device, src: int = 0):
     vals = [float(v) for v in constraints] if (rank == src and constraints is not None) else [0.0] * 6
     t = torch.tensor(vals, dtype=torch.float64, device=device)
     if ws > 1:
-        dist.broadcast(t, src=src)
+        tc = t.to(_comm_device(t))
+        dist.broadcast(tc, src=src)
+        t = tc
     return [float(v) for v in t.cpu()]
 
 
@@ -66,11 +73,12 @@ def all_gather_rows(local: torch.Tensor, n_paths: int) -> torch.Tensor:
         return local
     sizes = [shard_bounds(n_paths, r, ws) for r in range(ws)]
     width = max(b - a for a, b in sizes)
-    pad = torch.zeros((width,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    pad[: local.shape[0]] = local
+    cdev = _comm_device(local)
+    pad = torch.zeros((width,) + tuple(local.shape[1:]), dtype=local.dtype, device=cdev)
+    pad[: local.shape[0]] = local.to(cdev)
     bufs = [torch.empty_like(pad) for _ in range(ws)]
     dist.all_gather(bufs, pad)
-    return torch.cat([bufs[r][: sizes[r][1] - sizes[r][0]] for r in range(ws)])
+    return torch.cat([bufs[r][: sizes[r][1] - sizes[r][0]] for r in range(ws)]).to(local.device)
 
 
 def gather_rows_to_root(local: torch.Tensor, n_paths: int, dst: int = 0) -> Optional[torch.Tensor]:
