@@ -40,7 +40,12 @@ def cpu_baseline(wl, budget_s=12.0):
     """The fp64 C restatement (oracle/, kind "port") on this box's host cores, bounded sample."""
     from oracle import oracle
     from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
-    cores = os.cpu_count() or 1
+    # threads: the cores this process may run on, capped (a 1-GPU box shares its host)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 32))
     W, S = wl["W"], min(wl["S"], 100000)
     wp = make_waypoints(max(2 * cores, 8), W, wl["seed"]).astype(np.float64)
     t0 = time.perf_counter()

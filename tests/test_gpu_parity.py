@@ -247,3 +247,46 @@ def test_wave_per_path_ragged_rows(torch_mod):
         assert np.all(r["flags"] == 0)
         outs[which] = r["velocity"]
     assert np.array_equal(outs["relax_wave"], outs["seq_fast"])
+
+
+def test_edge_sizes_and_degenerate_inputs(torch_mod, gens):
+    """Minimum and maximum sizes, odd row lengths, coincident waypoints, non-finite input: defined
+    outputs and flags, never a hang or a fault."""
+    from oracle import oracle
+    from vexautonomousplanner_amd import _lib
+    from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
+    gen = gens["f32"]
+    torch = torch_mod
+    # smallest row: 2 samples (start and end sample only)
+    wp = make_waypoints(3, 4, 50).astype(np.float64)
+    r = run_gpu(torch, gen, wp, samples=2)
+    assert np.all(r["flags"] == 0) and np.allclose(r["velocity"], 0.01)
+    # odd row lengths exercise the unaligned store / stage paths
+    for S in (3, 5, 63, 257, 1021, 4099):
+        ref = oracle.profile_batch(wp, S, DEFAULT_CONSTRAINTS)
+        r = run_gpu(torch, gen, wp, samples=S)
+        assert np.all(r["flags"] == 0)
+        check_fields(r, ref, 1e-5, f"odd S={S}")
+    # widest supported path: 2048 waypoints (k_fit LDS limit); one more is refused, not truncated
+    wide = make_waypoints(1, 2048, 51).astype(np.float64)
+    ref = oracle.profile_batch(wide, 3000, DEFAULT_CONSTRAINTS)
+    r = run_gpu(torch, gen, wide, samples=3000)
+    assert np.all(r["flags"] == 0)
+    check_fields(r, ref, 1e-5, "W=2048")
+    with pytest.raises(_lib.VapError) as e:
+        gen.profile(torch.zeros((1, 2049, 2), dtype=gen.tdtype, device=gen.device), samples=100)
+    assert e.value.status == _lib.VAP_ERR_UNSUPPORTED
+    # coincident waypoints: the reference produces NaNs and then raises; here the path is flagged
+    bad = wp.copy()
+    bad[1, 2] = bad[1, 1]
+    r = run_gpu(torch, gen, bad, samples=300)
+    assert r["flags"][1] & _lib.FLAG_DEGENERATE
+    assert r["flags"][0] == 0 and r["flags"][2] == 0
+    good = oracle.profile_batch(wp[[0, 2]], 300, DEFAULT_CONSTRAINTS)
+    np.testing.assert_allclose(r["velocity"][[0, 2]], good["velocity"], rtol=1e-5)   # neighbours unaffected
+    # non-finite waypoint: flagged, finite rows elsewhere, and the call returns
+    nanp = wp.copy()
+    nanp[2, 1, 0] = np.nan
+    r = run_gpu(torch, gen, nanp, samples=300)
+    assert r["flags"][2] & _lib.FLAG_DEGENERATE
+    assert np.all(np.isfinite(r["velocity"][:2]))
