@@ -37,7 +37,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
 def cpu_baseline(wl, budget_s=12.0):
-    """The fp64 C restatement (oracle/, kind "port") on this box's host cores, bounded sample."""
+    """The fp64 C restatement (oracle/, kind "port") on this box's host cores, bounded sample: batches of
+    paths from the same generator until about budget_s seconds of CPU work have been timed."""
     from oracle import oracle
     from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
     # threads: the cores this process may run on, capped (a 1-GPU box shares its host)
@@ -47,18 +48,20 @@ def cpu_baseline(wl, budget_s=12.0):
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, 32))
     W, S = wl["W"], min(wl["S"], 100000)
-    wp = make_waypoints(max(2 * cores, 8), W, wl["seed"]).astype(np.float64)
-    t0 = time.perf_counter()
-    oracle.profile_batch(wp[:cores], S, DEFAULT_CONSTRAINTS, n_threads=cores, want=("velocity",))
-    t_cal = max(time.perf_counter() - t0, 1e-4)
-    n = int(min(4096, max(cores, cores * int(budget_s / t_cal))))
-    wp = make_waypoints(n, W, wl["seed"]).astype(np.float64)
-    t0 = time.perf_counter()
-    oracle.profile_batch(wp, S, DEFAULT_CONSTRAINTS, n_threads=cores, want=("velocity",))
-    dt = time.perf_counter() - t0
-    return {"value": n * S / dt, "unit": "sample-points/s", "cores": cores, "kind": "port",
-            "sample": f"{n} paths x {W} waypoints x {S} samples of the same generator, "
-                      f"{cores} threads, {dt:.1f}s"}
+    per_batch = max(cores, min(wl["paths"], 16 * cores))
+    oracle.profile_batch(make_waypoints(cores, W, wl["seed"]).astype(np.float64), min(S, 2000), DEFAULT_CONSTRAINTS,
+                         n_threads=cores, want=("velocity",))          # warm-up: library load, thread start
+    done, elapsed, k = 0, 0.0, 0
+    while elapsed < budget_s and k < 512:
+        wp = make_waypoints(per_batch, W, wl["seed"] + 1000 * k).astype(np.float64)
+        t0 = time.perf_counter()
+        oracle.profile_batch(wp, S, DEFAULT_CONSTRAINTS, n_threads=cores, want=("velocity",))
+        elapsed += time.perf_counter() - t0
+        done += per_batch
+        k += 1
+    return {"value": done * S / elapsed, "unit": "sample-points/s", "cores": cores, "kind": "port",
+            "sample": f"{done} paths x {W} waypoints x {S} samples of the same generator in {k} batches, "
+                      f"{cores} threads, {elapsed:.1f}s of CPU work"}
 
 
 def profiled_traffic(stage, workload, dtype, paths):

@@ -7,7 +7,7 @@ set -e
 tag=${1:-r01}
 root=$GRAFT_REPO_ROOT
 out=$root/gpurun_out/prof_$tag
-mkdir -p $out $root/profiles
+mkdir -p $out $root/profiles $root/gpurun_out/profiles
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python $root/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $out/trace.log 2>&1
 cp $out/trace/*/*kernel_stats.csv $root/profiles/${tag}_kernel_stats.csv
@@ -34,3 +34,5 @@ for k in sorted(set(fetch) | set(write)):
 json.dump(res, open("$root/profiles/${tag}_traffic.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
+# gpurun merges only gpurun_out/ back: leave copies there for the caller to move into profiles/
+cp $root/profiles/${tag}_kernel_stats.csv $root/profiles/${tag}_traffic.json $root/gpurun_out/profiles/
