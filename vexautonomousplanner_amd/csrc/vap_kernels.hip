@@ -320,7 +320,8 @@ __global__ void k_grid(int B, int W, int S, double dd_in, double *__restrict__ m
 // K3+K4: sampling.  grid = (tiles, B); a workgroup evaluates kSampleChunk consecutive samples of one
 // path, each thread kSPT consecutive ones (so every output leaves as one 16-byte store per lane and
 // the arc-length table is walked, not searched, after the thread's first sample).  The last thread's
-// samples belong to the next tile: they only supply the neighbour for |dtheta|.
+// samples belong to the next tile: they only supply the neighbour for |dtheta| (rows that fit one pass,
+// S <= kSampleChunk, need no such neighbour and are written by all threads).
 // LDS: distance table + interval slopes (16 KB), the path's coefficient blocks when they fit
 // (G <= kLdsCoefSegments; otherwise they are read through L1/L2, where a wavefront's consecutive
 // samples hit one or two blocks), and a 256-entry neighbour exchange.
@@ -344,7 +345,7 @@ __device__ __forceinline__ double curvature_of(double num, double ss)
 }
 
 template <typename OT, bool COEF_LDS>
-__global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int tiles_per_block,
+__global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int tile, int tiles_per_block,
                                                            const double *__restrict__ power,
                                                            const double *__restrict__ lut,
                                                            const double *__restrict__ slopes,
@@ -369,15 +370,17 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int 
     const double *ax = aux + (size_t)b * kAuxStride;
     const double lstep = ax[0], tstep = ax[1], inv_tstep = ax[2];
     const int tile0 = blockIdx.x * tiles_per_block;
-    if (tile0 * kSampleTile >= S) return;
+    if (tile0 * tile >= S) return;
     const size_t row = (size_t)b * S;
-    const bool writer = tid < kSampleThreads - 1;
+    // tile == kSampleChunk: the whole row is one tile, so the last thread's last sample is the row's last
+    // and needs no neighbour — every thread writes
+    const bool writer = tile == kSampleChunk || tid < kSampleThreads - 1;
     constexpr int VW = 16 / sizeof(OT);   // elements per 16-byte store
     const bool aligned = (S % VW) == 0;   // rows (and tile starts, multiples of kSPT) then start 16-byte aligned
 
     // the path's tables are staged once and serve every tile of this workgroup
     const double *pw = power + (size_t)b * G * kCoefDoubles;
-    if (tile0 * kSampleTile < N) {
+    if (tile0 * tile < N) {
         lds_fill<4>(sD, lut + (size_t)b * kLutN, kLutN, tid, kSampleThreads);
         lds_fill<4>(sWt, slopes + (size_t)b * kLutN, kLutN, tid, kSampleThreads);
         if constexpr (COEF_LDS) lds_fill<4>(s_coef, pw, G * kCoefDoubles, tid, kSampleThreads);
@@ -389,7 +392,7 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int 
     const int tab_n = W * kSamplesPerNode;
 
     for (int tl = 0; tl < tiles_per_block; tl++) {
-        const int k0 = (tile0 + tl) * kSampleTile;
+        const int k0 = (tile0 + tl) * tile;
         if (k0 >= S) break;
         const int kbase = k0 + tid * kSPT;
         auto store_vec = [&](OT *dst, const OT v[kSPT]) {
@@ -1233,7 +1236,10 @@ hipError_t launch_sample(hipStream_t st, bool f64, int B, int W, int S, const do
 {
     // one workgroup stages a path's tables once and walks tiles_per_block consecutive tiles; paths are
     // split over several workgroups only when the batch alone cannot fill the chip
-    const int n_tiles = (S + kSampleTile - 1) / kSampleTile;
+    // a tile is kSampleTile samples (the last thread only feeds its neighbour's |dtheta|) unless the whole
+    // row fits one workgroup pass (S <= kSampleChunk, e.g. 1024-sample rows), where no neighbour is needed
+    const int tile = S <= kSampleChunk ? kSampleChunk : kSampleTile;
+    const int n_tiles = (S + tile - 1) / tile;
     int split = (2048 + B - 1) / B;
     split = split < 1 ? 1 : (split > n_tiles ? n_tiles : split);
     const int tiles_per_block = (n_tiles + split - 1) / split;
@@ -1246,7 +1252,7 @@ hipError_t launch_sample(hipStream_t st, bool f64, int B, int W, int S, const do
     const size_t n_waves = (size_t)grid.x * grid.y * 4;
     if (want_stats) (void)hipMalloc(&stats, n_waves * 4 * sizeof(long long));
 #define VAP_SAMPLE(OT_, LDS_)                                                                                      \
-    hipLaunchKernelGGL((k_sample<OT_, LDS_>), grid, dim3(kSampleThreads), lds, st, W, S, tiles_per_block, pw, lut, \
+    hipLaunchKernelGGL((k_sample<OT_, LDS_>), grid, dim3(kSampleThreads), lds, st, W, S, tile, tiles_per_block, pw, lut, \
                        slopes, meta, aux, (OT_ *)x, (OT_ *)y, (OT_ *)h, (OT_ *)k, (OT_ *)dth, stats)
     if (f64) { if (in_lds) VAP_SAMPLE(double, true); else VAP_SAMPLE(double, false); }
     else { if (in_lds) VAP_SAMPLE(float, true); else VAP_SAMPLE(float, false); }
