@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=("f32", "f64"))
     ap.add_argument("--paths-per-gpu", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--time-domain", action="store_true",
+                    help="also time the batched time-domain resample (vap_time_profile) after the timed region")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="process-group backend; gloo + --share-device rehearses the multi-rank path on a 1-GPU box")
     ap.add_argument("--share-device", action="store_true", help="(rehearsal) every rank uses cuda:0")
@@ -172,6 +174,23 @@ def main():
     gen.ctx.set_timing(False)
 
     flags = int(out["flags"].abs().max().item())
+    # after the timed region, outside `value`: the time-domain resample of the same batch (SURVEY §8(f)-1,
+    # what generate_motion_profile does with the velocity rows), on request
+    time_domain = None
+    if args.time_domain and world == 1 and wl["S"] <= 100000:
+        cap_rows = 4096
+        tp = gen.time_profile(out, constraints, capacity_rows=cap_rows)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            tp = gen.time_profile(out, constraints, capacity_rows=cap_rows, out=tp)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        n_rows = int(tp["counts"][:, 0].sum().item())
+        ms = e0.elapsed_time(e1) / 3
+        time_domain = {"ms": ms, "rows": n_rows, "rows_per_s": n_rows / (ms * 1e-3), "dt_s": 0.01,
+                       "truncated_paths": int((tp["counts"][:, 0] >= cap_rows).sum().item())}
     # after the timed region: all-gather per-path summaries (length, samples, traversal time) over RCCL —
     # 24 B/path, what a caller ranking candidate trajectories needs from the other GPUs
     summ = vdist.all_gather_rows(vdist.path_summaries(out["meta"], out["velocity"]), B * world)
@@ -208,6 +227,8 @@ def main():
                          "frac_of_hbm_peak": bytes_per_point * B * S / (acc["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "stage_ms": {k: round(v, 4) for k, v in acc.items()}},
         }
+        if time_domain is not None:
+            line["time_domain"] = time_domain
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(line))

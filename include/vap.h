@@ -139,6 +139,24 @@ int vap_velocity_pass(vap_ctx *ctx, vap_dtype dt, int B, int S, const vap_constr
                       const void *d_curvature, const void *d_dtheta, const void *d_vcap,
                       void *d_velocity, uint32_t *d_flags);
 
+/* MPG:413-628, the time-domain resample that generate_motion_profile runs after
+ * forward_backward_pass, for B plain-node paths (no turn / wait / reverse nodes and no action points:
+ * those insert rows — use vap_route_motion_profile).  One row per time step of `time_step` seconds
+ * (0.01 in the reference, MPG:389):
+ *   rows      [B][capacity_rows][8] fp64  {time, position, linear velocity, acceleration, heading,
+ *                                          angular velocity, x, y}   (MPG:558-592)
+ *   counts    [B][2] int                  {rows written, entries of nodes_map}
+ *   nodes_map [B][W] int                  row index at which each node is passed (MPG:420, 527-529;
+ *                                          quirk Q5: the last node is never recorded)
+ * d_velocity is the [B][S] result of vap_velocity_pass / vap_profile_batch in `dt`; d_meta as above.
+ * d_segments / d_lut may both be NULL: the tables this context built in its last vap_profile_batch
+ * call (same B and W) are used.  A path needing more than capacity_rows rows is cut there and flagged
+ * VAP_FLAG_TRUNCATED. */
+int vap_time_profile(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, const double *d_segments,
+                     const double *d_lut, const double *d_meta, const void *d_velocity,
+                     const vap_constraints *c, double time_step, int capacity_rows, double *d_rows,
+                     int *d_counts, int *d_nodes_map, uint32_t *d_flags);
+
 /* ---- fused hot path ------------------------------------------------------------------------ */
 
 /* rebuild_tables (SM:582-594) + forward_backward_pass (MPG:70-316) for B plain-node paths, inputs

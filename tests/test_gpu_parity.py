@@ -290,3 +290,88 @@ def test_edge_sizes_and_degenerate_inputs(torch_mod, gens):
     r = run_gpu(torch, gen, nanp, samples=300)
     assert r["flags"][2] & _lib.FLAG_DEGENERATE
     assert np.all(np.isfinite(r["velocity"][:2]))
+
+
+# ---- batched time-domain resample (vap_time_profile; SURVEY §8(f)-1 at batch scale) -----------------
+def _time_profile(dtype, wp, dt=0.01, cap=4096):
+    import torch
+    from vexautonomousplanner_amd.batch import BatchedTrajectoryGenerator
+    from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS
+    gen = BatchedTrajectoryGenerator(0, dtype)
+    t = torch.tensor(wp, device="cuda:0", dtype=torch.float64 if dtype == "f64" else torch.float32)
+    res = gen.profile(t, DEFAULT_CONSTRAINTS, dd=0.005, capacity=16384)
+    tp = gen.time_profile(res, DEFAULT_CONSTRAINTS, dt=dt, capacity_rows=cap)
+    torch.cuda.synchronize()
+    return ({k: v.cpu().numpy() for k, v in tp.items()}, res["flags"].cpu().numpy())
+
+
+@pytest.mark.gpu
+def test_time_profile_batch_matches_reference_golden():
+    """Config 1: the reference's own 9-tuple (generate_motion_profile on the 8-waypoint path), through the
+    batched kernels with the path replicated next to two others."""
+    from vexautonomousplanner_amd.synth import make_waypoints
+    g = gu.load("c1_w8")
+    others = make_waypoints(2, 8, 77).astype(np.float64)
+    wp = np.concatenate([others[:1], g["waypoints"][None], others[1:]], axis=0)
+    tp, flags = _time_profile("f64", wp)
+    assert not flags.any()
+    T = len(g["profile_times"])
+    assert int(tp["counts"][1, 0]) == T
+    rows = tp["rows"][1, :T]
+    nm = g["profile_nodes_map"]
+    assert int(tp["counts"][1, 1]) == len(nm)
+    assert [int(v) for v in tp["nodes_map"][1, :len(nm)]] == [int(v) for v in nm]
+    for col, key in ((0, "times"), (1, "positions"), (2, "linear_vels"), (3, "accelerations"), (4, "headings"),
+                     (5, "angular_vels")):
+        ref = g["profile_" + key]
+        err = np.max(np.abs(rows[:, col] - ref) / np.maximum(np.abs(ref), 1.0))
+        assert err <= 1e-8, (key, err)
+    assert np.max(np.abs(rows[:, 6:8] - g["profile_coords"])) <= 1e-8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W", [5, 8, 32])
+def test_time_profile_batch_matches_oracle(W):
+    """fp64 batch vs the oracle time loop path by path: same row count, same node rows, values to 1e-7
+    (position errors of the distance-domain velocities, <= 4e-11 each, add up over ~10^3 time steps)."""
+    from oracle import oracle
+    from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
+    wp = make_waypoints(12, W, 400 + W).astype(np.float64)
+    tp, flags = _time_profile("f64", wp)
+    assert not flags.any()
+    for b in range(wp.shape[0]):
+        rows, nmap, _ = oracle.OraclePath(wp[b]).generate_motion_profile(DEFAULT_CONSTRAINTS, dt=0.01, dd=0.005)
+        T = rows.shape[0]
+        assert int(tp["counts"][b, 0]) == T, (b, int(tp["counts"][b, 0]), T)
+        assert [int(v) for v in tp["nodes_map"][b, :int(tp["counts"][b, 1])]] == [int(v) for v in nmap]
+        got = tp["rows"][b, :T]
+        err = np.max(np.abs(got - rows) / np.maximum(np.abs(rows), 1.0))
+        assert err <= 1e-7, (b, err)
+
+
+@pytest.mark.gpu
+def test_time_profile_batch_fp32_and_truncation():
+    """fp32 velocity rows: the time grid is discrete, so a 2e-6 velocity difference may move the end by a
+    row; the rows both have must agree to 1e-4 (table-quantised columns: at 97 % of the rows).  A too-small capacity cuts the path there and flags it."""
+    from oracle import oracle
+    from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
+    wp = make_waypoints(8, 8, 913).astype(np.float64)
+    tp, flags = _time_profile("f32", wp)
+    assert not flags.any()
+    for b in range(wp.shape[0]):
+        rows, _, _ = oracle.OraclePath(wp[b]).generate_motion_profile(DEFAULT_CONSTRAINTS, dt=0.01, dd=0.005)
+        T = int(tp["counts"][b, 0])
+        assert abs(T - rows.shape[0]) <= 1
+        n = min(T, rows.shape[0]) - 1
+        err = np.abs(tp["rows"][b, :n] - rows[:n]) / np.maximum(np.abs(rows[:n]), 1.0)
+        # time, position, velocity, x, y are continuous in the velocity rows; the acceleration is a
+        # difference of velocities over dt = 0.01 (MPG:572), so it carries 100x their 2e-6
+        assert err[:, [0, 1, 2, 6, 7]].max() <= 1e-4, (b, err[:, [0, 1, 2, 6, 7]].max())
+        assert err[:, 3].max() <= 1e-3, (b, err[:, 3].max())
+        # heading and angular velocity come from the reference's step lookup (SM:550-580): a position that
+        # differs in the 6th digit lands on the neighbouring table entry at isolated rows
+        assert np.mean(err[:, [4, 5]].max(axis=1) <= 1e-4) >= 0.97, b
+        assert err[:, [4, 5]].max() <= 5e-2, (b, err[:, [4, 5]].max())
+    tp, flags = _time_profile("f64", wp, cap=100)
+    assert (tp["counts"][:, 0] == 100).all()
+    assert (flags & 2).all()          # VAP_FLAG_TRUNCATED

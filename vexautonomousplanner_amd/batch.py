@@ -94,5 +94,39 @@ class BatchedTrajectoryGenerator:
         _lib.check(st, "vap_profile_batch")
         return res
 
+    def time_profile(self, result, constraints=DEFAULT_CONSTRAINTS, dt=0.01, capacity_rows=None, out=None):
+        """Time-domain resample (the loop of generate_motion_profile, MPG:413-628) of the batch that
+        ``profile`` has just produced with this generator: ``result`` is its return value (the
+        velocity rows and meta are read from it, the spline tables from the context).
+
+        Returns a dict with
+          rows      (B, capacity_rows, 8) fp64: time, position, velocity, acceleration, heading,
+                    angular velocity, x, y per time step of ``dt`` seconds (MPG:558-592)
+          counts    (B, 2) int32: rows written, entries of nodes_map
+          nodes_map (B, W) int32: row index at which each node is passed (MPG:420, 527-529)
+        Paths that need more than capacity_rows rows are cut there and flagged (result["flags"]).
+        """
+        vel, meta = result["velocity"], result["meta"]
+        B, S = vel.shape
+        W = int(round(float(meta[0, 0].item()))) + 1     # parameters[-1] = W - 1 (QHS:736)
+        if capacity_rows is None:
+            capacity_rows = 4096
+        res = {} if out is None else out
+        if "rows" not in res or res["rows"].shape != (B, capacity_rows, 8):
+            res["rows"] = torch.empty((B, capacity_rows, 8), dtype=torch.float64, device=self.device)
+        if "counts" not in res or res["counts"].shape != (B, 2):
+            res["counts"] = torch.empty((B, 2), dtype=torch.int32, device=self.device)
+        if "nodes_map" not in res or res["nodes_map"].shape != (B, W):
+            res["nodes_map"] = torch.empty((B, W), dtype=torch.int32, device=self.device)
+        c = _lib.make_constraints(constraints)
+        self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        st = self._L.vap_time_profile(self.ctx.handle, self.vdtype, B, W, S, None, None,
+                                      C.c_void_p(meta.data_ptr()), C.c_void_p(vel.data_ptr()), C.byref(c),
+                                      float(dt), int(capacity_rows), C.c_void_p(res["rows"].data_ptr()),
+                                      C.c_void_p(res["counts"].data_ptr()), C.c_void_p(res["nodes_map"].data_ptr()),
+                                      C.c_void_p(result["flags"].data_ptr()))
+        _lib.check(st, "vap_time_profile")
+        return res
+
     def timing(self):
         return self.ctx.last_timing()

@@ -320,6 +320,29 @@ int vap_profile_batch(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd
     VAP_TRY(run_velocity(ctx, f64, B, S, cc, start_vel, end_vel, meta, curv, ctx->dth.ptr, nullptr, d_velocity,
                          flags));
     tm.mark(VAP_T_VELOCITY);
+    ctx->last_B = B;
+    ctx->last_W = W;
+    return VAP_OK;
+}
+
+int vap_time_profile(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, const double *d_segments, const double *d_lut,
+                     const double *d_meta, const void *d_velocity, const vap_constraints *c, double time_step,
+                     int capacity_rows, double *d_rows, int *d_counts, int *d_nodes_map, uint32_t *d_flags)
+{
+    VAP_TRY(vap_set_device(ctx));
+    VAP_TRY(check_shape(B, W, S));
+    if (!d_meta || !d_velocity || !c || !d_rows || !d_counts || !d_nodes_map) return vap_fail(VAP_ERR_INVALID, "null buffer");
+    if (!(time_step > 0) || capacity_rows < 1) return vap_fail(VAP_ERR_INVALID, "time_step and capacity_rows must be positive");
+    if ((d_segments == nullptr) != (d_lut == nullptr)) return vap_fail(VAP_ERR_INVALID, "pass both d_segments and d_lut, or neither");
+    if (!d_segments) {
+        if (ctx->last_B != B || ctx->last_W != W || !ctx->seg.ptr || !ctx->lut.ptr)
+            return vap_fail(VAP_ERR_UNFITTED, "no tables of a %d x %d batch in this context (last vap_profile_batch: %d x %d)", B,
+                            W, ctx->last_B, ctx->last_W);
+        d_segments = (const double *)ctx->seg.ptr;
+        d_lut = (const double *)ctx->lut.ptr;
+    }
+    HIP_TRY(vap::launch_time_profile(ctx->stream, dt == VAP_F64, B, W, S, d_segments, d_lut, d_meta, d_velocity, c->max_acc,
+                                     c->max_dec, time_step, capacity_rows, d_rows, d_counts, d_nodes_map, d_flags));
     return VAP_OK;
 }
 

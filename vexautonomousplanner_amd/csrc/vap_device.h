@@ -503,4 +503,76 @@ __device__ __forceinline__ R fast_backward(const FastConsts<R> &c, R q, R g, R A
     return vmin(vmin(med3(x, u, u + A), cap), u_prev);
 }
 
+// Cooperative copy of n doubles from HBM/L2 into LDS: up to ITER loads per thread are issued before
+// the first LDS write, so a workgroup pays the memory latency once instead of once per element.
+template <int ITER>
+__device__ __forceinline__ void lds_fill(double *__restrict__ dst, const double *__restrict__ src, int n, int tid, int nt)
+{
+    for (int base = 0; base < n; base += ITER * nt) {
+        double v[ITER];
+#pragma unroll
+        for (int it = 0; it < ITER; it++) {
+            const int i = base + tid + it * nt;
+            v[it] = i < n ? src[i] : 0.0;
+        }
+#pragma unroll
+        for (int it = 0; it < ITER; it++) {
+            const int i = base + tid + it * nt;
+            if (i < n) dst[i] = v[it];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Scalar helpers of the time-domain resample (MPG:389-628), shared by the single-route kernel
+// (vap_route.hip) and the batched one (vap_time.hip).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double mod1(double v) { return fmod(v, 1.0); }
+
+__device__ __forceinline__ double py_mod(double a, double b)   // Python float % for b > 0
+{
+    double m = fmod(a, b);
+    if (m != 0.0) { if (m < 0) m += b; }
+    else m = copysign(0.0, b);
+    return m;
+}
+
+// np.searchsorted(xs, x, side="right") - 1 over xs[i] = i*dd, i < n: the largest i with i*dd <= x
+// (-1 if none).  The predicate is monotone in i, so an estimate from x * (1/dd) is corrected by at most
+// a step or two instead of bisecting; the result is the bisection's.
+__device__ __forceinline__ int grid_index(double x, double dd, double inv_dd, int n)
+{
+    double e = floor(x * inv_dd);
+    if (!(e >= -1.0)) e = -1.0;            // also NaN
+    if (e > (double)(n - 1)) e = (double)(n - 1);
+    int i = (int)e;
+    while (i + 1 < n && (double)(i + 1) * dd <= x) i++;
+    while (i >= 0 && !((double)i * dd <= x)) i--;
+    return i;
+}
+
+// MPG:349-386 lerp over x_array[i] = i*dd, given idx = grid_index(x) and the two samples it selects
+// (y0 = ys[clamp(idx)], y1 = ys[clamp(idx + 1)]).
+__device__ __forceinline__ double lerp_at(double x, double dd, int idx, int n, double y0, double y1)
+{
+    if (idx < 0 || idx >= n - 1) return y0;   // below the grid: ys[0]; at or past its end: ys[n-1]
+    const double x0 = (double)idx * dd, x1 = (double)(idx + 1) * dd;
+    return y0 + (x - x0) * (y1 - y0) / (x1 - x0);
+}
+
+__device__ __forceinline__ int clamp_index(int i, int n) { return i < 0 ? 0 : (i > n - 1 ? n - 1 : i); }
+
+template <typename T>
+__device__ __forceinline__ double lerp_grid(double x, double dd, double inv_dd, const T *__restrict__ ys, int n)
+{
+    const int idx = grid_index(x, dd, inv_dd, n);
+    return lerp_at(x, dd, idx, n, (double)ys[clamp_index(idx, n)], (double)ys[clamp_index(idx + 1, n)]);
+}
+
+__device__ __forceinline__ double clip(double x, double lo, double hi)
+{
+    const double m = x < lo ? lo : x;
+    return m > hi ? hi : m;
+}
+
 }  // namespace vap

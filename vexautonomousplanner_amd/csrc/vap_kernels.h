@@ -45,6 +45,9 @@ hipError_t launch_velocity_windows(hipStream_t st, int B, int S, const double c[
                                    const double *meta, const void *curv, const void *dth, void *vel, uint32_t *flags,
                                    void *ufwd, void *state, int *counters);
 hipError_t launch_power(hipStream_t st, int n_seg, const double *seg, double *pw);
+hipError_t launch_time_profile(hipStream_t st, bool f64, int B, int W, int S, const double *segments, const double *lut,
+                               const double *meta, const void *vel, double max_acc, double max_dec, double dt, int cap,
+                               double *rows, int *counts, int *nodes_map, uint32_t *flags);
 hipError_t launch_eval(hipStream_t st, int W, const double *seg, double t_max, int order, int n, const double *t,
                        double *out);
 hipError_t launch_lookup(hipStream_t st, int W, const double *seg, double t_max, const double *lut, int what,

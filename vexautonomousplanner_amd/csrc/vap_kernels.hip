@@ -20,26 +20,6 @@ namespace vap {
 
 static_assert(kCoefBlockDoubles == kCoefDoubles, "scratch sizing and block layout disagree");
 
-// Cooperative copy of n doubles from HBM/L2 into LDS: up to ITER loads per thread are issued before
-// the first LDS write, so a workgroup pays the memory latency once instead of once per element.
-template <int ITER>
-__device__ __forceinline__ void lds_fill(double *__restrict__ dst, const double *__restrict__ src, int n, int tid, int nt)
-{
-    for (int base = 0; base < n; base += ITER * nt) {
-        double v[ITER];
-#pragma unroll
-        for (int it = 0; it < ITER; it++) {
-            const int i = base + tid + it * nt;
-            v[it] = i < n ? src[i] : 0.0;
-        }
-#pragma unroll
-        for (int it = 0; it < ITER; it++) {
-            const int i = base + tid + it * nt;
-            if (i < n) dst[i] = v[it];
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // K1: fit.  One workgroup per path.  QHS:30-138, 149-219, 719-736; SM:65-77 tangent overrides.
 // LDS (dynamic): pts[W][2], dist[G], fd[W][2], sd[W][2]  (fp64)

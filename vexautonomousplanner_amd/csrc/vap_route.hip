@@ -330,7 +330,6 @@ __global__ void k_route_grid(RouteDev r, int N, double dd, double *__restrict__ 
 }
 
 // Python float % 1 for non-negative values
-__device__ __forceinline__ double mod1(double v) { return fmod(v, 1.0); }
 
 // MPG:84-176 bookkeeping of the sampling loop (one lane): initial velocities, boundary_map / max_accels
 // expanded to per-sample constraint values for the two sweeps.
@@ -423,37 +422,6 @@ __global__ void k_route_velocity(int N, VelConsts<double> c, double dd, double s
 // MPG:389-628 time-domain resample, one lane.  rows[T][8] = {time, position, linear velocity,
 // acceleration, heading, angular velocity, x, y}.
 // ---------------------------------------------------------------------------------------------------
-__device__ double py_mod(double a, double b)   // Python float % for b > 0
-{
-    double m = fmod(a, b);
-    if (m != 0.0) { if (m < 0) m += b; }
-    else m = copysign(0.0, b);
-    return m;
-}
-
-// MPG:349-386 lerp over x_array[i] = i*dd
-__device__ double lerp_grid(double x, double dd, const double *__restrict__ ys, int n)
-{
-    // np.searchsorted(xs, x, side="right") - 1 over xs[i] = i*dd
-    int lo = 0, hi = n;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (!(x < (double)mid * dd)) lo = mid + 1;
-        else hi = mid;
-    }
-    const int idx = lo - 1;
-    if (idx < 0) return ys[0];
-    if (idx >= n - 1) return ys[n - 1];
-    const double x0 = (double)idx * dd, x1 = (double)(idx + 1) * dd;
-    return ys[idx] + (x - x0) * (ys[idx + 1] - ys[idx]) / (x1 - x0);
-}
-
-__device__ double clip(double x, double lo, double hi)
-{
-    const double m = x < lo ? lo : x;
-    return m > hi ? hi : m;
-}
-
 #define ROW(i) (rows + (size_t)(i) * 8)
 
 // MPG:487-507 handle_turn (with MPG:319-346 motion_profile_angle and ODM:4-69 inlined); returns rows added or -1
@@ -585,8 +553,8 @@ __global__ void k_route_time(RouteDev r, int N, const double *__restrict__ vel, 
         heading *= -1;
         double px, py;
         route_eval(r, n_spl, t, 0, px, py);
-        double target_vel = lerp_grid(current_pos, dd, vel, N);
-        const double next_target_vel = lerp_grid(current_pos + dd, dd, vel, N);
+        double target_vel = lerp_grid(current_pos, dd, 1.0 / dd, vel, N);
+        const double next_target_vel = lerp_grid(current_pos + dd, dd, 1.0 / dd, vel, N);
         target_vel = (target_vel + next_target_vel) / 2;
         if (!(target_vel > 0.001)) target_vel = 0.001;
         const double accel = clip((target_vel - current_vel) / dt, -max_dec, max_acc);

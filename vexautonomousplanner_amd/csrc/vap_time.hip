@@ -1,0 +1,169 @@
+// vap_time.hip — batched time-domain resample: the loop of generate_motion_profile that follows
+// forward_backward_pass (MPG:413-628), for B plain-node paths (no turn / wait / reverse nodes, no
+// action points — those insert rows and are served by the single-route kernel in vap_route.hip).
+//
+// The reference's loop is sequential in current_pos, but only its kinematic half is: the position
+// and velocity of a time step depend on the previous step and on the distance-domain velocity row
+// alone; time -> parameter -> curvature / heading / point is a pure function of that position.
+// So the work is split:
+//   k_time_integrate   one lane per path, the scalar recurrence (MPG:566-584): a few dozen fp64
+//                      operations and two lerps per step — writes time, position, velocity,
+//                      acceleration and (scratch) target velocity of every row;
+//   k_time_geometry    one workgroup per path, all rows in parallel: SM:291-318 distance_to_time,
+//                      SM:332-346 curvature / heading step lookup, SM:204-215 point, the heading
+//                      sign / wrap of MPG:559-563, angular velocity (MPG:575), and the ordered list
+//                      of node crossings (nodes_map, MPG:420, 527-529).
+// All arithmetic is fp64 in the reference's order; only the velocity row is read in the batch dtype.
+#include "vap_device.h"
+#include "vap_kernels.h"
+
+namespace vap {
+
+constexpr int kRowWidth = 8;   // time, position, velocity, acceleration, heading, angular velocity, x, y
+
+// One lane per path (the recurrence is scalar and sequential, so a lane is all a path can use; the
+// instruction stream of a step is shared by the 64 paths of a wavefront).  The two lerps of a step read
+// the path's velocity row where the position stands — a dependent access, but consecutive steps stay
+// within a few cache lines of each other, so it is served by L2.  Variants measured on config 3
+// (4096 paths, ~1280 steps each): this one 2.5 ms; one wavefront per path with an LDS window of the
+// row 4.7 ms (64 lanes repeat the same arithmetic: issue-bound); per-lane LDS windows refilled
+// wave-wide 6.9 ms (some lane's window runs out nearly every step).
+template <typename R>
+__global__ __launch_bounds__(64) void k_time_integrate(int B, int S, const double *__restrict__ meta,
+                                                       const R *__restrict__ vel, double max_acc, double max_dec,
+                                                       double dt, int cap, double *__restrict__ rows,
+                                                       int *__restrict__ counts, uint32_t *__restrict__ flags)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double *m = meta + (size_t)b * kMetaStride;
+    const double total = m[1], dd = m[2], inv_dd = 1.0 / dd;
+    const int N = (int)m[3];
+    const R *v = vel + (size_t)b * S;
+    double *out = rows + (size_t)b * cap * kRowWidth;
+    double current_time = 0, current_pos = 0, current_vel = N > 0 ? (double)v[0] : 0.0;   // MPG:413-418
+    int T = 0;
+    bool full = false;
+    // `total > 0` also keeps degenerate paths (NaN / zero length) out of the loop
+    while (total > 0 && N > 1 && current_pos < total) {   // MPG:523
+        if (T >= cap) { full = true; break; }
+        // MPG:566-570: mean of the profile at the current position and one grid step ahead.  The four
+        // samples are fetched together: one memory round trip per step instead of two.
+        const double ahead = current_pos + dd;
+        const int i0 = grid_index(current_pos, dd, inv_dd, N), i1 = grid_index(ahead, dd, inv_dd, N);
+        const double a0 = (double)v[clamp_index(i0, N)], a1 = (double)v[clamp_index(i0 + 1, N)];
+        const double c0 = (double)v[clamp_index(i1, N)], c1 = (double)v[clamp_index(i1 + 1, N)];
+        double target_vel = lerp_at(current_pos, dd, i0, N, a0, a1);
+        const double next_target_vel = lerp_at(ahead, dd, i1, N, c0, c1);
+        target_vel = (target_vel + next_target_vel) / 2;
+        if (!(target_vel > 0.001)) target_vel = 0.001;
+        const double accel = clip((target_vel - current_vel) / dt, -max_dec, max_acc);   // MPG:572-573
+        current_vel = clip(current_vel + accel * dt, 0, target_vel);                      // MPG:578
+        double delta_pos = current_vel * dt + 0.5 * accel * dt * dt;                      // MPG:580
+        if (current_vel <= 0.1) delta_pos = 0.1 * dt + 0.5 * accel * dt * dt;             // MPG:581-582
+        current_pos += delta_pos;
+        double *q = out + (size_t)T * kRowWidth;
+        q[0] = current_time;
+        q[1] = current_pos;
+        q[2] = current_vel;
+        q[3] = accel;
+        q[5] = target_vel;   // scratch: k_time_geometry turns it into the angular velocity
+        T += 1;
+        current_time += dt;
+    }
+    counts[2 * b] = T;
+    if (full && flags) atomicOr(&flags[b], VAP_FLAG_TRUNCATED_BIT);
+}
+
+// One workgroup per path.  LDS: the path's distance table (8 KB) and, when they fit, its segment rows.
+template <bool SEG_LDS>
+__global__ __launch_bounds__(256) void k_time_geometry(int W, int cap, const double *__restrict__ segments,
+                                                       const double *__restrict__ lut,
+                                                       const double *__restrict__ meta, double *__restrict__ rows,
+                                                       int *__restrict__ counts, int *__restrict__ nodes_map)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_seg[];   // G * 12 when SEG_LDS
+    __shared__ double sD[kLutN];
+    __shared__ int s_wave[4], s_base;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int G = W - 1;
+    const double *m = meta + (size_t)b * kMetaStride;
+    const double t_max = m[0], total = m[1];
+    const int T = counts[2 * b];
+    const double *seg = segments + (size_t)b * G * 12;
+    lds_fill<4>(sD, lut + (size_t)b * kLutN, kLutN, tid, 256);
+    if constexpr (SEG_LDS) lds_fill<4>(s_seg, seg, G * 12, tid, 256);
+    if (tid == 0) { s_base = 1; nodes_map[(size_t)b * W] = 0; }   // MPG:420: the first node maps to row 0
+    __syncthreads();
+    if constexpr (SEG_LDS) seg = s_seg;
+    const double end_param = (double)(W - 1);
+    const int tab_n = W * kSamplesPerNode;
+    double *out = rows + (size_t)b * cap * kRowWidth;
+    for (int r0 = 0; r0 < T; r0 += 256) {
+        const int i = r0 + tid;
+        bool crossing = false;
+        if (i < T) {
+            double *q = out + (size_t)i * kRowWidth;
+            // the row was produced from the position BEFORE its own update: the previous row's
+            const double pos = i == 0 ? 0.0 : q[1 - kRowWidth];
+            const double t = distance_to_time(sD, total, t_max, end_param, pos);              // MPG:525
+            double prev_t = 0.0;                                                              // MPG:521
+            if (i > 0) prev_t = distance_to_time(sD, total, t_max, end_param, i == 1 ? 0.0 : q[1 - 2 * kRowWidth]);
+            crossing = mod1(t) < mod1(prev_t) && t < end_param;                               // MPG:527
+            // SM:332-346, 550-580: step lookup into the (never materialised) property table
+            const int jj = table_index(t, tab_n, end_param);
+            const double tp = linspace_at(end_param, tab_n, jj);
+            double d1x, d1y, d2x, d2y, px, py;
+            hermite_eval_ref(seg, t_max, G, 1, tp, d1x, d1y);
+            hermite_eval_ref(seg, t_max, G, 2, tp, d2x, d2y);
+            const double ss = d1x * d1x + d1y * d1y;
+            const double num = d1x * d2y - d1y * d2x;
+            const double curvature = (ss >= 1e-10) ? num / (ss * sqrt(ss)) : 0.0;             // SM:517-527
+            double heading = atan2(d1y, d1x);                                                 // SM:536
+            heading = py_mod(heading + M_PI, 2 * M_PI) - M_PI;                                // MPG:559-563
+            heading *= -1;
+            hermite_eval_ref(seg, t_max, G, 0, t, px, py);                                    // MPG:565
+            q[4] = heading;
+            q[5] = q[5] * curvature * -1;                                                     // MPG:575
+            q[6] = px;
+            q[7] = py;
+        }
+        // ordered compaction of the crossings of these 256 rows into nodes_map (MPG:528-529)
+        const unsigned long long bal = __ballot(crossing);
+        if ((tid & 63) == 0) s_wave[tid >> 6] = __popcll(bal);
+        __syncthreads();
+        int before = s_base;
+        for (int w = 0; w < (tid >> 6); w++) before += s_wave[w];
+        if (crossing) {
+            const int k = before + __popcll(bal & ((1ull << (tid & 63)) - 1ull));
+            if (k < W) nodes_map[(size_t)b * W + k] = i;
+        }
+        __syncthreads();
+        if (tid == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+    }
+    if (tid == 0) counts[2 * b + 1] = s_base < W ? s_base : W;
+}
+
+hipError_t launch_time_profile(hipStream_t st, bool f64, int B, int W, int S, const double *segments, const double *lut,
+                               const double *meta, const void *vel, double max_acc, double max_dec, double dt, int cap,
+                               double *rows, int *counts, int *nodes_map, uint32_t *flags)
+{
+    const int nblk = (B + 63) / 64;
+    if (f64)
+        hipLaunchKernelGGL(k_time_integrate<double>, dim3(nblk), dim3(64), 0, st, B, S, meta, (const double *)vel, max_acc,
+                           max_dec, dt, cap, rows, counts, flags);
+    else
+        hipLaunchKernelGGL(k_time_integrate<float>, dim3(nblk), dim3(64), 0, st, B, S, meta, (const float *)vel, max_acc,
+                           max_dec, dt, cap, rows, counts, flags);
+    const size_t seg_bytes = sizeof(double) * 12 * (size_t)(W - 1);
+    if (seg_bytes <= 40 * 1024)
+        hipLaunchKernelGGL(k_time_geometry<true>, dim3(B), dim3(256), seg_bytes, st, W, cap, segments, lut, meta, rows, counts,
+                           nodes_map);
+    else
+        hipLaunchKernelGGL(k_time_geometry<false>, dim3(B), dim3(256), 0, st, W, cap, segments, lut, meta, rows, counts,
+                           nodes_map);
+    return hipGetLastError();
+}
+
+}  // namespace vap
