@@ -396,7 +396,8 @@ __device__ __forceinline__ R backward_step(const VelConsts<R> &c, const SampleLi
 //   max_accel_kin = max_acc*r                                    and  max_accel_ang = 2amax/(tw*k) > amax*r
 // with r = 1/(1 + tw*k/2), so   cap = (vmax*r)^2,  A = amax*r   (straight samples: A = amax exactly,
 // MPG:204-206).  All accelerations are pre-multiplied by 2*dd ("p" suffix) so a step is
-//   u' = min(u_init', cap, u + clamp(amaxp - |dw|*g, 0, Ap)).
+//   u' = min(u_init', cap, u + clamp(amaxp - |dw|*g, 0, Ap))
+// (the offset form u + clamp(..) is also the reference's own order: v^2 + 2*a*dd with a clamped).
 // Heading-difference zero (two samples on one table entry) makes the reference produce +-inf / NaN
 // (SURVEY §8(a) "Edge semantics"); g is clamped to kHuge so the same decisions fall out without
 // NaNs: forward  dw==0 -> A, dw!=0 -> 0;  backward  dw>0 -> 0, dw<=0 -> A.
@@ -435,11 +436,23 @@ __device__ __forceinline__ double vmax_(double a, double b) { return fmax(a, b);
 __device__ __forceinline__ float clamp0(float x, float hi) { return __builtin_amdgcn_fmed3f(x, 0.0f, hi); }
 __device__ __forceinline__ double clamp0(double x, double hi) { return fmin(fmax(x, 0.0), hi); }
 
-// Per-sample step coefficients from (|curvature|, |dtheta|):
-//   q = k^2,  g = 2dd*tw/(4*dtheta) (0 on straight samples, clamped to kHuge),
-//   A = base_p * r,  cap = (vmax*r)^2  with r = 1/(1 + tw*k/2)  (straight samples: A = base_p).
+// Hides a value from code motion (loop-invariant hoisting, sinking into branches).
+__device__ __forceinline__ float opaque(float x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ double opaque(double x) { asm volatile("" : "+v"(x)); return x; }
+
+// Per-sample step coefficients.  With w_i = u_i*q_i (q = k^2, the squared angular velocity) the
+// reference's dw = w_i - w_{i-1} is formed as  q_i*(u_i - rho_i*u_{i-1}),  rho_i = q_{i-1}/q_i, so the
+// recurrence carries the last two squared velocities and a step is five dependent operations:
+//   t = u - rho*u_prev;  y = amaxp - |t|*gq;  u' = min(u + clamp(y, 0, A), cap [, u_init'])
+// with   gq  = g*q,  g = 2dd*tw/(4*dtheta)   (0 on straight samples, k < 1e-6, MPG:204-206)
+//        A   = base_p*r,  cap = (vmax*r)^2,  r = 1/(1 + tw*k/2)   (straight samples: A = base_p)
+//        rho = 0 on straight samples and on the first step of a sweep (MPG:190, 253: previous
+//              angular velocity 0).
+// A sample whose heading difference is zero has g clamped to kHuge; it is stored as gq = kHuge exactly
+// (ordinary samples are kept below kHuge/10), which the backward step reads as "sign-aware".
 template <typename R>
-__device__ __forceinline__ void fast_derive(const FastConsts<R> &c, R kabs, R dth, R base_p, R &q, R &g, R &A, R &cap)
+__device__ __forceinline__ void fast_derive_k(const FastConsts<R> &c, R kabs, R kprev_abs, R base_p, R &rho, R &q,
+                                              R &A, R &cap)
 {
     q = kabs * kabs;
     const bool straight = kabs < (R)1e-6;
@@ -447,60 +460,79 @@ __device__ __forceinline__ void fast_derive(const FastConsts<R> &c, R kabs, R dt
     const R vr = c.vmax * r;
     cap = vr * vr;
     A = straight ? base_p : base_p * r;
-    const R gg = vmin(c.gk * fast_rcp(dth), Huge<R>::v);
-    g = straight ? (R)0 : gg;
+    // rho must be exactly 1 when both samples read the same table entry: then t = u - u_prev is an exact
+    // zero for an unchanged velocity, the reference's 0/0 case (MPG:209 with dtheta == 0).
+    // Straight-line selects (opaque keeps the reciprocal out of a branch): this runs 80 times per thread.
+    const R qp = kprev_abs * kprev_abs;
+    R x = opaque(qp * fast_rcp(q));
+    x = qp == q ? (R)1 : x;
+    rho = straight ? (R)0 : x;
+}
+
+template <typename R>
+__device__ __forceinline__ R fast_gg(const FastConsts<R> &c, R dth) { return vmin(c.gk * fast_rcp(dth), Huge<R>::v); }
+
+// q = k^2 of the same step (straight <=> q < 1e-12).  Branch-free: selects only.
+template <typename R>
+__device__ __forceinline__ R fast_gq(R gg, R q)
+{
+    R r = vmin(gg * q, Huge<R>::v * (R)0.1);
+    r = gg >= Huge<R>::v ? Huge<R>::v : r;
+    return q < (R)1e-12 ? (R)0 : r;
+}
+
+template <typename R>
+__device__ __forceinline__ void fast_derive(const FastConsts<R> &c, R kabs, R kprev_abs, R dth, R base_p, R &rho, R &gq,
+                                            R &A, R &cap)
+{
+    R q;
+    fast_derive_k(c, kabs, kprev_abs, base_p, rho, q, A, cap);
+    gq = fast_gq(fast_gg(c, dth), q);
 }
 
 // Coefficients of a slot that holds no step (past the end of the path, or the fixed end sample in
-// the backward sweep): q = 0 zeroes the angular-velocity memory and the huge limits let the step
-// return min(u + amaxp, u_init) = u_init with wprev = 0 — i.e. walking through it restarts the chain.
+// the backward sweep): the huge limits let the step return min(u + amaxp, u_init) = u_init, and the
+// first real step after it has rho = 0 — i.e. walking through it restarts the chain.
 template <typename R>
-__device__ __forceinline__ void idle_coef(R &q, R &g, R &A, R &cap)
+__device__ __forceinline__ void idle_coef(R &rho, R &gq, R &A, R &cap)
 {
-    q = (R)0;
-    g = (R)0;
+    rho = (R)0;
+    gq = (R)0;
     A = Huge<R>::v;
     cap = Huge<R>::v;
 }
 
-// Hides a value from loop-invariant code motion.
-__device__ __forceinline__ float opaque(float x) { asm volatile("" : "+v"(x)); return x; }
-__device__ __forceinline__ double opaque(double x) { asm volatile("" : "+v"(x)); return x; }
-
 __device__ __forceinline__ float med3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
 __device__ __forceinline__ double med3(double a, double lo, double hi) { return fmin(fmax(a, lo), hi); }
 
-// Forward step, MPG:193-249:  u' = min(cap, u_init, clamp(u + amaxp - |d|*g, u, u + A)),
-// d = u*q - wprev.  DUP = the path has samples sharing a table entry (g == kHuge): d must then be
-// formed from the rounded product so that "angular velocity unchanged" is an exact zero (the
-// reference's 0/0 -> NaN -> skipped case); otherwise one fma takes an operation off the chain.
-template <bool DUP, typename R>
-__device__ __forceinline__ R fast_forward(const FastConsts<R> &c, R q, R g, R A, R cap, R u, R &wprev, R u_next)
+// Forward step, MPG:193-249.  A zero heading difference (gq = kHuge) gives the reference's
+// dw == 0 -> A, dw != 0 -> 0 without a special case: t is exactly zero when the table entry and the
+// velocity are unchanged (rho = 1), and any other t times kHuge exceeds amaxp.
+template <typename R>
+__device__ __forceinline__ R fast_forward(const FastConsts<R> &c, R rho, R gq, R A, R cap, R u, R &uprev, R u_next)
 {
-    const R w = u * q;
-    const R d = DUP ? w - wprev : fma(u, q, -wprev);
-    const R x = fma(-fabs(d), g, u + c.amaxp);
-    wprev = w;
-    return vmin(vmin(med3(x, u, u + A), cap), u_next);
+    const R t = fma(-rho, uprev, u);
+    const R y = fma(-fabs(t), gq, c.amaxp);
+    uprev = u;
+    return vmin(vmin(u + med3(y, (R)0, A), cap), u_next);
 }
 
-// Backward step, MPG:255-311.  DUP = the path has samples sharing a table entry (g == kHuge): the
-// reference's signed +-inf handling then differs from the forward one (dw > 0 -> 0, dw <= 0 -> A).
+// Backward step, MPG:255-311.  DUP = the path has samples with a zero heading difference: the
+// reference's signed +-inf handling there differs from the forward one (dw > 0 -> 0, dw <= 0 -> A).
 template <bool DUP, typename R>
-__device__ __forceinline__ R fast_backward(const FastConsts<R> &c, R q, R g, R A, R cap, R u, R &wprev, R u_prev)
+__device__ __forceinline__ R fast_backward(const FastConsts<R> &c, R rho, R gq, R A, R cap, R u, R &uprev, R u_prev)
 {
-    const R w = u * q;
-    const R d = DUP ? w - wprev : fma(u, q, -wprev);
-    R x;
+    const R t = fma(-rho, uprev, u);
+    R y;
     if constexpr (DUP) {
-        g = opaque(g);   // keep the select below inside the round loop (one register per sample otherwise)
-        const R gn = g >= Huge<R>::v ? (R)0 : g;
-        x = (u + c.amaxp) - vmax_(d * g, -d * gn);
+        gq = opaque(gq);   // keep the select below inside the round loop (one register per sample otherwise)
+        const R gn = gq >= Huge<R>::v ? (R)0 : gq;
+        y = c.amaxp - vmax_(t * gq, -t * gn);
     } else {
-        x = fma(-fabs(d), g, u + c.amaxp);
+        y = fma(-fabs(t), gq, c.amaxp);
     }
-    wprev = w;
-    return vmin(vmin(med3(x, u, u + A), cap), u_prev);
+    uprev = u;
+    return vmin(vmin(u + med3(y, (R)0, A), cap), u_prev);
 }
 
 // Cooperative copy of n doubles from HBM/L2 into LDS: up to ITER loads per thread are issued before

@@ -515,25 +515,23 @@ __global__ __launch_bounds__(64) void k_velocity_seq(int B, int S, VelConsts<R> 
     R *V = vel + row;
     const R vmax2 = c.vmax * c.vmax;
     const FastConsts<R> fc = make_fast(c, twodd);
-    // same per-path decision as the relaxation kernel: does any step have a clamped (huge) g?
+    // same per-path decision as the relaxation kernel: does any step have a zero heading difference?
     bool dup = false;
     if constexpr (FAST) {
         for (int i = 0; i < N - 1; i++) {
-            R q, g, A, cap;
-            fast_derive(fc, (R)fabs(K[i]), DT[i], fc.amaxp, q, g, A, cap);
-            dup |= g >= Huge<R>::v;
+            const R kabs = (R)fabs(K[i]);
+            dup |= fast_gq(fast_gg(fc, DT[i]), kabs * kabs) >= Huge<R>::v;
         }
     }
     // forward, MPG:188-249
-    R u = start_u, wprev = (R)0;
+    R u = start_u, wprev = (R)0;   // FAST: wprev carries the previous squared velocity instead
     V[0] = u;
     for (int i = 0; i < N - 1; i++) {
         const R un = (i + 1 == N - 1) ? end_u : (vcap ? vcap[row + i + 1] * vcap[row + i + 1] : vmax2);
         if constexpr (FAST) {
-            R q, g, A, cap;
-            fast_derive(fc, (R)fabs(K[i]), DT[i], fc.amaxp, q, g, A, cap);
-            u = dup ? fast_forward<true>(fc, q, g, A, cap, u, wprev, un)
-                    : fast_forward<false>(fc, q, g, A, cap, u, wprev, un);
+            R rho, gq, A, cap;
+            fast_derive(fc, (R)fabs(K[i]), i > 0 ? (R)fabs(K[i - 1]) : (R)0, DT[i], fc.amaxp, rho, gq, A, cap);
+            u = fast_forward(fc, rho, gq, A, cap, u, wprev, un);
         } else {
             const SampleLimits<R> L = sample_limits(c, (R)fabs(K[i]), c.amax, c.adec);
             u = forward_step(c, L, c.amax, twodd, u, wprev, DT[i], un);
@@ -546,10 +544,10 @@ __global__ __launch_bounds__(64) void k_velocity_seq(int B, int S, VelConsts<R> 
     for (int i = N - 1; i > 0; i--) {
         R up;
         if constexpr (FAST) {
-            R q, g, A, cap;
-            fast_derive(fc, (R)fabs(K[i]), DT[i - 1], fc.adecp, q, g, A, cap);
-            up = dup ? fast_backward<true>(fc, q, g, A, cap, u, wprev, V[i - 1])
-                     : fast_backward<false>(fc, q, g, A, cap, u, wprev, V[i - 1]);
+            R rho, gq, A, cap;
+            fast_derive(fc, (R)fabs(K[i]), i + 1 <= N - 1 ? (R)fabs(K[i + 1]) : (R)0, DT[i - 1], fc.adecp, rho, gq, A, cap);
+            up = dup ? fast_backward<true>(fc, rho, gq, A, cap, u, wprev, V[i - 1])
+                     : fast_backward<false>(fc, rho, gq, A, cap, u, wprev, V[i - 1]);
         } else {
             const SampleLimits<R> L = sample_limits(c, (R)fabs(K[i]), c.amax, c.adec);
             up = backward_step(c, L, c.amax, twodd, u, wprev, DT[i - 1], V[i - 1]);
@@ -631,6 +629,12 @@ __device__ __forceinline__ void stage_load(R *__restrict__ stage, const R *__res
     }
 }
 
+// Boundary state of the recurrence between two chunks: the last two squared velocities.
+template <typename R>
+struct alignas(2 * sizeof(R)) BoundaryState {
+    R u, w;
+};
+
 template <typename R, int L, int MAXT, int MINW>
 __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<R> c, R start_u, R end_u,
                                                                const double *__restrict__ meta,
@@ -642,7 +646,7 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     R *stage = reinterpret_cast<R *>(smem_raw);   // (T*L + T + 2) elements
     // boundary states, double-buffered by round parity so one barrier per round suffices
-    __shared__ R s_u[2][MAXT + 2], s_w[2][MAXT + 2];
+    __shared__ BoundaryState<R> s_bs[2][MAXT + 2];
     __shared__ int s_any[3];   // "some chunk's incoming state changed" per round, rotating slots
     __shared__ int s_dup;
     const long long t_start = stats ? __builtin_amdgcn_s_memtime() : 0;
@@ -660,34 +664,61 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
     if (tid == 0) { s_any[0] = 0; s_any[1] = 0; s_any[2] = 0; s_dup = 0; }
 
     // ---------------- forward sweep: the step (j-1 -> j) into owned sample j uses k[j-1], dth[j-1]
+    // (and k[j-2] for rho).  q[] holds rho, g[] holds g*k^2 (vap_device.h) once both rows are consumed.
+    // Stage positions of this thread's window: sample lo + k sits at cbase + k for 0 <= k < L, one word
+    // further for the next chunk's samples and one word nearer for the previous chunk's.
+    const int cbase = tid * (L + 1);
+    auto cpos = [&](int k) { return k < 0 ? cbase + k - 1 : (k < L ? cbase + k : cbase + k + 1); };
     stage_load<R, L>(stage, K, N < TL ? N : TL, TL, aligned, tid, T);
     __syncthreads();
+    // Samples are handled BK at a time: BK unconditional LDS reads in one batch (one wait), then
+    // straight-line arithmetic, one sample after the other (the opaque() keeps the scheduler from
+    // interleaving all L of them, which costs registers the rounds need).
+    constexpr int BK = (L % 8 == 0) ? 8 : ((L % 5 == 0) ? 5 : 4);
+    {
+        // k[lo-2], k[lo-1] first (tid 0 has no previous chunk: clamped to word 0 and masked)
+        R kp = (R)fabs(stage[(lo >= 2) ? cpos(-2) : 0]);
+        R kc = (R)fabs(stage[(lo >= 1) ? cpos(-1) : 0]);
 #pragma unroll
-    for (int s = 0; s < L; s++) {
-        const int j = lo + s;
-        const bool valid = j >= 1 && j <= N - 1;
-        const R kabs = (R)fabs(stage[stage_pos<R, L>(valid ? j - 1 : 0)]);
-        R gdummy;
-        fast_derive(fc, kabs, (R)1, fc.amaxp, q[s], gdummy, A[s], cp[s]);
-        if (!valid) idle_coef(q[s], gdummy, A[s], cp[s]);
-        u[s] = start_u;
+        for (int s0 = 0; s0 < L; s0 += BK) {
+            R kn[BK];
+#pragma unroll
+            for (int i = 0; i < BK; i++) kn[i] = (R)fabs(stage[cpos(s0 + i)]);
+#pragma unroll
+            for (int i = 0; i < BK; i++) {
+                const int s = s0 + i, j = lo + s;
+                const bool valid = j >= 1 && j <= N - 1;
+                fast_derive_k(fc, kc, (j >= 2) ? kp : (R)0, fc.amaxp, q[s], g[s], A[s], cp[s]);   // g[s] = k^2 for now
+                if (!valid) idle_coef(q[s], g[s], A[s], cp[s]);
+                q[s] = opaque(q[s]);
+                kp = kc;
+                kc = kn[i];
+            }
+        }
     }
     __syncthreads();
     stage_load<R, L>(stage, DT, N < TL ? N : TL, TL, aligned, tid, T);
     __syncthreads();
     bool dup = false;
 #pragma unroll
-    for (int s = 0; s < L; s++) {
-        const int j = lo + s;
-        const bool valid = j >= 1 && j <= N - 1;
-        const R dth = stage[stage_pos<R, L>(valid ? j - 1 : 0)];
-        const R gg = vmin(fc.gk * fast_rcp(dth), Huge<R>::v);
-        g[s] = (valid && q[s] >= (R)1e-12) ? gg : (R)0;   // q = k^2: straight <=> k < 1e-6
-        dup |= g[s] >= Huge<R>::v;
+    for (int s0 = 0; s0 < L; s0 += BK) {
+        R dn[BK];
+#pragma unroll
+        for (int i = 0; i < BK; i++) dn[i] = stage[(lo + s0 + i >= 1) ? cpos(s0 + i - 1) : 0];
+#pragma unroll
+        for (int i = 0; i < BK; i++) {
+            const int s = s0 + i, j = lo + s;
+            const bool valid = j >= 1 && j <= N - 1;
+            const R gq = fast_gq(fast_gg(fc, dn[i]), g[s]);
+            g[s] = opaque(valid ? gq : (R)0);
+            dup |= g[s] >= Huge<R>::v;
+            u[s] = start_u;
+        }
     }
+    // boundary state = the last two squared velocities (u, u_prev)
     R in_u, in_w;
     if (tid == 0) { in_u = start_u; in_w = (R)0; }
-    else { in_u = cp[0]; in_w = in_u * q[0]; }
+    else { in_u = cp[0]; in_w = in_u; }
     const bool fwd_active = lo <= N - 1;       // the chunk holds at least one real sample
     bool need = fwd_active;
     R out_u = in_u, out_w = in_w;
@@ -697,43 +728,38 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
     const bool any_dup = s_dup != 0;
     const long long t_fwd0 = stats ? __builtin_amdgcn_s_memtime() : 0;
     // Round r: evaluate if the incoming state changed; publish (always) into buffer r&1; barrier;
-    // pick up the neighbour's state; raise s_any[r%3] if it differs.  s_any[r%3] is read after the
-    // NEXT barrier (round r+1), so termination lags one cheap round and needs no second barrier.
+    // pick up the neighbour's state together with the "someone changed" flag of round r-1 (one LDS
+    // round trip); raise this round's flag if the state differs.  The flags rotate over three slots
+    // (this round's, the next one's being cleared, the previous one's being read), so termination lags
+    // one cheap round and needs no second barrier.
+    int f_cur = 0, f_nxt = 1, f_prv = 2;
     while (true) {
         if (need) {
             R uu = in_u, wp = in_w;
-            if (any_dup) {
 #pragma unroll
-                for (int s = 0; s < L; s++) {
-                    if (s == 0 && tid == 0) continue;   // sample 0 is the given start velocity (MPG:189)
-                    uu = fast_forward<true>(fc, q[s], g[s], A[s], cp[s], uu, wp, Huge<R>::v);
-                    u[s] = uu;
-                }
-            } else {
-#pragma unroll
-                for (int s = 0; s < L; s++) {
-                    if (s == 0 && tid == 0) continue;
-                    uu = fast_forward<false>(fc, q[s], g[s], A[s], cp[s], uu, wp, Huge<R>::v);
-                    u[s] = uu;
-                }
+            for (int s = 0; s < L; s++) {
+                if (s == 0 && tid == 0) continue;   // sample 0 is the given start velocity (MPG:189)
+                uu = fast_forward(fc, q[s], g[s], A[s], cp[s], uu, wp, Huge<R>::v);
+                u[s] = uu;
             }
             out_u = uu;
             out_w = wp;
         }
         const int pb = rounds & 1;
-        s_u[pb][tid + 1] = out_u;
-        s_w[pb][tid + 1] = out_w;
-        if (tid == 0) s_any[(rounds + 1) % 3] = 0;
+        s_bs[pb][tid + 1] = BoundaryState<R>{out_u, out_w};
+        if (tid == 0) s_any[f_nxt] = 0;
         __syncthreads();
-        if (rounds > 0 && s_any[(rounds - 1) % 3] == 0) break;   // nobody changed last round
+        const int changed_last = s_any[f_prv];
+        const BoundaryState<R> nb = s_bs[pb][tid];
+        if (rounds > 0 && changed_last == 0) break;   // nobody changed last round
         need = false;
         if (tid > 0 && fwd_active) {
-            const R nu = s_u[pb][tid], nw = s_w[pb][tid];
-            need = !(same_bits(nu, in_u) && same_bits(nw, in_w));
-            in_u = nu;
-            in_w = nw;
+            need = !(same_bits(nb.u, in_u) && same_bits(nb.w, in_w));
+            in_u = nb.u;
+            in_w = nb.w;
         }
-        if (need) s_any[rounds % 3] = 1;
+        if (need) s_any[f_cur] = 1;
+        { const int t = f_prv; f_prv = f_cur; f_cur = f_nxt; f_nxt = t; }
         rounds++;
         if (rounds > 2 * T + 8) {
             if (tid == 0 && flags) atomicOr(&flags[b], VAP_FLAG_NOCONVERGE_BIT);
@@ -744,31 +770,37 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
     const long long t_fwd1 = stats ? __builtin_amdgcn_s_memtime() : 0;
 
     // ---------------- backward sweep: the step (j+1 -> j) into owned sample j uses k[j+1], dth[j]
-    // Slots at or past the fixed end sample N-1 are idle slots holding u = end_u: walking through
-    // them restarts the chain exactly as MPG:252-253 does.  (The stage still holds dtheta.)
+    // (and k[j+2] for rho).  Slots at or past the fixed end sample N-1 are idle slots holding
+    // u = end_u: walking through them restarts the chain exactly as MPG:252-253 does.
+    // (The stage still holds dtheta.)
 #pragma unroll
-    for (int s = 0; s < L; s++) {
-        const int j = lo + s;
-        const bool valid = j <= N - 2;
-        const R dth = stage[stage_pos<R, L>(valid ? j : 0)];
-        g[s] = vmin(fc.gk * fast_rcp(dth), Huge<R>::v);
-    }
+    for (int s = 0; s < L; s++) g[s] = stage[cpos(s)];   // dtheta[j] for now
     __syncthreads();
-    stage_load<R, L>(stage, K, N < TL + 1 ? N : TL + 1, TL + 1, aligned, tid, T);
+    stage_load<R, L>(stage, K, N < TL + 2 ? N : TL + 2, TL + 2, aligned, tid, T);
     __syncthreads();
+    {
+        R kc = (R)fabs(stage[cpos(1)]);
 #pragma unroll
-    for (int s = 0; s < L; s++) {
-        const int j = lo + s;
-        const bool valid = j <= N - 2;
-        const R kabs = (R)fabs(stage[stage_pos<R, L>(valid ? j + 1 : 0)]);
-        R gdummy;
-        fast_derive(fc, kabs, (R)1, fc.adecp, q[s], gdummy, A[s], cp[s]);
-        if (q[s] < (R)1e-12) g[s] = (R)0;
-        if (!valid) { idle_coef(q[s], g[s], A[s], cp[s]); u[s] = end_u; }
+        for (int s0 = 0; s0 < L; s0 += BK) {
+            R kn[BK];
+#pragma unroll
+            for (int i = 0; i < BK; i++) kn[i] = (R)fabs(stage[cpos(s0 + i + 2)]);
+#pragma unroll
+            for (int i = 0; i < BK; i++) {
+                const int s = s0 + i, j = lo + s;
+                const bool valid = j <= N - 2;
+                R qq;
+                fast_derive_k(fc, kc, (j + 2 <= N - 1) ? kn[i] : (R)0, fc.adecp, q[s], qq, A[s], cp[s]);
+                g[s] = fast_gq(fast_gg(fc, g[s]), qq);
+                if (!valid) { idle_coef(q[s], g[s], A[s], cp[s]); u[s] = end_u; }
+                q[s] = opaque(q[s]);
+                kc = kn[i];
+            }
+        }
     }
     const int last_chunk = (N - 1) / L;     // chunk that owns the fixed end sample
     if (tid >= last_chunk) { in_u = end_u; in_w = (R)0; }
-    else { in_u = u[L - 1]; in_w = in_u * q[L - 1]; }
+    else { in_u = u[L - 1]; in_w = in_u; }
     // The backward step reads the forward value of the sample it overwrites, so a chunk cannot be
     // re-run in place: the rounds only propagate boundary states (u[] stays the forward result) and
     // one commit evaluation with the final incoming state stores the backward velocities.
@@ -779,6 +811,7 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
     rounds = 0;
     if (tid == 0) { s_any[0] = 0; s_any[1] = 0; s_any[2] = 0; }
     __syncthreads();
+    f_cur = 0; f_nxt = 1; f_prv = 2;
     while (true) {
         if (need) {
             R uu = in_u, wp = in_w;
@@ -793,19 +826,20 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
             out_w = wp;
         }
         const int pb = rounds & 1;
-        s_u[pb][tid] = out_u;
-        s_w[pb][tid] = out_w;
-        if (tid == 0) s_any[(rounds + 1) % 3] = 0;
+        s_bs[pb][tid] = BoundaryState<R>{out_u, out_w};
+        if (tid == 0) s_any[f_nxt] = 0;
         __syncthreads();
-        if (rounds > 0 && s_any[(rounds - 1) % 3] == 0) break;
+        const int changed_last = s_any[f_prv];
+        const BoundaryState<R> nb = s_bs[pb][tid + 1];
+        if (rounds > 0 && changed_last == 0) break;
         need = false;
         if (tid < last_chunk) {
-            const R nu = s_u[pb][tid + 1], nw = s_w[pb][tid + 1];
-            need = !(same_bits(nu, in_u) && same_bits(nw, in_w));
-            in_u = nu;
-            in_w = nw;
+            need = !(same_bits(nb.u, in_u) && same_bits(nb.w, in_w));
+            in_u = nb.u;
+            in_w = nb.w;
         }
-        if (need) s_any[rounds % 3] = 1;
+        if (need) s_any[f_cur] = 1;
+        { const int t = f_prv; f_prv = f_cur; f_cur = f_nxt; f_nxt = t; }
         rounds++;
         if (rounds > 2 * T + 8) {
             if (tid == 0 && flags) atomicOr(&flags[b], VAP_FLAG_NOCONVERGE_BIT);
@@ -873,19 +907,18 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
 //   used  [B][nsc][2]       incoming state of the last evaluation      (NaN pattern = never)
 //   outst [B][nsc][2]       outgoing state of the last evaluation
 // ------------------------------------------------------------------------------------------------
-__global__ void k_dup_scan(int B, int S, const double *__restrict__ meta, const float *__restrict__ curv_f,
-                           const double *__restrict__ curv_d, const float *__restrict__ dth_f,
-                           const double *__restrict__ dth_d, int *__restrict__ dup)
+template <typename R>
+__global__ void k_dup_scan(int B, int S, VelConsts<R> c, const double *__restrict__ meta, const R *__restrict__ curv,
+                           const R *__restrict__ dth, int *__restrict__ dup)
 {
     const int b = blockIdx.y;
     const int N = (int)meta[(size_t)b * kMetaStride + 3];
-    const double twodd = 2.0 * meta[(size_t)b * kMetaStride + 2];
+    const FastConsts<R> fc = make_fast(c, (R)2 * (R)meta[(size_t)b * kMetaStride + 2]);
     bool any = false;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N - 1; i += gridDim.x * blockDim.x) {
         const size_t o = (size_t)b * S + i;
-        // same predicate as the kernels: g = gk/dtheta clamped at kHuge, on a non-straight sample
-        if (curv_f) any |= fabsf(curv_f[o]) >= 1e-6f && !(dth_f[o] > 0.0f && (float)(twodd) * 0.25f / dth_f[o] < 1e29f);
-        else any |= fabs(curv_d[o]) >= 1e-6 && !(dth_d[o] > 0.0 && twodd * 0.25 / dth_d[o] < 1e299);
+        const R kabs = (R)fabs(curv[o]);
+        any |= fast_gq(fast_gg(fc, dth[o]), kabs * kabs) >= Huge<R>::v;   // the kernels' own predicate
     }
     if (__syncthreads_or(any ? 1 : 0) && threadIdx.x == 0) atomicOr(&dup[b], 1);
 }
@@ -941,12 +974,13 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_long(int S, int nsc, in
         }
     }
     if (tid == 0) { s_any[0] = 0; s_any[1] = 0; s_any[2] = 0; }
-    R q[L], g[L], A[L], cp[L], u[L];
+    R q[L], g[L], A[L], cp[L], u[L];   // q[] = rho, g[] = g*k^2 (vap_device.h)
     const R base_p = BWD ? fc.adecp : fc.amaxp;
-    // element e of the stage = global sample g0 + e
-    const int g0 = BWD ? base : (base > 0 ? base - 1 : 0);
-    const int n_k = (BWD ? SC + 1 : SC + (base > 0 ? 0 : 0));
-    const bool aligned = (S % (16 / (int)sizeof(R))) == 0 && (g0 % (16 / (int)sizeof(R))) == 0;
+    // element e of the stage = global sample g0 + e; a forward super-chunk needs k[base-2 ..]
+    constexpr int VW = 16 / (int)sizeof(R);
+    const int g0 = BWD ? base : (base > 0 ? base - VW : 0);
+    const int n_k = BWD ? SC + 2 : SC + VW;
+    const bool aligned = (S % VW) == 0;
     {
         int n = N - g0;
         n = n < 0 ? 0 : (n > n_k ? n_k : n);
@@ -958,17 +992,19 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_long(int S, int nsc, in
         const int j = base + lo + s;                                  // global owned sample
         const bool valid = BWD ? (j <= N - 2) : (j >= 1 && j <= N - 1);
         const int src = BWD ? j + 1 : j - 1;                          // curvature sample of the step
+        const int prv = BWD ? j + 2 : j - 2;                          // ... and of the step before it
+        const bool has_prv = valid && prv >= 0 && prv <= N - 1;
         const R kabs = (R)fabs(stage[stage_pos<R, L>(valid ? src - g0 : 0)]);
-        R gdummy;
-        fast_derive(fc, kabs, (R)1, base_p, q[s], gdummy, A[s], cp[s]);
-        if (!valid) idle_coef(q[s], gdummy, A[s], cp[s]);
+        const R kpv = (R)fabs(stage[stage_pos<R, L>(has_prv ? prv - g0 : 0)]);
+        fast_derive_k(fc, kabs, has_prv ? kpv : (R)0, base_p, q[s], g[s], A[s], cp[s]);   // g[s] = k^2 for now
+        if (!valid) idle_coef(q[s], g[s], A[s], cp[s]);
         u[s] = BWD ? end_u : start_u;
     }
     __syncthreads();
     {
         int n = N - g0;
-        n = n < 0 ? 0 : (n > SC ? SC : n);
-        stage_load<R, L>(stage, DT + g0, n, SC, aligned, tid, T);
+        n = n < 0 ? 0 : (n > n_k ? n_k : n);
+        stage_load<R, L>(stage, DT + g0, n, n_k, aligned, tid, T);
     }
     __syncthreads();
 #pragma unroll
@@ -977,8 +1013,8 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_long(int S, int nsc, in
         const bool valid = BWD ? (j <= N - 2) : (j >= 1 && j <= N - 1);
         const int src = BWD ? j : j - 1;                              // dtheta sample of the step
         const R dth = stage[stage_pos<R, L>(valid ? src - g0 : 0)];
-        const R gg = vmin(fc.gk * fast_rcp(dth), Huge<R>::v);
-        g[s] = (valid && q[s] >= (R)1e-12) ? gg : (R)0;
+        const R gq = fast_gq(fast_gg(fc, dth), g[s]);
+        g[s] = valid ? gq : (R)0;
     }
     if constexpr (BWD) {
         // forward velocities of the owned samples (idle slots hold end_u)
@@ -999,16 +1035,16 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_long(int S, int nsc, in
     const bool bwd_has_end = BWD && sc == last_sc;
     if constexpr (!BWD) {
         if (tid == 0) {
-            if (!exact_in && round == 0 && !seq) { in0_u = cp[0]; in0_w = in0_u * q[0]; }
+            if (!exact_in && round == 0 && !seq) { in0_u = cp[0]; in0_w = in0_u; }
             in_u = in0_u; in_w = in0_w;
-        } else { in_u = cp[0]; in_w = in_u * q[0]; }
+        } else { in_u = cp[0]; in_w = in_u; }
     } else {
         const bool tail = bwd_has_end ? tid >= local_last : false;
         if (tail) { in_u = end_u; in_w = (R)0; }
         else if (tid == T - 1) {
-            if (round == 0 && !seq) { in0_u = u[L - 1]; in0_w = in0_u * q[L - 1]; }
+            if (round == 0 && !seq) { in0_u = u[L - 1]; in0_w = in0_u; }
             in_u = in0_u; in_w = in0_w;
-        } else { in_u = u[L - 1]; in_w = in_u * q[L - 1]; }
+        } else { in_u = u[L - 1]; in_w = in_u; }
     }
     const bool active = BWD ? (!bwd_has_end || tid <= local_last) : (base + lo <= N - 1);
     bool need = active;
@@ -1022,8 +1058,7 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_long(int S, int nsc, in
 #pragma unroll
                 for (int s = 0; s < L; s++) {
                     if (s == 0 && tid == 0 && base == 0) continue;   // sample 0 is the given start velocity
-                    uu = any_dup ? fast_forward<true>(fc, q[s], g[s], A[s], cp[s], uu, wp, Huge<R>::v)
-                                 : fast_forward<false>(fc, q[s], g[s], A[s], cp[s], uu, wp, Huge<R>::v);
+                    uu = fast_forward(fc, q[s], g[s], A[s], cp[s], uu, wp, Huge<R>::v);
                     u[s] = uu;
                 }
             } else {
@@ -1359,9 +1394,8 @@ static hipError_t velocity_long_t(hipStream_t st, int B, int S, const double c[6
     int *changed = counters + B;    // [2 * (nsc + 2)] one counter per super-round and direction
     hipError_t err;
     if ((err = hipMemsetAsync(counters, 0, sizeof(int) * ((size_t)B + 2 * (nsc + 2)), st)) != hipSuccess) return err;
-    hipLaunchKernelGGL(k_dup_scan, dim3(64, B), dim3(256), 0, st, B, S, meta, sizeof(R) == 4 ? (const float *)curv : nullptr,
-                       sizeof(R) == 8 ? (const double *)curv : nullptr, sizeof(R) == 4 ? (const float *)dth : nullptr,
-                       sizeof(R) == 8 ? (const double *)dth : nullptr, dup);
+    hipLaunchKernelGGL(k_dup_scan<R>, dim3(64, B), dim3(256), 0, st, B, S, make_consts<R>(c), meta, (const R *)curv,
+                       (const R *)dth, dup);
     for (int dir = 0; dir < 2; dir++) {
         for (int round = 0; round <= nsc + 1; round++) {
             int *ch = changed + dir * (nsc + 2) + round;
@@ -1430,8 +1464,8 @@ hipError_t launch_velocity_windows(hipStream_t st, int B, int S, const double c[
     int *dup = counters, *changed = counters + B;
     hipError_t err;
     if ((err = hipMemsetAsync(counters, 0, sizeof(int) * ((size_t)B + 8), st)) != hipSuccess) return err;
-    hipLaunchKernelGGL(k_dup_scan, dim3(8, B), dim3(256), 0, st, B, S, meta, (const float *)curv, nullptr, (const float *)dth,
-                       nullptr, dup);
+    hipLaunchKernelGGL(k_dup_scan<R>, dim3(8, B), dim3(256), 0, st, B, S, make_consts<R>(c), meta, (const R *)curv,
+                       (const R *)dth, dup);
     for (int sc = 0; sc < nsc; sc++)
         hipLaunchKernelGGL((k_velocity_long<R, L, T, 2, false>), dim3(1, B), dim3(T), lds, st, S, nsc, 0, sc,
                            make_consts<R>(c), s * s, e * e, meta, (const R *)curv, (const R *)dth, (R *)ufwd, (R *)vel, bnd,
