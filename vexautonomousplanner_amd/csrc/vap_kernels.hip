@@ -552,10 +552,10 @@ __global__ __launch_bounds__(64) void k_velocity_seq(int B, int S, VelConsts<R> 
             const SampleLimits<R> L = sample_limits(c, (R)fabs(K[i]), c.amax, c.adec);
             up = backward_step(c, L, c.amax, twodd, u, wprev, DT[i - 1], V[i - 1]);
         }
-        V[i] = sqrt(u);
+        V[i] = vel_sqrt(u);
         u = up;
     }
-    V[0] = sqrt(u);
+    V[0] = vel_sqrt(u);
     for (int i = N; i < S; i++) V[i] = (R)0;
 }
 
@@ -849,11 +849,12 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
     const long long t_bwd1 = stats ? __builtin_amdgcn_s_memtime() : 0;
     if (bwd_active) {
         R uu = in_u, wp = in_w;
+        if (any_dup) {
 #pragma unroll
-        for (int s = L - 1; s >= 0; s--) {
-            uu = any_dup ? fast_backward<true>(fc, q[s], g[s], A[s], cp[s], uu, wp, u[s])
-                         : fast_backward<false>(fc, q[s], g[s], A[s], cp[s], uu, wp, u[s]);
-            u[s] = uu;
+            for (int s = L - 1; s >= 0; s--) u[s] = uu = fast_backward<true>(fc, q[s], g[s], A[s], cp[s], uu, wp, u[s]);
+        } else {
+#pragma unroll
+            for (int s = L - 1; s >= 0; s--) u[s] = uu = fast_backward<false>(fc, q[s], g[s], A[s], cp[s], uu, wp, u[s]);
         }
     }
     // velocities leave through the stage so the row is written with 16 bytes per lane
@@ -861,7 +862,7 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
 #pragma unroll
     for (int s = 0; s < L; s++) {
         const int j = lo + s;
-        stage[stage_pos<R, L>(j)] = j < N ? sqrt(u[s]) : (R)0;
+        stage[cpos(s)] = j < N ? vel_sqrt(u[s]) : (R)0;
     }
     __syncthreads();
     R *V = vel + row;
@@ -874,8 +875,10 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
             for (int i = tid; i < n / VW; i += T) {
                 VT v;
                 R *e = reinterpret_cast<R *>(&v);
+                const int p0 = stage_pos<R, L>(i * VW);
 #pragma unroll
-                for (int k = 0; k < VW; k++) e[k] = stage[stage_pos<R, L>(i * VW + k)];
+                for (int k = 0; k < VW; k++)   // L % VW == 0: the VW elements share a chunk
+                    e[k] = stage[(L % VW == 0) ? p0 + k : stage_pos<R, L>(i * VW + k)];
                 dst[i] = v;
             }
             for (int i = (n / VW) * VW + tid; i < n; i += T) V[i] = stage[stage_pos<R, L>(i)];
@@ -1124,7 +1127,7 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_long(int S, int nsc, in
 #pragma unroll
     for (int s = 0; s < L; s++) {
         const int j = base + lo + s;
-        stage[stage_pos<R, L>(lo + s)] = BWD ? (j < N ? sqrt(u[s]) : (R)0) : u[s];
+        stage[stage_pos<R, L>(lo + s)] = BWD ? (j < N ? vel_sqrt(u[s]) : (R)0) : u[s];
     }
     __syncthreads();
     R *dst = (BWD ? vel : ufwd) + row + base;
