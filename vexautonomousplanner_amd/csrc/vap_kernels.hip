@@ -598,20 +598,28 @@ __device__ __forceinline__ void stage_load(R *__restrict__ stage, const R *__res
         using VT = typename std::conditional<sizeof(R) == 4, float4, double2>::type;
         const VT *src4 = reinterpret_cast<const VT *>(src);
         VT v[ITER];
-        // all loads first (independent, so the memory latency is paid once), then the LDS writes
+        // all loads first (independent, so the memory latency is paid once), then the LDS writes; the one
+        // group that straddles the end of the row is assembled element by element, zero-padded
 #pragma unroll
         for (int it = 0; it < ITER; it++) {
             const int i = tid + it * T;
-            if ((i + 1) * V <= n) v[it] = src4[i];
+            if ((i + 1) * V <= n) {
+                v[it] = src4[i];
+            } else {
+                R *e = reinterpret_cast<R *>(&v[it]);
+#pragma unroll
+                for (int k = 0; k < V; k++) e[k] = (i * V + k < n) ? src[i * V + k] : (R)0;
+            }
         }
 #pragma unroll
         for (int it = 0; it < ITER; it++) {
             const int i = tid + it * T;
             const R *e = reinterpret_cast<const R *>(&v[it]);
+            if (i * V < cap_n) {   // the stage has room for a whole group past cap_n (T*L + T + 8 words)
+                const int p0 = stage_pos<R, L>(i * V);
 #pragma unroll
-            for (int k = 0; k < V; k++) {
-                const int idx = i * V + k;
-                if (idx < cap_n) stage[stage_pos<R, L>(idx)] = (i + 1) * V <= n ? e[k] : (idx < n ? src[idx] : (R)0);
+                for (int k = 0; k < V; k++)   // L % V == 0: the V elements share a chunk
+                    stage[(L % V == 0) ? p0 + k : stage_pos<R, L>(i * V + k)] = e[k];
             }
         }
     } else {
