@@ -643,6 +643,35 @@ struct alignas(2 * sizeof(R)) BoundaryState {
     R u, w;
 };
 
+// Whole-wave lane shifts by DPP (no LDS round trip): lane i receives lane i-1 (up) / i+1 (down);
+// lane 0 (up) / lane 63 (down) keep their own value.
+__device__ __forceinline__ float wave_shift_up(float x)
+{
+    const int v = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(v, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_shift_down(float x)
+{
+    const int v = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(v, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+}
+__device__ __forceinline__ double wave_shift_up(double x)
+{
+    const uint64_t v = __builtin_bit_cast(uint64_t, x);
+    const int lo = (int)(uint32_t)v, hi = (int)(uint32_t)(v >> 32);
+    const uint32_t l2 = (uint32_t)__builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
+    const uint32_t h2 = (uint32_t)__builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((uint64_t)h2 << 32) | l2);
+}
+__device__ __forceinline__ double wave_shift_down(double x)
+{
+    const uint64_t v = __builtin_bit_cast(uint64_t, x);
+    const int lo = (int)(uint32_t)v, hi = (int)(uint32_t)(v >> 32);
+    const uint32_t l2 = (uint32_t)__builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
+    const uint32_t h2 = (uint32_t)__builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((uint64_t)h2 << 32) | l2);
+}
+
 template <typename R, int L, int MAXT, int MINW>
 __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<R> c, R start_u, R end_u,
                                                                const double *__restrict__ meta,
@@ -654,7 +683,7 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     R *stage = reinterpret_cast<R *>(smem_raw);   // (T*L + T + 2) elements
     // boundary states, double-buffered by round parity so one barrier per round suffices
-    __shared__ BoundaryState<R> s_bs[2][MAXT + 2];
+    __shared__ BoundaryState<R> s_bs[2][MAXT / 64 + 2];   // states crossing a wavefront boundary
     __shared__ int s_any[3];   // "some chunk's incoming state changed" per round, rotating slots
     __shared__ int s_dup;
     const long long t_start = stats ? __builtin_amdgcn_s_memtime() : 0;
@@ -735,33 +764,46 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
     __syncthreads();
     const bool any_dup = s_dup != 0;
     const long long t_fwd0 = stats ? __builtin_amdgcn_s_memtime() : 0;
-    // Round r: evaluate if the incoming state changed; publish (always) into buffer r&1; barrier;
-    // pick up the neighbour's state together with the "someone changed" flag of round r-1 (one LDS
-    // round trip); raise this round's flag if the state differs.  The flags rotate over three slots
-    // (this round's, the next one's being cleared, the previous one's being read), so termination lags
-    // one cheap round and needs no second barrier.
+    // A round: up to kInner times { lanes whose incoming state changed re-run their chunk; the outgoing
+    // states move one lane up inside each wavefront by DPP }, then the states that cross a wavefront
+    // boundary go through LDS (buffer r&1) behind one workgroup barrier, picked up together with the
+    // "someone still has work" flag of round r-1.  The flags rotate over three slots (this round's, the
+    // next one's being cleared, the previous one's being read), so termination lags one cheap round and
+    // needs no second barrier.  Chains are ~6 chunks long on average: most end inside one round.
+    constexpr int kInner = 8;
+    const int wv = tid >> 6, lane = tid & 63;
     int f_cur = 0, f_nxt = 1, f_prv = 2;
     while (true) {
-        if (need) {
-            R uu = in_u, wp = in_w;
+#pragma unroll 1
+        for (int k = 0; k < kInner; k++) {
+            if (need) {
+                R uu = in_u, wp = in_w;
 #pragma unroll
-            for (int s = 0; s < L; s++) {
-                if (s == 0 && tid == 0) continue;   // sample 0 is the given start velocity (MPG:189)
-                uu = fast_forward(fc, q[s], g[s], A[s], cp[s], uu, wp, Huge<R>::v);
-                u[s] = uu;
+                for (int s = 0; s < L; s++) {
+                    if (s == 0 && tid == 0) continue;   // sample 0 is the given start velocity (MPG:189)
+                    uu = fast_forward(fc, q[s], g[s], A[s], cp[s], uu, wp, Huge<R>::v);
+                    u[s] = uu;
+                }
+                out_u = uu;
+                out_w = wp;
             }
-            out_u = uu;
-            out_w = wp;
+            const R nu = wave_shift_up(out_u), nw = wave_shift_up(out_w);
+            need = false;
+            if (lane > 0 && fwd_active) {
+                need = !(same_bits(nu, in_u) && same_bits(nw, in_w));
+                in_u = nu;
+                in_w = nw;
+            }
+            if (__ballot(need) == 0) break;
         }
         const int pb = rounds & 1;
-        s_bs[pb][tid + 1] = BoundaryState<R>{out_u, out_w};
+        if (lane == 63) s_bs[pb][wv + 1] = BoundaryState<R>{out_u, out_w};
         if (tid == 0) s_any[f_nxt] = 0;
         __syncthreads();
         const int changed_last = s_any[f_prv];
-        const BoundaryState<R> nb = s_bs[pb][tid];
-        if (rounds > 0 && changed_last == 0) break;   // nobody changed last round
-        need = false;
-        if (tid > 0 && fwd_active) {
+        const BoundaryState<R> nb = s_bs[pb][wv];
+        if (rounds > 0 && changed_last == 0) break;   // nobody had work left last round
+        if (lane == 0 && tid > 0 && fwd_active) {
             need = !(same_bits(nb.u, in_u) && same_bits(nb.w, in_w));
             in_u = nb.u;
             in_w = nb.w;
@@ -820,28 +862,38 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
     if (tid == 0) { s_any[0] = 0; s_any[1] = 0; s_any[2] = 0; }
     __syncthreads();
     f_cur = 0; f_nxt = 1; f_prv = 2;
-    while (true) {
-        if (need) {
-            R uu = in_u, wp = in_w;
-            if (any_dup) {
+    while (true) {   // mirror image: states move one lane down, wave w+1 hands its first chunk's state to wave w
+#pragma unroll 1
+        for (int k = 0; k < kInner; k++) {
+            if (need) {
+                R uu = in_u, wp = in_w;
+                if (any_dup) {
 #pragma unroll
-                for (int s = L - 1; s >= 0; s--) uu = fast_backward<true>(fc, q[s], g[s], A[s], cp[s], uu, wp, u[s]);
-            } else {
+                    for (int s = L - 1; s >= 0; s--) uu = fast_backward<true>(fc, q[s], g[s], A[s], cp[s], uu, wp, u[s]);
+                } else {
 #pragma unroll
-                for (int s = L - 1; s >= 0; s--) uu = fast_backward<false>(fc, q[s], g[s], A[s], cp[s], uu, wp, u[s]);
+                    for (int s = L - 1; s >= 0; s--) uu = fast_backward<false>(fc, q[s], g[s], A[s], cp[s], uu, wp, u[s]);
+                }
+                out_u = uu;
+                out_w = wp;
             }
-            out_u = uu;
-            out_w = wp;
+            const R nu = wave_shift_down(out_u), nw = wave_shift_down(out_w);
+            need = false;
+            if (lane < 63 && tid < last_chunk) {
+                need = !(same_bits(nu, in_u) && same_bits(nw, in_w));
+                in_u = nu;
+                in_w = nw;
+            }
+            if (__ballot(need) == 0) break;
         }
         const int pb = rounds & 1;
-        s_bs[pb][tid] = BoundaryState<R>{out_u, out_w};
+        if (lane == 0) s_bs[pb][wv] = BoundaryState<R>{out_u, out_w};
         if (tid == 0) s_any[f_nxt] = 0;
         __syncthreads();
         const int changed_last = s_any[f_prv];
-        const BoundaryState<R> nb = s_bs[pb][tid + 1];
+        const BoundaryState<R> nb = s_bs[pb][wv + 1];
         if (rounds > 0 && changed_last == 0) break;
-        need = false;
-        if (tid < last_chunk) {
+        if (lane == 63 && tid < last_chunk) {
             need = !(same_bits(nb.u, in_u) && same_bits(nb.w, in_w));
             in_u = nb.u;
             in_w = nb.w;
