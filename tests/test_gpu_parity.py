@@ -375,3 +375,41 @@ def test_time_profile_batch_fp32_and_truncation():
     tp, flags = _time_profile("f64", wp, cap=100)
     assert (tp["counts"][:, 0] == 100).all()
     assert (flags & 2).all()          # VAP_FLAG_TRUNCATED
+
+
+@pytest.mark.gpu
+def test_time_profile_argument_errors(torch_mod):
+    """vap_time_profile through the C-ABI: status codes for a context without tables, a shape that does not
+    match the last batch, and null / non-positive arguments."""
+    import ctypes as C
+    from vexautonomousplanner_amd import _lib
+    from vexautonomousplanner_amd.batch import BatchedTrajectoryGenerator
+    from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
+    torch = torch_mod
+    L = _lib.lib()
+    c = _lib.make_constraints(DEFAULT_CONSTRAINTS)
+    B, W, S, cap = 4, 8, 512, 64
+    vel = torch.zeros((B, S), dtype=torch.float32, device="cuda:0")
+    meta = torch.zeros((B, 4), dtype=torch.float64, device="cuda:0")
+    rows = torch.zeros((B, cap, 8), dtype=torch.float64, device="cuda:0")
+    counts = torch.zeros((B, 2), dtype=torch.int32, device="cuda:0")
+    nmap = torch.zeros((B, W), dtype=torch.int32, device="cuda:0")
+
+    def call(ctx, b=B, w=W, dt=0.01, rows_p=rows, cap_rows=cap):
+        return L.vap_time_profile(ctx.handle, _lib.VAP_F32, b, w, S, None, None, C.c_void_p(meta.data_ptr()),
+                                  C.c_void_p(vel.data_ptr()), C.byref(c), dt, cap_rows,
+                                  C.c_void_p(rows_p.data_ptr()) if rows_p is not None else None,
+                                  C.c_void_p(counts.data_ptr()), C.c_void_p(nmap.data_ptr()), None)
+
+    fresh = _lib.Context(0)
+    assert call(fresh) == _lib.VAP_ERR_UNFITTED           # no tables in this context yet
+    gen = BatchedTrajectoryGenerator(0, "f32")
+    wp = torch.tensor(make_waypoints(B, W, 5), device="cuda:0", dtype=torch.float32)
+    res = gen.profile(wp, DEFAULT_CONSTRAINTS, samples=S)
+    assert call(gen.ctx, b=B + 1) == _lib.VAP_ERR_UNFITTED    # tables are for another batch shape
+    assert call(gen.ctx, dt=0.0) == _lib.VAP_ERR_INVALID
+    assert call(gen.ctx, cap_rows=0) == _lib.VAP_ERR_INVALID
+    assert call(gen.ctx, rows_p=None) == _lib.VAP_ERR_INVALID
+    tp = gen.time_profile(res, DEFAULT_CONSTRAINTS, capacity_rows=2048)
+    torch.cuda.synchronize()
+    assert int(tp["counts"][:, 0].min().item()) > 10
