@@ -588,33 +588,56 @@ __device__ __forceinline__ bool same_bits(R a, R b)
 template <typename R, int L>
 __device__ __forceinline__ int stage_pos(int i) { return i + i / L; }
 
+// One thread's share of a row on its way from HBM to the stage.  Fetch and put are separate so that a
+// row's loads can be in flight while the previous row is being consumed.
 template <typename R, int L>
-__device__ __forceinline__ void stage_load(R *__restrict__ stage, const R *__restrict__ src, int n, int cap_n,
-                                           bool aligned, int tid, int T)
+struct RowRegs {
+    static constexpr int V = 16 / sizeof(R);
+    static constexpr int ITER = (L + V - 1) / V + 1;   // covers cap_n <= T*L + V elements
+    using VT = typename std::conditional<sizeof(R) == 4, float4, double2>::type;
+    VT v[ITER];      // rows that start 16-byte aligned: 16 bytes per lane
+    R s[L + 1];      // other rows: one element per lane
+};
+
+template <typename R, int L>
+__device__ __forceinline__ void row_fetch(RowRegs<R, L> &r, const R *__restrict__ src, int n, bool aligned, int tid, int T)
 {
-    constexpr int V = 16 / sizeof(R);
-    constexpr int ITER = (L + V - 1) / V + 1;   // covers cap_n <= T*L + 1 elements
+    using RR = RowRegs<R, L>;
+    constexpr int V = RR::V;
     if (aligned) {
-        using VT = typename std::conditional<sizeof(R) == 4, float4, double2>::type;
-        const VT *src4 = reinterpret_cast<const VT *>(src);
-        VT v[ITER];
-        // all loads first (independent, so the memory latency is paid once), then the LDS writes; the one
-        // group that straddles the end of the row is assembled element by element, zero-padded
+        const typename RR::VT *src4 = reinterpret_cast<const typename RR::VT *>(src);
+        // all loads first (independent, so the memory latency is paid once); the one group that straddles
+        // the end of the row is assembled element by element, zero-padded
 #pragma unroll
-        for (int it = 0; it < ITER; it++) {
+        for (int it = 0; it < RR::ITER; it++) {
             const int i = tid + it * T;
             if ((i + 1) * V <= n) {
-                v[it] = src4[i];
+                r.v[it] = src4[i];
             } else {
-                R *e = reinterpret_cast<R *>(&v[it]);
+                R *e = reinterpret_cast<R *>(&r.v[it]);
 #pragma unroll
                 for (int k = 0; k < V; k++) e[k] = (i * V + k < n) ? src[i * V + k] : (R)0;
             }
         }
+    } else {
 #pragma unroll
-        for (int it = 0; it < ITER; it++) {
+        for (int it = 0; it < L + 1; it++) {
             const int i = tid + it * T;
-            const R *e = reinterpret_cast<const R *>(&v[it]);
+            r.s[it] = i < n ? src[i] : (R)0;
+        }
+    }
+}
+
+template <typename R, int L>
+__device__ __forceinline__ void stage_put(R *__restrict__ stage, const RowRegs<R, L> &r, int cap_n, bool aligned, int tid, int T)
+{
+    using RR = RowRegs<R, L>;
+    constexpr int V = RR::V;
+    if (aligned) {
+#pragma unroll
+        for (int it = 0; it < RR::ITER; it++) {
+            const int i = tid + it * T;
+            const R *e = reinterpret_cast<const R *>(&r.v[it]);
             if (i * V < cap_n) {   // the stage has room for a whole group past cap_n (T*L + T + 8 words)
                 const int p0 = stage_pos<R, L>(i * V);
 #pragma unroll
@@ -623,18 +646,21 @@ __device__ __forceinline__ void stage_load(R *__restrict__ stage, const R *__res
             }
         }
     } else {
-        R v[L + 1];
 #pragma unroll
         for (int it = 0; it < L + 1; it++) {
             const int i = tid + it * T;
-            v[it] = i < n ? src[i] : (R)0;
-        }
-#pragma unroll
-        for (int it = 0; it < L + 1; it++) {
-            const int i = tid + it * T;
-            if (i < cap_n) stage[stage_pos<R, L>(i)] = v[it];
+            if (i < cap_n) stage[stage_pos<R, L>(i)] = r.s[it];
         }
     }
+}
+
+template <typename R, int L>
+__device__ __forceinline__ void stage_load(R *__restrict__ stage, const R *__restrict__ src, int n, int cap_n,
+                                           bool aligned, int tid, int T)
+{
+    RowRegs<R, L> r;
+    row_fetch<R, L>(r, src, n, aligned, tid, T);
+    stage_put<R, L>(stage, r, cap_n, aligned, tid, T);
 }
 
 // Boundary state of the recurrence between two chunks: the last two squared velocities.
@@ -707,6 +733,8 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
     const int cbase = tid * (L + 1);
     auto cpos = [&](int k) { return k < 0 ? cbase + k - 1 : (k < L ? cbase + k : cbase + k + 1); };
     stage_load<R, L>(stage, K, N < TL ? N : TL, TL, aligned, tid, T);
+    RowRegs<R, L> rd;   // the dtheta row is fetched while the curvature row is consumed
+    row_fetch<R, L>(rd, DT, N < TL ? N : TL, aligned, tid, T);
     __syncthreads();
     // Samples are handled BK at a time: BK unconditional LDS reads in one batch (one wait), then
     // straight-line arithmetic, one sample after the other (the opaque() keeps the scheduler from
@@ -734,7 +762,7 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
         }
     }
     __syncthreads();
-    stage_load<R, L>(stage, DT, N < TL ? N : TL, TL, aligned, tid, T);
+    stage_put<R, L>(stage, rd, TL, aligned, tid, T);
     __syncthreads();
     bool dup = false;
 #pragma unroll
@@ -823,10 +851,12 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
     // (and k[j+2] for rho).  Slots at or past the fixed end sample N-1 are idle slots holding
     // u = end_u: walking through them restarts the chain exactly as MPG:252-253 does.
     // (The stage still holds dtheta.)
+    RowRegs<R, L> rk;   // the curvature row comes back while dtheta is read out of the stage
+    row_fetch<R, L>(rk, K, N < TL + 2 ? N : TL + 2, aligned, tid, T);
 #pragma unroll
     for (int s = 0; s < L; s++) g[s] = stage[cpos(s)];   // dtheta[j] for now
     __syncthreads();
-    stage_load<R, L>(stage, K, N < TL + 2 ? N : TL + 2, TL + 2, aligned, tid, T);
+    stage_put<R, L>(stage, rk, TL + 2, aligned, tid, T);
     __syncthreads();
     {
         R kc = (R)fabs(stage[cpos(1)]);
