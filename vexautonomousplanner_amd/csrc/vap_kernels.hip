@@ -732,9 +732,11 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
     // further for the next chunk's samples and one word nearer for the previous chunk's.
     const int cbase = tid * (L + 1);
     auto cpos = [&](int k) { return k < 0 ? cbase + k - 1 : (k < L ? cbase + k : cbase + k + 1); };
-    stage_load<R, L>(stage, K, N < TL ? N : TL, TL, aligned, tid, T);
+    // rows are read up to the capacity S, not the sample count N (samples past N hold zeros): the loads
+    // then do not wait for the meta record
+    stage_load<R, L>(stage, K, S < TL ? S : TL, TL, aligned, tid, T);
     RowRegs<R, L> rd;   // the dtheta row is fetched while the curvature row is consumed
-    row_fetch<R, L>(rd, DT, N < TL ? N : TL, aligned, tid, T);
+    row_fetch<R, L>(rd, DT, S < TL ? S : TL, aligned, tid, T);
     __syncthreads();
     // Samples are handled BK at a time: BK unconditional LDS reads in one batch (one wait), then
     // straight-line arithmetic, one sample after the other (the opaque() keeps the scheduler from
@@ -852,7 +854,7 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
     // u = end_u: walking through them restarts the chain exactly as MPG:252-253 does.
     // (The stage still holds dtheta.)
     RowRegs<R, L> rk;   // the curvature row comes back while dtheta is read out of the stage
-    row_fetch<R, L>(rk, K, N < TL + 2 ? N : TL + 2, aligned, tid, T);
+    row_fetch<R, L>(rk, K, S < TL + 2 ? S : TL + 2, aligned, tid, T);
 #pragma unroll
     for (int s = 0; s < L; s++) g[s] = stage[cpos(s)];   // dtheta[j] for now
     __syncthreads();
