@@ -144,7 +144,7 @@ int vap_ctx_create(int device, vap_ctx **out)
     c->stream = c->own_stream;
     for (auto &e : c->ev) {
         if (hipEventCreate(&e) != hipSuccess) {
-            delete c;
+            (void)vap_ctx_destroy(c);   // releases the stream and the events created so far
             return vap_fail(VAP_ERR_HIP, "hipEventCreate failed");
         }
     }
