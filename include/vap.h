@@ -132,6 +132,9 @@ int vap_sample(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd, const
                void *d_curvature, void *d_dtheta, uint32_t *d_flags);
 
 /* MPG:188-316 forward + backward pass.  d_velocity receives the final velocities (MPG:316).
+ * As in the reference, max_dec does not take part: boundary_map always contains sample 0 (MPG:110), so
+ * forward_backward_pass replaces it with max_acc before its first step (MPG:194-196) and decelerates
+ * with max_acc; max_dec is used by the time loop only (vap_time_profile, vap_route_motion_profile).
  * d_vcap: optional [B][S] (dtype) per-sample initial velocities (MPG:121,127,153,172; NULL = the
  * plain-node default max_vel with start/end velocities at the ends). */
 int vap_velocity_pass(vap_ctx *ctx, vap_dtype dt, int B, int S, const vap_constraints *c,

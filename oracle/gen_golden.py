@@ -217,6 +217,17 @@ def main():
     if args.c2 and want("c2_w256_S1000000"):
         run_case(mods, "c2_w256_S1000000", c2wp, samples=1000000, keep="strided")
 
+    # robots whose max_dec differs from max_acc: boundary_map always holds sample 0 (MPG:110), so the
+    # reference overwrites max_dec with max_acc before the first forward step (MPG:194-196) and the
+    # backward sweep decelerates with max_acc; only the time loop sees the given max_dec (MPG:572-573)
+    for tag, cons in (("dec_lt_acc", (4.0, 12.0, 6.0, 0.8, 16.0, 12.5 / 12)),
+                      ("dec_gt_acc", (4.0, 6.0, 12.0, 0.8, 16.0, 12.5 / 12)),
+                      ("other_robot", (6.5, 10.0, 7.0, 0.8, 16.0, 0.75))):
+        if want(f"cons_{tag}_w8"):
+            run_case(mods, f"cons_{tag}_w8", make_waypoints(1, 8, 21)[0], constraints=cons, full_profile=True)
+        if want(f"cons_{tag}_S1024"):
+            run_case(mods, f"cons_{tag}_S1024", make_waypoints(1, 8, 22)[0], samples=1024, constraints=cons)
+
     # ---- feature cases for SURVEY.md §8(f) "next" rows (node / action-point semantics) ----
     wp8 = make_waypoints(1, 8, 11)[0]
     if want("feat_stop"):

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Developer tool (GPU box): randomized parity sweep of the batched pipeline against the oracle.
+
+Random batch shapes (W, S on the fixed-S grid), random robots, both dtypes; reports the worst relative
+errors per field and any path that is flagged.  tests/ holds the curated cases; this looks for rare ones
+(DESIGN.md §2 "How far the fp32 bound holds" summarises what it finds).
+  python tools/fuzz_parity.py [seconds]
+"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from oracle import oracle
+from vexautonomousplanner_amd.batch import BatchedTrajectoryGenerator
+from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(20260101)
+gens = {"f32": BatchedTrajectoryGenerator(0, "f32"), "f64": BatchedTrajectoryGenerator(0, "f64")}
+tol = {"f32": 1e-5, "f64": 1e-9}
+worst = {"f32": {}, "f64": {}}
+fails = 0
+t0 = time.time()
+n_cases = 0
+while time.time() - t0 < budget:
+    W = int(rng.choice([2, 3, 4, 5, 8, 13, 32, 57]))
+    S = int(rng.choice([2, 3, 7, 64, 255, 256, 257, 1000, 1024, 1025, 4096, 4097, 10000, 20480, 20481, 30000]))
+    B = int(rng.integers(1, 9)) if S <= 10000 else int(rng.integers(1, 3))
+    seed = int(rng.integers(0, 1 << 30))
+    cons = list(DEFAULT_CONSTRAINTS)
+    if rng.random() < 0.5:   # other robots: max_vel, max_acc, max_dec, track width
+        cons[0] = float(rng.uniform(1.0, 8.0))
+        cons[1] = float(rng.uniform(2.0, 16.0))
+        cons[2] = float(rng.uniform(2.0, 16.0))
+        cons[5] = float(rng.uniform(0.5, 2.0))
+    wp = make_waypoints(B, W, seed).astype(np.float64)
+    ref = oracle.profile_batch(wp, S, cons, n_threads=8)
+    for dt in ("f32", "f64"):
+        t = torch.tensor(wp, device="cuda:0", dtype=torch.float32 if dt == "f32" else torch.float64)
+        got = gens[dt].profile(t, cons, samples=S)
+        torch.cuda.synchronize()
+        flags = got["flags"].cpu().numpy()
+        g = {k: got[k].cpu().numpy().astype(np.float64) for k in ("x", "y", "heading", "curvature", "velocity")}
+        e = {"velocity": np.max(np.abs(g["velocity"] - ref["velocity"]) / np.abs(ref["velocity"])),
+             "curvature": np.max(np.abs(g["curvature"] - ref["curvature"]) / np.maximum(np.abs(ref["curvature"]), 1e-2)),
+             "heading": np.max(np.abs(g["heading"] - ref["heading"])) / np.pi,
+             "x": np.max(np.abs(g["x"] - ref["x"]) / np.maximum(np.abs(ref["x"]), 1.0)),
+             "y": np.max(np.abs(g["y"] - ref["y"]) / np.maximum(np.abs(ref["y"]), 1.0))}
+        for k, v in e.items():
+            worst[dt][k] = max(worst[dt].get(k, 0.0), float(v))
+        bad = [k for k, v in e.items() if not (v <= tol[dt])]
+        if bad or flags.any():
+            fails += 1
+            print(f"FAIL {dt} B={B} W={W} S={S} seed={seed} cons={cons} flags={flags.tolist()} " +
+                  " ".join(f"{k}={e[k]:.2e}" for k in e), flush=True)
+    n_cases += 1
+print(f"{n_cases} cases in {time.time() - t0:.0f} s, {fails} failures")
+for dt in ("f32", "f64"):
+    print(dt, " ".join(f"{k} {v:.2e}" for k, v in worst[dt].items()))
+sys.exit(1 if fails else 0)

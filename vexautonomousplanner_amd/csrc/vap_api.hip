@@ -268,7 +268,11 @@ int vap_velocity_pass(vap_ctx *ctx, vap_dtype dt, int B, int S, const vap_constr
     VAP_TRY(vap_set_device(ctx));
     VAP_TRY(check_shape(B, 2, S));
     if (!c || !d_meta || !d_curvature || !d_dtheta || !d_velocity) return vap_fail(VAP_ERR_INVALID, "null buffer");
-    const double cc[6] = {c->max_vel, c->max_acc, c->max_dec, c->friction_coef, c->max_jerk, c->track_width};
+    // Quirk Q9: boundary_map always holds sample 0 (MPG:110), so the reference overwrites max_dec with
+    // max_accels[0] — max_acc for a plain node — before the first forward step (MPG:194-196) and never
+    // restores it until the pass returns: the backward sweep decelerates with max_acc.  (The time loop
+    // does see the caller's max_dec, MPG:572-573 — vap_time_profile.)
+    const double cc[6] = {c->max_vel, c->max_acc, c->max_acc, c->friction_coef, c->max_jerk, c->track_width};
     VAP_TRY(run_velocity(ctx, dt == VAP_F64, B, S, cc, start_vel, end_vel, d_meta, d_curvature, d_dtheta, d_vcap,
                          d_velocity, d_flags));
     return VAP_OK;
@@ -304,7 +308,11 @@ int vap_profile_batch(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd
         VAP_TRY(ctx->ensure(ctx->io[7], n_pts * esz(dt)));
         curv = ctx->io[7].ptr;
     }
-    const double cc[6] = {c->max_vel, c->max_acc, c->max_dec, c->friction_coef, c->max_jerk, c->track_width};
+    // Quirk Q9: boundary_map always holds sample 0 (MPG:110), so the reference overwrites max_dec with
+    // max_accels[0] — max_acc for a plain node — before the first forward step (MPG:194-196) and never
+    // restores it until the pass returns: the backward sweep decelerates with max_acc.  (The time loop
+    // does see the caller's max_dec, MPG:572-573 — vap_time_profile.)
+    const double cc[6] = {c->max_vel, c->max_acc, c->max_acc, c->friction_coef, c->max_jerk, c->track_width};
     StageTimer tm(ctx);
     HIP_TRY(vap::launch_fit(ctx->stream, f64, B, W, d_waypoints, nullptr, nullptr, (double *)ctx->seg.ptr,
                             (double *)ctx->power.ptr, nullptr, meta, flags));
