@@ -38,13 +38,41 @@ while time.time() - t0 < budget:
         cons[2] = float(rng.uniform(2.0, 16.0))
         cons[5] = float(rng.uniform(0.5, 2.0))
     wp = make_waypoints(B, W, seed).astype(np.float64)
-    ref = oracle.profile_batch(wp, S, cons, n_threads=8)
+    sv, ev = 0.01, 0.01
+    if rng.random() < 0.3:   # other start / end velocities (forward_backward_pass arguments, MPG:74-75)
+        sv, ev = float(rng.uniform(0.01, 2.0)), float(rng.uniform(0.01, 2.0))
+    use_dd = S <= 4097 and rng.random() < 0.3   # the reference's own grid (ragged sample counts), path by path
+    if use_dd:
+        dd = float(rng.uniform(0.002, 0.02))
+        per = []
+        for b in range(B):
+            op = oracle.OraclePath(wp[b])
+            op.rebuild_tables()
+            per.append(op.forward_backward(cons, dd=dd, start_vel=sv, end_vel=ev))
+        cap = max(len(p["velocity"]) for p in per) + 3
+        ref = {k: np.zeros((B, cap)) for k in ("x", "y", "heading", "curvature", "velocity")}
+        for b, pth in enumerate(per):
+            for k in ref:
+                ref[k][b, :len(pth[k])] = pth[k]
+        ref["velocity"][ref["velocity"] == 0] = 1.0     # padding: both sides are 0 there, keep the ratio finite
+    else:
+        ref = oracle.profile_batch(wp, S, cons, start_vel=sv, end_vel=ev, n_threads=8)
     for dt in ("f32", "f64"):
         t = torch.tensor(wp, device="cuda:0", dtype=torch.float32 if dt == "f32" else torch.float64)
-        got = gens[dt].profile(t, cons, samples=S)
+        if use_dd:
+            got = gens[dt].profile(t, cons, dd=dd, capacity=cap, start_vel=sv, end_vel=ev)
+        else:
+            got = gens[dt].profile(t, cons, samples=S, start_vel=sv, end_vel=ev)
         torch.cuda.synchronize()
         flags = got["flags"].cpu().numpy()
         g = {k: got[k].cpu().numpy().astype(np.float64) for k in ("x", "y", "heading", "curvature", "velocity")}
+        if use_dd:
+            n_ref = np.array([len(p["velocity"]) for p in per])
+            if not np.array_equal(got["meta"][:, 3].cpu().numpy().astype(int), n_ref):
+                fails += 1
+                print(f"FAIL {dt} sample counts differ B={B} W={W} dd={dd} seed={seed}", flush=True)
+                continue
+            g["velocity"] = np.where(ref["velocity"] == 1.0, 1.0, g["velocity"])
         e = {"velocity": np.max(np.abs(g["velocity"] - ref["velocity"]) / np.abs(ref["velocity"])),
              "curvature": np.max(np.abs(g["curvature"] - ref["curvature"]) / np.maximum(np.abs(ref["curvature"]), 1e-2)),
              "heading": np.max(np.abs(g["heading"] - ref["heading"])) / np.pi,
@@ -55,7 +83,7 @@ while time.time() - t0 < budget:
         bad = [k for k, v in e.items() if not (v <= tol[dt])]
         if bad or flags.any():
             fails += 1
-            print(f"FAIL {dt} B={B} W={W} S={S} seed={seed} cons={cons} flags={flags.tolist()} " +
+            print(f"FAIL {dt} B={B} W={W} S={S} {'dd' if use_dd else 'fixed'} sv={sv:.3f} ev={ev:.3f} seed={seed} cons={cons} flags={flags.tolist()} " +
                   " ".join(f"{k}={e[k]:.2e}" for k in e), flush=True)
     n_cases += 1
 print(f"{n_cases} cases in {time.time() - t0:.0f} s, {fails} failures")
