@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Developer tool (GPU box): randomised check of the drop-in classes (general routes: stops, limits, tangent
+overrides, reverse / turn nodes, waits, action points; random robots) against the oracle, which
+oracle/fuzz_vs_reference.py holds to the real reference on the same kind of routes.
+  python tools/fuzz_routes.py [seconds] [seed]
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "dropin"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+
+import oracle                                              # oracle/oracle.py (ctypes binding of the C restatement)
+from fuzz_vs_reference import random_route                 # the same route generator
+from gen_golden import node_arrays
+from motion_profiling_v2 import motion_profile_generator as mpg
+from splines.spline_manager import QuinticHermiteSplineManager
+from vexautonomousplanner_amd.nodes import ActionPoint, Node
+from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 11)
+n = fails = 0
+worst_v = worst_p = 0.0
+t0 = time.time()
+while time.time() - t0 < budget:
+    W = int(rng.integers(2, 9))
+    wp = make_waypoints(1, W, int(rng.integers(0, 1 << 30)))[0].astype(np.float64)
+    plain = rng.random() < 0.3
+    na, aps = ([{} for _ in range(W)], []) if plain else random_route(rng, W)
+    cons = list(DEFAULT_CONSTRAINTS)
+    if rng.random() < 0.6:
+        cons[0] = float(rng.uniform(1.5, 7.0))
+        cons[1] = float(rng.uniform(2.0, 14.0))
+        cons[2] = float(rng.uniform(2.0, 14.0))
+        cons[5] = float(rng.uniform(0.6, 1.6))
+    dd = float(rng.choice([0.005, 0.003, 0.011]))
+    tag = f"W={W} plain={plain} cons={[round(c, 3) for c in cons]} dd={dd} nodes={na} aps={aps}"
+    # oracle
+    arrs = node_arrays(W, na)
+    nodes = dict(is_reverse=arrs["node_is_reverse_node"], turn=arrs["node_turn"], stop=arrs["node_stop"],
+                 wait_time=arrs["node_wait_time"], max_velocity=arrs["node_max_velocity"],
+                 max_acceleration=arrs["node_max_acceleration"], tangent=arrs["node_tangent"],
+                 magnitudes=np.nan_to_num(arrs["node_magnitudes"]))
+    actions = None
+    if aps:
+        actions = dict(t=np.array([a["t"] for a in aps]),
+                       **{k: np.array([float(a.get(k, 0)) for a in aps]) for k in ("stop", "wait_time", "max_velocity", "max_acceleration")})
+    op = oracle.OraclePath(wp, nodes=nodes, actions=actions)
+    op.rebuild_tables()
+    v_or = op.forward_backward(cons, dd=dd)["velocity"]
+    try:
+        rows, nmap, amap = op.generate_motion_profile(cons, dd=dd)
+    except ValueError:
+        continue          # routes on which the reference (and the oracle) fail
+    # drop-in classes on the GPU
+    gn = []
+    for a in na:
+        kw = dict(a)
+        if kw.get("tangent") is not None:
+            kw["tangent"] = np.asarray(kw["tangent"], dtype=float)
+        gn.append(Node(**kw))
+    ga = [ActionPoint(**a) for a in aps]
+    m = QuinticHermiteSplineManager()
+    assert m.build_path(wp, gn, ga) is True
+    m.rebuild_tables()
+    v = np.array(mpg.forward_backward_pass(m, mpg.Constraints(*cons), dd))
+    res = mpg.generate_motion_profile(m, mpg.Constraints(*cons), dd=dd)
+    n += 1
+    ok = len(v) == len(v_or)
+    ev = np.max(np.abs(v - v_or) / np.abs(v_or)) if ok else np.inf
+    T = len(res[0])
+    ok = ok and T == rows.shape[0] and [int(x) for x in res[6]] == list(nmap) and [int(x) for x in res[7]] == list(amap)
+    ep = np.inf
+    if ok:
+        got = np.column_stack([np.array(res[k], dtype=np.float64) for k in range(6)] + [np.array([np.asarray(p, float) for p in res[8]]).reshape(T, 2)])
+        ep = np.max(np.abs(got - rows) / np.maximum(np.abs(rows), 1.0)) if T else 0.0
+    worst_v, worst_p = max(worst_v, ev), max(worst_p, ep)
+    if not (ok and ev <= 1e-9 and ep <= 1e-7):
+        fails += 1
+        print(f"MISMATCH velocity {ev:.2e} profile {ep:.2e} rows {T} vs {rows.shape[0]} | {tag}", flush=True)
+print(f"{n} routes in {time.time() - t0:.0f} s, {fails} mismatches; worst velocity {worst_v:.2e}, worst profile {worst_p:.2e}")
+sys.exit(1 if fails else 0)
