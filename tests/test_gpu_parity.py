@@ -321,27 +321,30 @@ def test_batch_vs_oracle_other_robots(torch_mod, gens, cons, dtype, tol):
 
 
 # ---- batched time-domain resample (vap_time_profile; SURVEY §8(f)-1 at batch scale) -----------------
-def _time_profile(dtype, wp, dt=0.01, cap=4096):
+def _time_profile(dtype, wp, dt=0.01, cap=4096, cons=None):
     import torch
     from vexautonomousplanner_amd.batch import BatchedTrajectoryGenerator
     from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS
+    cons = DEFAULT_CONSTRAINTS if cons is None else cons
     gen = BatchedTrajectoryGenerator(0, dtype)
     t = torch.tensor(wp, device="cuda:0", dtype=torch.float64 if dtype == "f64" else torch.float32)
-    res = gen.profile(t, DEFAULT_CONSTRAINTS, dd=0.005, capacity=16384)
-    tp = gen.time_profile(res, DEFAULT_CONSTRAINTS, dt=dt, capacity_rows=cap)
+    res = gen.profile(t, cons, dd=0.005, capacity=16384)
+    tp = gen.time_profile(res, cons, dt=dt, capacity_rows=cap)
     torch.cuda.synchronize()
     return ({k: v.cpu().numpy() for k, v in tp.items()}, res["flags"].cpu().numpy())
 
 
 @pytest.mark.gpu
-def test_time_profile_batch_matches_reference_golden():
-    """Config 1: the reference's own 9-tuple (generate_motion_profile on the 8-waypoint path), through the
-    batched kernels with the path replicated next to two others."""
+@pytest.mark.parametrize("name", ["c1_w8"] + [n for n in gu.names("cons_") if n.endswith("_w8")])
+def test_time_profile_batch_matches_reference_golden(name):
+    """The reference's own 9-tuple (generate_motion_profile) for config 1 and for the robots with
+    max_dec != max_acc (the time loop is where max_dec acts, MPG:572-573), through the batched kernels with
+    the path placed between two others."""
     from vexautonomousplanner_amd.synth import make_waypoints
-    g = gu.load("c1_w8")
+    g = gu.load(name)
     others = make_waypoints(2, 8, 77).astype(np.float64)
     wp = np.concatenate([others[:1], g["waypoints"][None], others[1:]], axis=0)
-    tp, flags = _time_profile("f64", wp)
+    tp, flags = _time_profile("f64", wp, cons=[float(v) for v in g["constraints"]])
     assert not flags.any()
     T = len(g["profile_times"])
     assert int(tp["counts"][1, 0]) == T
