@@ -444,3 +444,58 @@ def test_time_profile_argument_errors(torch_mod):
     tp = gen.time_profile(res, DEFAULT_CONSTRAINTS, capacity_rows=2048)
     torch.cuda.synchronize()
     assert int(tp["counts"][:, 0].min().item()) > 10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_staged_api_equals_fused_call(torch_mod, dtype):
+    """vap_fit -> vap_build_lut -> vap_sample -> vap_velocity_pass -> vap_time_profile with caller-owned
+    buffers on a batch of 5 paths gives the fused vap_profile_batch (+ time_profile) results bit for bit."""
+    import ctypes as C
+    from vexautonomousplanner_amd import _lib
+    from vexautonomousplanner_amd.batch import BatchedTrajectoryGenerator
+    from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
+    torch = torch_mod
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    td = torch.float32 if dtype == "f32" else torch.float64
+    vd = _lib.VAP_F32 if dtype == "f32" else _lib.VAP_F64
+    B, W, S, cap_rows = 5, 8, 2000, 1024
+    wp = torch.tensor(make_waypoints(B, W, 41), device=dev, dtype=td)
+    gen = BatchedTrajectoryGenerator(0, dtype)
+    fused = gen.profile(wp, DEFAULT_CONSTRAINTS, samples=S)
+    fused_tp = gen.time_profile(fused, DEFAULT_CONSTRAINTS, capacity_rows=cap_rows)
+    torch.cuda.synchronize()
+
+    ctx = _lib.Context(0)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    c = _lib.make_constraints(DEFAULT_CONSTRAINTS)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    seg = torch.empty((B, W - 1, 6, 2), dtype=torch.float64, device=dev)
+    seglen = torch.empty((B, W - 1), dtype=torch.float64, device=dev)
+    meta = torch.zeros((B, 4), dtype=torch.float64, device=dev)
+    flags = torch.zeros((B,), dtype=torch.int32, device=dev)
+    lut = torch.empty((B, _lib.LUT_SAMPLES), dtype=torch.float64, device=dev)
+    out = {k: torch.empty((B, S), dtype=td, device=dev) for k in ("x", "y", "heading", "curvature", "dtheta", "velocity")}
+    _lib.check(L.vap_fit(ctx.handle, vd, B, W, p(wp), None, None, p(seg), p(seglen), p(meta), p(flags)), "vap_fit")
+    _lib.check(L.vap_build_lut(ctx.handle, B, W, p(seg), p(lut), p(meta), p(flags)), "vap_build_lut")
+    _lib.check(L.vap_sample(ctx.handle, vd, B, W, S, 0.0, p(seg), p(lut), p(meta), p(out["x"]), p(out["y"]), p(out["heading"]),
+                            p(out["curvature"]), p(out["dtheta"]), p(flags)), "vap_sample")
+    _lib.check(L.vap_velocity_pass(ctx.handle, vd, B, S, C.byref(c), 0.01, 0.01, p(meta), p(out["curvature"]), p(out["dtheta"]),
+                                   None, p(out["velocity"]), p(flags)), "vap_velocity_pass")
+    rows = torch.zeros((B, cap_rows, 8), dtype=torch.float64, device=dev)
+    counts = torch.zeros((B, 2), dtype=torch.int32, device=dev)
+    nmap = torch.zeros((B, W), dtype=torch.int32, device=dev)
+    _lib.check(L.vap_time_profile(ctx.handle, vd, B, W, S, p(seg), p(lut), p(meta), p(out["velocity"]), C.byref(c), 0.01, cap_rows,
+                                  p(rows), p(counts), p(nmap), p(flags)), "vap_time_profile")
+    torch.cuda.synchronize()
+    assert not flags.any().item()
+    for k in ("x", "y", "heading", "curvature", "velocity"):
+        assert torch.equal(out[k], fused[k]), k
+    assert torch.equal(meta, fused["meta"])
+    assert torch.equal(counts, fused_tp["counts"])
+    T = int(counts[:, 0].max().item())
+    assert torch.equal(rows[:, :T], fused_tp["rows"][:, :T]) or all(
+        torch.equal(rows[b, :int(counts[b, 0])], fused_tp["rows"][b, :int(counts[b, 0])]) for b in range(B))
+    for b in range(B):
+        assert torch.equal(nmap[b, :int(counts[b, 1])], fused_tp["nodes_map"][b, :int(counts[b, 1])])
