@@ -92,6 +92,7 @@ class BatchedTrajectoryGenerator:
                                        C.c_void_p(res["meta"].data_ptr()),
                                        C.c_void_p(res["flags"].data_ptr()))
         _lib.check(st, "vap_profile_batch")
+        self._last_shape = (B, W, S)
         return res
 
     def time_profile(self, result, constraints=DEFAULT_CONSTRAINTS, dt=0.01, capacity_rows=None, out=None):
@@ -108,7 +109,10 @@ class BatchedTrajectoryGenerator:
         """
         vel, meta = result["velocity"], result["meta"]
         B, S = vel.shape
-        W = int(round(float(meta[0, 0].item()))) + 1     # parameters[-1] = W - 1 (QHS:736)
+        last = getattr(self, "_last_shape", None)
+        if last is None or (last[0], last[2]) != (B, S):
+            raise ValueError("time_profile needs the result of this generator's last profile() call")
+        W = last[1]
         if capacity_rows is None:
             capacity_rows = 4096
         res = {} if out is None else out
