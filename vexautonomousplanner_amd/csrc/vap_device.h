@@ -448,8 +448,8 @@ __device__ __forceinline__ double opaque(double x) { asm volatile("" : "+v"(x));
 //        A   = base_p*r,  cap = (vmax*r)^2,  r = 1/(1 + tw*k/2)   (straight samples: A = base_p)
 //        rho = 0 on straight samples and on the first step of a sweep (MPG:190, 253: previous
 //              angular velocity 0).
-// A sample whose heading difference is zero has g clamped to kHuge; it is stored as gq = kHuge exactly
-// (ordinary samples are kept below kHuge/10), which the backward step reads as "sign-aware".
+// A sample whose heading difference is zero has g clamped to kHuge; it is stored as gq = -kHuge
+// (ordinary samples are kept in [0, kHuge/10]): the sign tells the backward step to be "sign-aware".
 template <typename R>
 __device__ __forceinline__ void fast_derive_k(const FastConsts<R> &c, R kabs, R kprev_abs, R base_p, R &rho, R &q,
                                               R &A, R &cap)
@@ -472,12 +472,14 @@ __device__ __forceinline__ void fast_derive_k(const FastConsts<R> &c, R kabs, R 
 template <typename R>
 __device__ __forceinline__ R fast_gg(const FastConsts<R> &c, R dth) { return vmin(c.gk * fast_rcp(dth), Huge<R>::v); }
 
-// q = k^2 of the same step (straight <=> q < 1e-12).  Branch-free: selects only.
+// q = k^2 of the same step (straight <=> q < 1e-12).  Branch-free: selects only.  A zero heading
+// difference (gg clamped to kHuge) is returned as -kHuge: the magnitude is what both sweeps multiply
+// by, the sign is the marker the backward sweep reads.
 template <typename R>
 __device__ __forceinline__ R fast_gq(R gg, R q)
 {
     R r = vmin(gg * q, Huge<R>::v * (R)0.1);
-    r = gg >= Huge<R>::v ? Huge<R>::v : r;
+    r = gg >= Huge<R>::v ? -Huge<R>::v : r;
     return q < (R)1e-12 ? (R)0 : r;
 }
 
@@ -512,20 +514,21 @@ __device__ __forceinline__ double vel_sqrt(double u) { return sqrt(u); }
 __device__ __forceinline__ float med3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
 __device__ __forceinline__ double med3(double a, double lo, double hi) { return fmin(fmax(a, lo), hi); }
 
-// Forward step, MPG:193-249.  A zero heading difference (gq = kHuge) gives the reference's
+// Forward step, MPG:193-249.  A zero heading difference (|gq| = kHuge) gives the reference's
 // dw == 0 -> A, dw != 0 -> 0 without a special case: t is exactly zero when the table entry and the
 // velocity are unchanged (rho = 1), and any other t times kHuge exceeds amaxp.
 template <typename R>
 __device__ __forceinline__ R fast_forward(const FastConsts<R> &c, R rho, R gq, R A, R cap, R u, R &uprev, R u_next)
 {
     const R t = fma(-rho, uprev, u);
-    const R y = fma(-fabs(t), gq, c.amaxp);
+    const R y = fma(-fabs(t), fabs(gq), c.amaxp);
     uprev = u;
     return vmin(vmin(u + med3(y, (R)0, A), cap), u_next);
 }
 
-// Backward step, MPG:255-311.  DUP = the path has samples with a zero heading difference: the
-// reference's signed +-inf handling there differs from the forward one (dw > 0 -> 0, dw <= 0 -> A).
+// Backward step, MPG:255-311.  DUP = the path has samples with a zero heading difference (gq < 0): the
+// reference's signed +-inf handling there differs from the forward one (dw > 0 -> 0, dw <= 0 -> A), i.e.
+// the penalty is max(t, 0)*kHuge where an ordinary sample has |t|*gq = max(t, -t)*gq.
 template <bool DUP, typename R>
 __device__ __forceinline__ R fast_backward(const FastConsts<R> &c, R rho, R gq, R A, R cap, R u, R &uprev, R u_prev)
 {
@@ -533,8 +536,8 @@ __device__ __forceinline__ R fast_backward(const FastConsts<R> &c, R rho, R gq, 
     R y;
     if constexpr (DUP) {
         gq = opaque(gq);   // keep the select below inside the round loop (one register per sample otherwise)
-        const R gn = gq >= Huge<R>::v ? (R)0 : gq;
-        y = c.amaxp - vmax_(t * gq, -t * gn);
+        const R other = gq < (R)0 ? (R)0 : -t;
+        y = fma(-vmax_(t, other), fabs(gq), c.amaxp);
     } else {
         y = fma(-fabs(t), gq, c.amaxp);
     }

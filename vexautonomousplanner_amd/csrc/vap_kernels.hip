@@ -520,7 +520,7 @@ __global__ __launch_bounds__(64) void k_velocity_seq(int B, int S, VelConsts<R> 
     if constexpr (FAST) {
         for (int i = 0; i < N - 1; i++) {
             const R kabs = (R)fabs(K[i]);
-            dup |= fast_gq(fast_gg(fc, DT[i]), kabs * kabs) >= Huge<R>::v;
+            dup |= fast_gq(fast_gg(fc, DT[i]), kabs * kabs) < (R)0;
         }
     }
     // forward, MPG:188-249
@@ -778,7 +778,7 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
             const bool valid = j >= 1 && j <= N - 1;
             const R gq = fast_gq(fast_gg(fc, dn[i]), g[s]);
             g[s] = opaque(valid ? gq : (R)0);
-            dup |= g[s] >= Huge<R>::v;
+            dup |= g[s] < (R)0;
             u[s] = start_u;
         }
     }
@@ -1013,7 +1013,7 @@ __global__ void k_dup_scan(int B, int S, VelConsts<R> c, const double *__restric
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N - 1; i += gridDim.x * blockDim.x) {
         const size_t o = (size_t)b * S + i;
         const R kabs = (R)fabs(curv[o]);
-        any |= fast_gq(fast_gg(fc, dth[o]), kabs * kabs) >= Huge<R>::v;   // the kernels' own predicate
+        any |= fast_gq(fast_gg(fc, dth[o]), kabs * kabs) < (R)0;   // the kernels' own predicate
     }
     if (__syncthreads_or(any ? 1 : 0) && threadIdx.x == 0) atomicOr(&dup[b], 1);
 }
@@ -1030,7 +1030,7 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_long(int S, int nsc, in
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     R *stage = reinterpret_cast<R *>(smem_raw);
-    __shared__ R s_u[2][MAXT + 2], s_w[2][MAXT + 2];
+    __shared__ BoundaryState<R> s_bs[2][MAXT / 64 + 2];   // states crossing a wavefront boundary
     __shared__ int s_any[3];
     constexpr int T = MAXT;
     constexpr int SC = T * L;
@@ -1146,40 +1146,59 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_long(int S, int nsc, in
     R out_u = in_u, out_w = in_w;
     int rounds = 0;
     __syncthreads();
+    // same round structure as k_velocity_relax: up to kInner evaluations per workgroup barrier, states
+    // handed lane to lane by DPP inside a wavefront, through LDS across wavefronts
+    constexpr int kInner = 8;
+    const int wv = tid >> 6, lane = tid & 63;
+    const bool in_wave_nb = BWD ? (lane < 63 && tid < T - 1 && (!bwd_has_end || tid < local_last)) : (lane > 0 && active);
+    const bool edge_nb = BWD ? (lane == 63 && tid < T - 1 && (!bwd_has_end || tid < local_last)) : (lane == 0 && tid > 0 && active);
+    int f_cur = 0, f_nxt = 1, f_prv = 2;
     while (true) {
-        if (need) {
-            R uu = in_u, wp = in_w;
-            if constexpr (!BWD) {
+#pragma unroll 1
+        for (int k = 0; k < kInner; k++) {
+            if (need) {
+                R uu = in_u, wp = in_w;
+                if constexpr (!BWD) {
 #pragma unroll
-                for (int s = 0; s < L; s++) {
-                    if (s == 0 && tid == 0 && base == 0) continue;   // sample 0 is the given start velocity
-                    uu = fast_forward(fc, q[s], g[s], A[s], cp[s], uu, wp, Huge<R>::v);
-                    u[s] = uu;
+                    for (int s = 0; s < L; s++) {
+                        if (s == 0 && tid == 0 && base == 0) continue;   // sample 0 is the given start velocity
+                        uu = fast_forward(fc, q[s], g[s], A[s], cp[s], uu, wp, Huge<R>::v);
+                        u[s] = uu;
+                    }
+                } else if (any_dup) {
+#pragma unroll
+                    for (int s = L - 1; s >= 0; s--) uu = fast_backward<true>(fc, q[s], g[s], A[s], cp[s], uu, wp, u[s]);
+                } else {
+#pragma unroll
+                    for (int s = L - 1; s >= 0; s--) uu = fast_backward<false>(fc, q[s], g[s], A[s], cp[s], uu, wp, u[s]);
                 }
-            } else {
-#pragma unroll
-                for (int s = L - 1; s >= 0; s--)
-                    uu = any_dup ? fast_backward<true>(fc, q[s], g[s], A[s], cp[s], uu, wp, u[s])
-                                 : fast_backward<false>(fc, q[s], g[s], A[s], cp[s], uu, wp, u[s]);
+                out_u = uu;
+                out_w = wp;
             }
-            out_u = uu;
-            out_w = wp;
+            const R nu = BWD ? wave_shift_down(out_u) : wave_shift_up(out_u);
+            const R nw = BWD ? wave_shift_down(out_w) : wave_shift_up(out_w);
+            need = false;
+            if (in_wave_nb) {
+                need = !(same_bits(nu, in_u) && same_bits(nw, in_w));
+                in_u = nu;
+                in_w = nw;
+            }
+            if (__ballot(need) == 0) break;
         }
         const int pb = rounds & 1;
-        s_u[pb][tid + (BWD ? 0 : 1)] = out_u;
-        s_w[pb][tid + (BWD ? 0 : 1)] = out_w;
-        if (tid == 0) s_any[(rounds + 1) % 3] = 0;
+        if (lane == (BWD ? 0 : 63)) s_bs[pb][wv + (BWD ? 0 : 1)] = BoundaryState<R>{out_u, out_w};
+        if (tid == 0) s_any[f_nxt] = 0;
         __syncthreads();
-        if (rounds > 0 && s_any[(rounds - 1) % 3] == 0) break;
-        need = false;
-        const bool has_nb = BWD ? (tid < T - 1 && (!bwd_has_end || tid < local_last)) : (tid > 0 && active);
-        if (has_nb) {
-            const R nu = s_u[pb][BWD ? tid + 1 : tid], nw = s_w[pb][BWD ? tid + 1 : tid];
-            need = !(same_bits(nu, in_u) && same_bits(nw, in_w));
-            in_u = nu;
-            in_w = nw;
+        const int changed_last = s_any[f_prv];
+        const BoundaryState<R> nb = s_bs[pb][wv + (BWD ? 1 : 0)];
+        if (rounds > 0 && changed_last == 0) break;
+        if (edge_nb) {
+            need = !(same_bits(nb.u, in_u) && same_bits(nb.w, in_w));
+            in_u = nb.u;
+            in_w = nb.w;
         }
-        if (need) s_any[rounds % 3] = 1;
+        if (need) s_any[f_cur] = 1;
+        { const int t = f_prv; f_prv = f_cur; f_cur = f_nxt; f_nxt = t; }
         rounds++;
         if (rounds > 2 * T + 8) {
             if (tid == 0 && flags) atomicOr(&flags[b], VAP_FLAG_NOCONVERGE_BIT);
@@ -1189,19 +1208,20 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_long(int S, int nsc, in
     if constexpr (BWD) {
         if (active) {
             R uu = in_u, wp = in_w;
+            if (any_dup) {
 #pragma unroll
-            for (int s = L - 1; s >= 0; s--) {
-                uu = any_dup ? fast_backward<true>(fc, q[s], g[s], A[s], cp[s], uu, wp, u[s])
-                             : fast_backward<false>(fc, q[s], g[s], A[s], cp[s], uu, wp, u[s]);
-                u[s] = uu;
+                for (int s = L - 1; s >= 0; s--) u[s] = uu = fast_backward<true>(fc, q[s], g[s], A[s], cp[s], uu, wp, u[s]);
+            } else {
+#pragma unroll
+                for (int s = L - 1; s >= 0; s--) u[s] = uu = fast_backward<false>(fc, q[s], g[s], A[s], cp[s], uu, wp, u[s]);
             }
         }
     }
-    // publish the super-chunk's outgoing interface state
-    const int pbl = (rounds) & 1;   // parity of the last published buffer
+    // publish the super-chunk's outgoing interface state: the out-state of its last (forward) / first
+    // (backward) chunk, which that thread holds
     const int owner = BWD ? 0 : T - 1;
     if (tid == owner) {
-        const R ou = BWD ? out_u : s_u[pbl][T], ow = BWD ? out_w : s_w[pbl][T];
+        const R ou = out_u, ow = out_w;
         const bool diff = !seq && (round == 0 || !(same_bits(ou, bnd_prev[if_out * 2]) && same_bits(ow, bnd_prev[if_out * 2 + 1])));
         bnd_cur[if_out * 2] = ou;
         bnd_cur[if_out * 2 + 1] = ow;
@@ -1491,23 +1511,30 @@ static hipError_t velocity_long_t(hipStream_t st, int B, int S, const double c[6
     if ((err = hipMemsetAsync(counters, 0, sizeof(int) * ((size_t)B + 2 * (nsc + 2)), st)) != hipSuccess) return err;
     hipLaunchKernelGGL(k_dup_scan<R>, dim3(64, B), dim3(256), 0, st, B, S, make_consts<R>(c), meta, (const R *)curv,
                        (const R *)dth, dup);
+    // Super-round convergence is decided on the host, one 4-byte read per check — but a super-round in
+    // which nothing changes costs a few microseconds (every workgroup returns at once), a host round trip
+    // ~35: rounds are launched three at a time and only the last one's counter is read.
+    constexpr int kRoundsPerCheck = 3;
     for (int dir = 0; dir < 2; dir++) {
-        for (int round = 0; round <= nsc + 1; round++) {
-            int *ch = changed + dir * (nsc + 2) + round;
-            if (dir == 0)
-                hipLaunchKernelGGL((k_velocity_long<R, L, MAXT, MINW, false>), dim3(nsc, B), dim3(MAXT), lds, st, S, nsc,
-                                   round, -1, make_consts<R>(c), s * s, e * e, meta, (const R *)curv, (const R *)dth,
-                                   (R *)ufwd, (R *)vel, bnd, used, outst, dup, ch, flags);
-            else
-                hipLaunchKernelGGL((k_velocity_long<R, L, MAXT, MINW, true>), dim3(nsc, B), dim3(MAXT), lds, st, S, nsc,
-                                   round, -1, make_consts<R>(c), s * s, e * e, meta, (const R *)curv, (const R *)dth,
-                                   (R *)ufwd, (R *)vel, bnd, used, outst, dup, ch, flags);
-            if ((err = hipGetLastError()) != hipSuccess) return err;
-            // super-round convergence is decided on the host: one 4-byte read per super-round
+        int round = 0;
+        while (round <= nsc + 1) {
+            int *ch = nullptr;
+            for (int k = 0; k < kRoundsPerCheck && round <= nsc + 1; k++, round++) {
+                ch = changed + dir * (nsc + 2) + round;
+                if (dir == 0)
+                    hipLaunchKernelGGL((k_velocity_long<R, L, MAXT, MINW, false>), dim3(nsc, B), dim3(MAXT), lds, st, S, nsc,
+                                       round, -1, make_consts<R>(c), s * s, e * e, meta, (const R *)curv, (const R *)dth,
+                                       (R *)ufwd, (R *)vel, bnd, used, outst, dup, ch, flags);
+                else
+                    hipLaunchKernelGGL((k_velocity_long<R, L, MAXT, MINW, true>), dim3(nsc, B), dim3(MAXT), lds, st, S, nsc,
+                                       round, -1, make_consts<R>(c), s * s, e * e, meta, (const R *)curv, (const R *)dth,
+                                       (R *)ufwd, (R *)vel, bnd, used, outst, dup, ch, flags);
+                if ((err = hipGetLastError()) != hipSuccess) return err;
+            }
             int h = 0;
             if ((err = hipMemcpyAsync(&h, ch, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return err;
             if ((err = hipStreamSynchronize(st)) != hipSuccess) return err;
-            if (round > 0 && h == 0) break;
+            if (h == 0) break;   // round >= 1 here: the last launched round saw no interface change
         }
     }
     return hipSuccess;
@@ -1515,13 +1542,13 @@ static hipError_t velocity_long_t(hipStream_t st, int B, int S, const double c[6
 
 size_t velocity_long_state_bytes(bool f64, int B, int S)
 {
-    const int SC = f64 ? 512 * 16 : 256 * 40;
+    const int SC = f64 ? 512 * 16 : 64 * 40;   // the smallest super-chunk launch_velocity_long may pick
     const int nsc = (S + SC - 1) / SC;
     return (f64 ? 8 : 4) * ((size_t)2 * B * (nsc + 1) * 2 + (size_t)2 * B * nsc * 2) + 64;
 }
 size_t velocity_long_counter_bytes(bool f64, int B, int S)
 {
-    const int SC = f64 ? 512 * 16 : 256 * 40;
+    const int SC = f64 ? 512 * 16 : 64 * 40;
     const int nsc = (S + SC - 1) / SC;
     return sizeof(int) * ((size_t)B + 2 * (nsc + 2)) + 64;
 }
@@ -1531,6 +1558,13 @@ hipError_t launch_velocity_long(hipStream_t st, bool f64, int B, int S, const do
                                 void *ufwd, void *state, int *counters)
 {
     if (f64) return velocity_long_t<double, 16, 512, 2>(st, B, S, c, sv, ev, meta, curv, dth, vel, flags, ufwd, state, counters);
+    // super-chunk = 256 or 64 threads x 40 samples: few long rows (config 2: one) are cut finer so that the
+    // chip has more workgroups to run and a super-round is shorter
+    static const char *cfg = getenv("VAP_LONG_T");   // developer knob (tuning only): 64 or 256
+    const int forced = cfg ? atoi(cfg) : 0;
+    const long blocks256 = (long)B * ((S + 256 * 40 - 1) / (256 * 40));
+    if (forced == 64 || (forced != 256 && blocks256 < 512))
+        return velocity_long_t<float, 40, 64, 2>(st, B, S, c, sv, ev, meta, curv, dth, vel, flags, ufwd, state, counters);
     return velocity_long_t<float, 40, 256, 2>(st, B, S, c, sv, ev, meta, curv, dth, vel, flags, ufwd, state, counters);
 }
 
