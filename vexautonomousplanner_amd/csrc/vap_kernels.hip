@@ -561,16 +561,18 @@ __global__ __launch_bounds__(64) void k_velocity_seq(int B, int S, VelConsts<R> 
 
 // ------------------------------------------------------------------------------------------------
 // K5b: velocity pass by speculative chunk relaxation.  One workgroup per path; thread c owns the L
-// consecutive samples [c*L, c*L+L) and keeps their step coefficients and squared velocities in
-// registers.  The recurrence is sequential only through the 2-word state (u_i, w_{i-1}) that
-// crosses a chunk boundary, so every round each thread whose incoming state changed re-runs its L
-// steps from that state and publishes its outgoing state; a thread whose incoming state is
-// bit-identical to the one it last used is already final.  Chunk 0's incoming state is exact, so by
-// induction chunk c is exact after at most c+1 rounds, and the fixed point (no state changed) is
-// bit-identical to the sequential sweep — in practice the velocity rides its curvature cap often
-// enough that ~10-100 rounds suffice for 10^4 samples.
-// LDS: two words per thread for the boundary states.  No HBM traffic besides one read of
-// (curvature, dtheta) per sweep direction and the final velocity store.
+// consecutive samples [c*L, c*L+L) and keeps their step coefficients (rho, g*k^2, A, cap — vap_device.h)
+// and squared velocities in registers.  The recurrence is sequential only through the 2-word state
+// (u_i, u_{i-1}) that crosses a chunk boundary, so a thread whose incoming state changed re-runs its L
+// steps from that state and hands its outgoing state on; a thread whose incoming state is bit-identical
+// to the one it last used is already final.  Chunk 0's incoming state is exact, so by induction chunk c
+// is exact after at most c+1 evaluations, and the fixed point (no state changed) is bit-identical to
+// the sequential sweep.  Two trajectories started from different states merge (bitwise) after ~240
+// samples on average, so config 3 needs ~29 + 23 evaluations by the busiest wavefront, not 250
+// (DESIGN.md §5, K5).
+// States move lane to lane by DPP inside a wavefront and through a 2-word LDS record per wavefront
+// across wavefronts, one workgroup barrier per 8 evaluations.  HBM traffic: one read of (curvature,
+// dtheta) per sweep direction and the final velocity store.
 // ------------------------------------------------------------------------------------------------
 template <typename R> struct BitsOf;
 template <> struct BitsOf<float> { using type = uint32_t; };
