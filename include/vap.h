@@ -123,8 +123,11 @@ int vap_build_lut(vap_ctx *ctx, int B, int W, const double *d_segments, double *
  * with SM:291-318 distance_to_time, SM:477-580 (the curvature/heading table entry the reference's
  * step lookup selects, evaluated on demand — the 1000*W table is never materialised) and
  * SM:204-215 get_point_at_parameter.
- *   dd > 0 : reference grid, s_k = k*dd while s_k < L, plus the end sample; n_samples varies
- *   dd <= 0: fixed grid of exactly S samples, dd_b = L_b / (S - 1.5)
+ *   dd > 0 : reference grid: s_0 = 0, s_k = fl(s_(k-1) + dd) while s_k < L (the reference's
+ *            accumulated current_dist += dd, rounding included), plus the end sample; n_samples varies
+ *   dd <= 0: fixed grid of exactly S samples, the same accumulation with dd_b = L_b / (S - 1.5)
+ * The accumulated sum is reproduced in closed form (per binade the rounded increment is a constant
+ * number of ulps), so sample k needs no scan over its predecessors: vap_grid_distances shows it.
  * Writes meta[2], meta[3]; d_dtheta [B][S] (dtype) receives |heading[k+1]-heading[k]| for the
  * velocity pass (scratch; may be NULL only if the velocity pass is not wanted). */
 int vap_sample(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd, const double *d_segments,
@@ -232,6 +235,11 @@ int vap_route_eval(vap_route *route, int order, int n, const double *h_t, double
 int vap_route_lookup(vap_route *route, int what, int n, const double *h_in, double *h_out);
 /* Samples forward_backward_pass produces for spacing dd (MPG:112-122, 172-175). */
 int vap_route_sample_count(vap_route *route, double dd, int *n_out);
+/* Host only, no device needed: the distance grid of MPG:112-122 for a path of length total_length
+ * from the closed form the kernels use (csrc/vap_device.h build_grid_runs / grid_s).  Writes
+ * s_k for k < min(*n_out, capacity) into h_s (may be NULL) and the loop count — the number of k with
+ * s_k < total_length, i.e. n_samples - 1 — into *n_out.  Bit-identical to the reference's running sum. */
+int vap_grid_distances(double dd, double total_length, long capacity, double *h_s, long *n_out);
 /* MPG:70-316 with node / action-point limits (MPG:100-163) and boundary_map (MPG:194-196, 256-257).
  * Outputs (capacity each, any may be NULL): parameter t, x, y, heading, curvature, velocity. */
 int vap_route_forward_backward(vap_route *route, const vap_constraints *c, double dd, double start_vel,

@@ -106,6 +106,43 @@ def test_constraints_helpers_match_reference_formulas():
     assert get_wheel_trajectory([2.0], [1.0], c.track_width) == ([l], [r])
 
 
+def test_distance_grid_closed_form_equals_running_sum():
+    """MPG:112-122: the reference's grid is the running sum current_dist += dd, rounding included.  The
+    kernels take sample k from a closed form (csrc/vap_device.h build_grid_runs); vap_grid_distances
+    exposes that form on the host and must agree with the plain sum bit for bit, count included."""
+    L = _lib.lib()
+    rng = np.random.default_rng(5)
+    cases = [(0.005, 31.7), (0.005, 0.004), (0.005, 0.005), (2.0 ** -7, 9.0), (3 * 2.0 ** -9, 17.25), (0.7, 0.3)]
+    for _ in range(120):
+        mode = rng.integers(0, 4)
+        if mode == 0:
+            cases.append((float(rng.uniform(0.001, 0.02)), float(rng.uniform(0.5, 400.0))))
+        elif mode == 1:     # dyadic spacings: the rounding ties
+            cases.append((float(2.0 ** -int(rng.integers(3, 13)) * int(rng.integers(1, 8))), float(rng.uniform(1.0, 200.0))))
+        elif mode == 2:     # this build's fixed-S spacing
+            total = float(rng.uniform(5.0, 2000.0))
+            cases.append((total / (int(rng.integers(1000, 100000)) - 1.5), total))
+        else:               # spacing above the path length
+            cases.append((float(rng.uniform(0.3, 1.3)), float(rng.uniform(0.2, 10.0))))
+    for dd, total in cases:
+        want = []
+        s = 0.0
+        while s < total:
+            want.append(s)
+            s += dd
+        want = np.array(want)
+        got = np.full(len(want) + 4, -1.0)
+        n = ctypes.c_long(0)
+        rc = L.vap_grid_distances(dd, total, len(got), got.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), ctypes.byref(n))
+        assert rc == 0 and n.value == len(want), (dd, total, n.value, len(want))
+        assert np.array_equal(got[:n.value], want), (dd, total)
+        assert np.all(got[n.value:] == -1.0)
+    n = ctypes.c_long(0)
+    assert L.vap_grid_distances(0.0, 1.0, 0, None, ctypes.byref(n)) != 0
+    assert L.vap_grid_distances(0.01, float("inf"), 0, None, ctypes.byref(n)) != 0
+    assert L.vap_grid_distances(0.01, 2.0, 0, None, ctypes.byref(n)) == 0 and n.value == 200
+
+
 def test_turn_profile_matches_oracle_time_domain_rows():
     """motion_profile_angle + generate_trapezoidal_profile against the turn rows of the reference's
     own output (feat_turn golden: the samples inserted at node 4, MPG:487-507)."""

@@ -19,6 +19,8 @@ from vexautonomousplanner_amd.batch import BatchedTrajectoryGenerator
 from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+# waypoint counts: the default set, or "big" = past the LDS-resident coefficient limit (112 segments) up to the maximum
+WS = [113, 114, 200, 513, 1000, 2048] if len(sys.argv) > 2 and sys.argv[2] == "big" else [2, 3, 4, 5, 8, 13, 32, 57]
 rng = np.random.default_rng(20260101)
 gens = {"f32": BatchedTrajectoryGenerator(0, "f32"), "f64": BatchedTrajectoryGenerator(0, "f64")}
 tol = {"f32": 1e-5, "f64": 1e-9}
@@ -27,7 +29,7 @@ fails = 0
 t0 = time.time()
 n_cases = 0
 while time.time() - t0 < budget:
-    W = int(rng.choice([2, 3, 4, 5, 8, 13, 32, 57]))
+    W = int(rng.choice(WS))
     S = int(rng.choice([2, 3, 7, 64, 255, 256, 257, 1000, 1024, 1025, 4096, 4097, 10000, 20480, 20481, 30000]))
     B = int(rng.integers(1, 9)) if S <= 10000 else int(rng.integers(1, 3))
     seed = int(rng.integers(0, 1 << 30))

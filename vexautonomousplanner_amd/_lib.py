@@ -38,6 +38,7 @@ EXPORTS = (
     "vap_time_profile", "vap_profile_batch", "vap_profile_batch_host", "vap_eval_host", "vap_lookup_host",
     "vap_route_create", "vap_route_destroy", "vap_route_info", "vap_route_get_splines", "vap_route_eval",
     "vap_route_lookup", "vap_route_sample_count", "vap_route_forward_backward", "vap_route_motion_profile",
+    "vap_grid_distances",
 )
 
 
@@ -121,6 +122,7 @@ def lib():
     L.vap_route_eval.argtypes = [vp, C.c_int, C.c_int, dp, dp]
     L.vap_route_lookup.argtypes = [vp, C.c_int, C.c_int, dp, dp]
     L.vap_route_sample_count.argtypes = [vp, C.c_double, ip]
+    L.vap_grid_distances.argtypes = [C.c_double, C.c_double, C.c_long, dp, C.POINTER(C.c_long)]
     L.vap_route_forward_backward.argtypes = [vp, C.POINTER(Constraints), C.c_double, C.c_double, C.c_double,
                                              C.c_int, ip, dp, dp, dp, dp, dp, dp]
     L.vap_route_motion_profile.argtypes = [vp, C.POINTER(Constraints), C.c_double, C.c_double, C.c_long, dp, lp,

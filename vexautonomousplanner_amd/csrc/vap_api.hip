@@ -157,7 +157,7 @@ int vap_ctx_destroy(vap_ctx *ctx)
     if (!ctx) return VAP_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    VapBuffer *bufs[] = {&ctx->ufwd, &ctx->lstate, &ctx->lcount, &ctx->seg, &ctx->power, &ctx->lut, &ctx->slopes, &ctx->aux, &ctx->meta, &ctx->dth, &ctx->flags, &ctx->small_in,
+    VapBuffer *bufs[] = {&ctx->ufwd, &ctx->lstate, &ctx->lcount, &ctx->seg, &ctx->power, &ctx->lut, &ctx->slopes, &ctx->aux, &ctx->runs, &ctx->meta, &ctx->dth, &ctx->flags, &ctx->small_in,
                       &ctx->small_out, &ctx->small_seg, &ctx->small_lut};
     for (VapBuffer *b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
@@ -252,12 +252,13 @@ int vap_sample(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd, const
     VAP_TRY(ctx->ensure(ctx->power, n_seg * vap::kCoefBlockDoubles * sizeof(double)));
     VAP_TRY(ctx->ensure(ctx->slopes, (size_t)B * VAP_LUT_SAMPLES * sizeof(double)));
     VAP_TRY(ctx->ensure(ctx->aux, (size_t)B * 4 * sizeof(double)));
+    VAP_TRY(ctx->ensure(ctx->runs, (size_t)B * vap::kGridRunBlockDoubles * sizeof(double)));
     HIP_TRY(vap::launch_power(ctx->stream, (int)n_seg, d_segments, (double *)ctx->power.ptr));
     HIP_TRY(vap::launch_lut_slopes(ctx->stream, B, d_lut, d_meta, (double *)ctx->slopes.ptr));
-    HIP_TRY(vap::launch_grid(ctx->stream, B, W, S, dd, d_meta, (double *)ctx->aux.ptr, d_flags));
+    HIP_TRY(vap::launch_grid(ctx->stream, B, W, S, dd, d_meta, (double *)ctx->aux.ptr, (double *)ctx->runs.ptr, d_flags));
     HIP_TRY(vap::launch_sample(ctx->stream, dt == VAP_F64, B, W, S, (const double *)ctx->power.ptr, d_lut,
-                               (const double *)ctx->slopes.ptr, d_meta, (const double *)ctx->aux.ptr, d_x, d_y,
-                               d_heading, d_curvature, d_dtheta));
+                               (const double *)ctx->slopes.ptr, d_meta, (const double *)ctx->aux.ptr,
+                               (const double *)ctx->runs.ptr, d_x, d_y, d_heading, d_curvature, d_dtheta));
     return VAP_OK;
 }
 
@@ -292,6 +293,7 @@ int vap_profile_batch(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd
     VAP_TRY(ctx->ensure(ctx->lut, (size_t)B * VAP_LUT_SAMPLES * sizeof(double)));
     VAP_TRY(ctx->ensure(ctx->slopes, (size_t)B * VAP_LUT_SAMPLES * sizeof(double)));
     VAP_TRY(ctx->ensure(ctx->aux, (size_t)B * 4 * sizeof(double)));
+    VAP_TRY(ctx->ensure(ctx->runs, (size_t)B * vap::kGridRunBlockDoubles * sizeof(double)));
     VAP_TRY(ctx->ensure(ctx->dth, n_pts * esz(dt)));
     double *meta = d_meta;
     if (!meta) {
@@ -319,11 +321,12 @@ int vap_profile_batch(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd
     tm.mark(VAP_T_FIT);
     HIP_TRY(vap::launch_lut(ctx->stream, B, W, (const double *)ctx->seg.ptr, (double *)ctx->lut.ptr,
                             (double *)ctx->slopes.ptr, meta, flags));
-    HIP_TRY(vap::launch_grid(ctx->stream, B, W, S, dd, meta, (double *)ctx->aux.ptr, flags));
+    HIP_TRY(vap::launch_grid(ctx->stream, B, W, S, dd, meta, (double *)ctx->aux.ptr, (double *)ctx->runs.ptr, flags));
     tm.mark(VAP_T_LUT);
     HIP_TRY(vap::launch_sample(ctx->stream, f64, B, W, S, (const double *)ctx->power.ptr,
                                (const double *)ctx->lut.ptr, (const double *)ctx->slopes.ptr, meta,
-                               (const double *)ctx->aux.ptr, d_x, d_y, d_heading, curv, ctx->dth.ptr));
+                               (const double *)ctx->aux.ptr, (const double *)ctx->runs.ptr, d_x, d_y, d_heading, curv,
+                               ctx->dth.ptr));
     tm.mark(VAP_T_SAMPLE);
     VAP_TRY(run_velocity(ctx, f64, B, S, cc, start_vel, end_vel, meta, curv, ctx->dth.ptr, nullptr, d_velocity,
                          flags));

@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 namespace vap {
 
@@ -563,6 +564,130 @@ __device__ __forceinline__ void lds_fill(double *__restrict__ dst, const double 
             if (i < n) dst[i] = v[it];
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The distance grid of forward_backward_pass (MPG:112-122): the reference ACCUMULATES,
+//     current_dist = 0;  while current_dist < total: ...; current_dist += delta_dist
+// so sample k sits at s_k = fl(s_{k-1} + dd), which is not fl(k*dd): the two drift apart by up to
+// k*ulp(s)/2, enough to move a sample across a table-entry boundary now and then (~3e-7 of the samples
+// at 10^4 samples per path, more on long rows).  The sum has a closed form inside a binade
+// [2^e, 2^(e+1)): every s there is a multiple of ulp_e = 2^(e-52), so fl(s + dd) = s + m*ulp_e with
+// m = round(dd/ulp_e) — constant from the second element of the binade on (a tie rounds to even; the
+// first result is even, after which the choice no longer depends on s).  A path's grid is therefore at
+// most two arithmetic runs per binade; GridRuns lists them and grid_s() evaluates s_k exactly:
+//   run r covers k in [k0[r], k0[r+1]):  s_k = s0[r] + (k - k0[r]) * D[r]     (exact in fp64)
+// ------------------------------------------------------------------------------------------------
+constexpr int kMaxGridRuns = 96;   // two per binade from dd to the path length: 2^-25 ft steps on a 2^22 ft path
+constexpr int kGridRunStride = kMaxGridRuns + 4;      // + end markers, so a reader may load three entries ahead
+constexpr int kGridRunDoubles = 3 * kGridRunStride;   // per path: 100 entries of {k0 (int64 bits), s0, D}
+
+__host__ __device__ inline long grid_run_k0(const double *tab, int r)
+{
+    long v;
+    __builtin_memcpy(&v, tab + 3 * r, sizeof v);
+    return v;
+}
+__host__ __device__ inline void grid_run_set_k0(double *tab, int r, long k) { __builtin_memcpy(tab + 3 * r, &k, sizeof k); }
+
+// Builds the runs for indices 0 .. k_limit (inclusive) or until s_k >= total, whichever comes first, into
+// tab (kGridRunStride entries of {first index k0 — an int64 stored in the double's bits —, its distance s0,
+// increment D}) and returns the number of indices k with s_k < total among
+// those built (the reference's loop count; the appended end sample is not included).  dd > 0, total > 0.
+__host__ __device__ inline long build_grid_runs(double dd, double total, long k_limit, double *__restrict__ tab,
+                                                int &n_runs)
+{
+    int R = 0;
+    long k = 0;
+    double s = 0.0;
+    long n_below = 0;            // indices with s_k < total found so far
+    auto emit = [&](long kk, double ss, double dd_run) {
+        grid_run_set_k0(tab, R, kk);
+        tab[3 * R + 1] = ss;
+        tab[3 * R + 2] = dd_run;
+        R++;
+    };
+    // k = 0: s = 0, then s_1 = fl(0 + dd) = dd
+    emit(0, 0.0, dd);
+    n_below = 1;                 // s_0 = 0 < total
+    k = 1;
+    s = dd;
+    while (k <= k_limit && s < total && R < kMaxGridRuns - 2) {
+        const int e = ilogb(s);                           // s in [2^e, 2^(e+1))
+        const double top = ldexp(1.0, e + 1), ulp = ldexp(1.0, e - 52);
+        const double s1 = s + dd;                         // hardware rounding, whichever binade it lands in
+        emit(k, s, s1 - s);                               // the binade's first element: a run of one
+        n_below = k + 1;
+        if (s1 >= top) {                                  // the next element already left the binade:
+            emit(k + 1, s1, 0.0);                         // an empty second run keeps two runs per binade
+            k += 1;
+            s = s1;
+            continue;
+        }
+        // constant increment from s1 on
+        const double x = ldexp(dd, 52 - e);                // dd / ulp, exact (power-of-two scaling)
+        const double f = floor(x), fr = x - f;
+        double m = f;
+        if (fr > 0.5 || (fr == 0.5 && fmod(f, 2.0) != 0.0)) m = f + 1.0;
+        const double Dc = m * ulp;
+        // elements s1 + j*Dc, j = 0..J, stay below top: J = floor(((top - s1)/ulp - 1) / m)
+        double J = 0.0;
+        if (m > 0.0) {
+            const double a = ldexp(top - s1, 52 - e) - 1.0; // (top - s1) / ulp - 1: integer-valued, exact
+            J = floor(a / m);
+            while ((J + 1.0) * m <= a) J += 1.0;
+            while (J > 0.0 && J * m > a) J -= 1.0;
+        } else {
+            J = (double)(k_limit - k);                    // dd below half an ulp: s no longer moves
+        }
+        long Jl = (J > 4.0e15) ? (long)4e15 : (long)J;
+        if (k + 1 + Jl > k_limit) Jl = k_limit - (k + 1) < 0 ? 0 : k_limit - (k + 1);
+        emit(k + 1, s1, Dc);
+        if (s1 < total) {
+            // run elements below total: the first j with s1 + j*Dc >= total ends the grid
+            long jt = Jl;
+            if (Dc > 0.0) {
+                double q = floor((total - s1) / Dc);
+                while (s1 + q * Dc < total) q += 1.0;
+                while (q > 0.0 && s1 + (q - 1.0) * Dc >= total) q -= 1.0;
+                if (q - 1.0 < (double)jt) jt = (long)(q - 1.0);
+            }
+            n_below = k + 1 + jt + 1;
+            if (jt < Jl) break;                           // the grid ends inside this run
+        } else {
+            break;
+        }
+        const double s_last = s1 + (double)Jl * Dc;       // exact
+        k = k + 1 + Jl + 1;
+        s = s_last + dd;                                  // crossing step: hardware rounding in the next binade
+    }
+    for (int j = 0; j < 4; j++) {                         // the last run extends as far as anyone asks
+        grid_run_set_k0(tab, R + j, k_limit + 2);
+        tab[3 * (R + j) + 1] = 0.0;
+        tab[3 * (R + j) + 2] = 0.0;
+    }
+    n_runs = R;
+    return n_below;
+}
+
+// s_k from the runs (k within what build_grid_runs covered); r is a hint / cursor: the run of the previous
+// lookup, moved forward or back as needed.
+__host__ __device__ inline double grid_s(const double *__restrict__ tab, int n_runs, long k, int &r)
+{
+    while (r + 1 < n_runs && k >= grid_run_k0(tab, r + 1)) r++;
+    while (r > 0 && k < grid_run_k0(tab, r)) r--;
+    return tab[3 * r + 1] + (double)(k - grid_run_k0(tab, r)) * tab[3 * r + 2];
+}
+
+// First guess of the run that holds sample k: run 0 is k = 0 and binade i above dd's (i = 0, 1, ...)
+// owns runs 1 + 2i (its first element) and 2 + 2i (the arithmetic rest), so the exponent of k*dd lands
+// within a run or two of the right one; grid_s() walks the rest.
+__host__ __device__ inline int grid_run_hint(double dd, long k, int n_runs)
+{
+    if (k <= 0) return 0;
+    int r = 2 + 2 * (ilogb((double)k * dd) - ilogb(dd));
+    r = r < 1 ? 1 : r;
+    return r > n_runs - 1 ? n_runs - 1 : r;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -37,7 +37,7 @@ struct vap_ctx {
     hipEvent_t ev[VAP_T_COUNT + 1] = {};
     float ms[VAP_T_COUNT] = {};
     // scratch arena (grow-only, reused across calls)
-    VapBuffer seg, power, lut, slopes, aux, meta, dth, flags, io[8], small_in, small_out, small_seg, small_lut;
+    VapBuffer seg, power, lut, slopes, aux, runs, meta, dth, flags, io[8], small_in, small_out, small_seg, small_lut;
     VapBuffer ufwd, lstate, lcount;   // long-row velocity pass
     int last_B = 0, last_W = 0;       // shape of the tables the last vap_profile_batch left in seg / lut
 

@@ -14,6 +14,7 @@ constexpr int kSPT = 4;                                   // consecutive samples
 constexpr int kSampleChunk = kSampleThreads * kSPT;       // samples evaluated per workgroup
 constexpr int kSampleTile = kSampleChunk - kSPT;          // samples written: the last thread only feeds its neighbour
 constexpr int kCoefBlockDoubles = 36;                      // doubles per segment coefficient block (scratch sizing)
+constexpr int kGridRunBlockDoubles = 3 * 100;            // distance-grid runs per path: 100 entries of {k0, s0, D} (vap_device.h)
 constexpr int kLdsCoefSegments = 112;                     // segments whose coefficient blocks are staged in LDS
 constexpr int kMaxWaypoints = 2048;              // k_fit LDS: 7*W doubles
 
@@ -22,10 +23,11 @@ hipError_t launch_fit(hipStream_t st, bool f64, int B, int W, const void *wp, co
 hipError_t launch_lut(hipStream_t st, int B, int W, const double *seg, double *lut, double *slopes, double *meta,
                       uint32_t *flags);
 hipError_t launch_lut_slopes(hipStream_t st, int B, const double *lut, const double *meta, double *slopes);
-hipError_t launch_grid(hipStream_t st, int B, int W, int S, double dd, double *meta, double *aux, uint32_t *flags);
+hipError_t launch_grid(hipStream_t st, int B, int W, int S, double dd, double *meta, double *aux, double *runs,
+                       uint32_t *flags);
 hipError_t launch_sample(hipStream_t st, bool f64, int B, int W, int S, const double *pw, const double *lut,
-                         const double *slopes, const double *meta, const double *aux, void *x, void *y, void *h,
-                         void *k, void *dth);
+                         const double *slopes, const double *meta, const double *aux, const double *runs, void *x,
+                         void *y, void *h, void *k, void *dth);
 hipError_t launch_velocity_seq(hipStream_t st, bool f64, bool fast, int B, int S, const double c[6], double sv,
                                double ev, const double *meta, const void *curv, const void *dth, const void *vcap,
                                void *vel);

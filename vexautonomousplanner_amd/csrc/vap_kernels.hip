@@ -19,6 +19,7 @@
 namespace vap {
 
 static_assert(kCoefBlockDoubles == kCoefDoubles, "scratch sizing and block layout disagree");
+static_assert(kGridRunBlockDoubles == kGridRunDoubles, "scratch sizing and run-table layout disagree");
 
 // ------------------------------------------------------------------------------------------------
 // K1: fit.  One workgroup per path.  QHS:30-138, 149-219, 719-736; SM:65-77 tangent overrides.
@@ -263,28 +264,40 @@ __global__ void k_lut_slopes(int B, const double *__restrict__ lut, const double
 // Grid definition: one thread per path.  MPG:112-122 sample count, or this build's fixed-S grid.
 // ------------------------------------------------------------------------------------------------
 __global__ void k_grid(int B, int W, int S, double dd_in, double *__restrict__ meta, double *__restrict__ aux,
-                       uint32_t *__restrict__ flags)
+                       double *__restrict__ runs, uint32_t *__restrict__ flags)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const double total = meta[(size_t)b * kMetaStride + 1];
+    double *tab = runs + (size_t)b * kGridRunDoubles;
     double dd, n;
+    int n_runs = 1;
+    const bool usable = total > 0.0 && isfinite(total);
     if (dd_in > 0) {
         dd = dd_in;
-        // loop samples: k >= 0 with k*dd < total (the reference accumulates current_dist += dd)
-        long nl = (long)ceil(total / dd);
-        if (nl < 1) nl = 1;
-        while (nl > 1 && (double)(nl - 1) * dd >= total) nl--;
-        while ((double)nl * dd < total) nl++;
-        long N = nl + 1;  // + appended end sample, MPG:172-175
+    } else {
+        dd = total / ((double)S - 1.5);
+    }
+    long n_loop = 1;
+    if (usable && dd > 0.0) {
+        // the reference's accumulated grid (current_dist += dd, MPG:112-122), exactly: vap_device.h
+        n_loop = build_grid_runs(dd, total, (long)S, tab, n_runs);
+    } else {
+        for (int j = 0; j < 5; j++) {     // one run that never moves, and the end markers
+            grid_run_set_k0(tab, j, j == 0 ? 0 : (long)S + 2);
+            tab[3 * j + 1] = 0.0;
+            tab[3 * j + 2] = 0.0;
+        }
+    }
+    if (dd_in > 0) {
+        long N = n_loop + 1;  // + appended end sample, MPG:172-175
         if (N > S) {
             N = S;
             if (flags) atomicOr(&flags[b], VAP_FLAG_TRUNCATED_BIT);
         }
         n = (double)N;
     } else {
-        dd = total / ((double)S - 1.5);
-        n = (double)S;
+        n = (double)S;      // dd = total/(S-1.5): s_(S-2) < total <= s_(S-1) with half a step of margin
     }
     meta[(size_t)b * kMetaStride + 2] = dd;
     meta[(size_t)b * kMetaStride + 3] = n;
@@ -293,7 +306,7 @@ __global__ void k_grid(int B, int W, int S, double dd_in, double *__restrict__ m
     aux[(size_t)b * kAuxStride + 0] = t_max / (double)(kLutN - 1);             // SM:443
     aux[(size_t)b * kAuxStride + 1] = tstep;
     aux[(size_t)b * kAuxStride + 2] = 1.0 / tstep;
-    aux[(size_t)b * kAuxStride + 3] = 0.0;
+    aux[(size_t)b * kAuxStride + 3] = (double)n_runs;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -331,6 +344,7 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int 
                                                            const double *__restrict__ slopes,
                                                            const double *__restrict__ meta,
                                                            const double *__restrict__ aux,
+                                                           const double *__restrict__ runs,
                                                            OT *__restrict__ ox, OT *__restrict__ oy,
                                                            OT *__restrict__ oh, OT *__restrict__ ok,
                                                            OT *__restrict__ odth, long long *__restrict__ stats)
@@ -349,6 +363,7 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int 
     const int N = (int)m[3];
     const double *ax = aux + (size_t)b * kAuxStride;
     const double lstep = ax[0], tstep = ax[1], inv_tstep = ax[2];
+    const int n_runs = (int)ax[3];
     const int tile0 = blockIdx.x * tiles_per_block;
     if (tile0 * tile >= S) return;
     const size_t row = (size_t)b * S;
@@ -360,12 +375,42 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int 
 
     // the path's tables are staged once and serve every tile of this workgroup
     const double *pw = power + (size_t)b * G * kCoefDoubles;
+    // (touch the head of the run table now: its lookup below depends on meta / aux and would otherwise wait
+    // for memory a second time)
+    const double run_touch = runs[(size_t)b * kGridRunDoubles + (tid < 120 ? tid : 0)];
     if (tile0 * tile < N) {
         lds_fill<4>(sD, lut + (size_t)b * kLutN, kLutN, tid, kSampleThreads);
         lds_fill<4>(sWt, slopes + (size_t)b * kLutN, kLutN, tid, kSampleThreads);
         if constexpr (COEF_LDS) lds_fill<4>(s_coef, pw, G * kCoefDoubles, tid, kSampleThreads);
     }
+    // MPG:112-122 distance grid: the reference accumulates current_dist += dd.  A thread's first sample of a
+    // tile comes from the path's run table (that sum in closed form, vap_device.h), the following ones by the
+    // reference's own addition.
+    const double *run_tab = runs + (size_t)b * kGridRunDoubles;
+    const int dd_exp = (__double2hiint(dd) >> 20) & 0x7ff;
+    auto grid_first = [&](int kb0) {
+        const int kf = kb0 < N - 1 ? kb0 : N - 1;
+        // the run from the exponent of kf*dd: right except next to a binade boundary
+        int r = 2 + 2 * (((__double2hiint((double)kf * dd) >> 20) & 0x7ff) - dd_exp);
+        r = kf <= 0 ? 0 : r < 1 ? 1 : r;
+        r = r > n_runs - 1 ? n_runs - 1 : r;
+        const double *e = run_tab + 3 * r;
+        int ka = (int)grid_run_k0(e, 0);
+        const int kb = (int)grid_run_k0(e, 1);
+        double sa = e[1], da = e[2];
+        if (kf < ka || kf >= kb) {
+            while ((int)grid_run_k0(run_tab, r + 1) <= kf) r++;                      // the end markers stop this
+            while (r > 0 && (int)grid_run_k0(run_tab, r) > kf) r--;
+            ka = (int)grid_run_k0(run_tab, r);
+            sa = run_tab[3 * r + 1];
+            da = run_tab[3 * r + 2];
+        }
+        return sa + (double)(kf - ka) * da;
+    };
+    // the first tile's lookup goes out together with the staging loads
+    const double sk_first = tile0 * tile < N ? grid_first(tile0 * tile + tid * kSPT) : 0.0;
     __syncthreads();
+    asm volatile("" ::"v"(run_touch));
     const double *coef = COEF_LDS ? s_coef : pw;
     const long long ts1 = stats ? __builtin_amdgcn_s_memtime() : 0;
     const double end_param = (double)(W - 1);
@@ -397,6 +442,11 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int 
             continue;
         }
         OT vx[kSPT], vy[kSPT], vh[kSPT], vk[kSPT], vd[kSPT];
+        // MPG:112-122 distance grid: the reference accumulates current_dist += dd.  The thread's first
+        // sample comes from the path's run table (that sum in closed form), the following ones by the
+        // reference's own addition.  The wave's kSPT*64 consecutive samples almost always lie in one run,
+        // or in three (a binade boundary: the old run, the boundary element, the new run).
+        double sk = tl == 0 ? sk_first : grid_first(kbase);
         double d1x[kSPT], d1y[kSPT];
         int jjv[kSPT];
         int idx = 0;
@@ -405,8 +455,8 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int 
             // samples past the end of the grid (last tile only) are evaluated at the end sample and
             // blanked on store: the body stays straight-line
             const int k = kbase + i < N - 1 ? kbase + i : N - 1;
-            // MPG:112-122 distance grid; the reference accumulates s += dd, we form k*dd
-            const double s = (k == N - 1) ? total : (double)k * dd;
+            if (i > 0) sk = sk + dd;
+            const double s = (k == N - 1) ? total : sk;
             // SM:291-318 distance_to_time.  s = 0 lands on entry 1 with t = 0 exactly; s = total is the
             // reference's early return of len(nodes)-1.
             if (i == 0) idx = lut_search_left(sD, s);
@@ -1356,15 +1406,16 @@ hipError_t launch_lut_slopes(hipStream_t st, int B, const double *lut, const dou
     return hipGetLastError();
 }
 
-hipError_t launch_grid(hipStream_t st, int B, int W, int S, double dd, double *meta, double *aux, uint32_t *flags)
+hipError_t launch_grid(hipStream_t st, int B, int W, int S, double dd, double *meta, double *aux, double *runs,
+                       uint32_t *flags)
 {
-    hipLaunchKernelGGL(k_grid, dim3((B + 255) / 256), dim3(256), 0, st, B, W, S, dd, meta, aux, flags);
+    hipLaunchKernelGGL(k_grid, dim3((B + 63) / 64), dim3(64), 0, st, B, W, S, dd, meta, aux, runs, flags);
     return hipGetLastError();
 }
 
 hipError_t launch_sample(hipStream_t st, bool f64, int B, int W, int S, const double *pw, const double *lut,
-                         const double *slopes, const double *meta, const double *aux, void *x, void *y, void *h,
-                         void *k, void *dth)
+                         const double *slopes, const double *meta, const double *aux, const double *runs, void *x,
+                         void *y, void *h, void *k, void *dth)
 {
     // one workgroup stages a path's tables once and walks tiles_per_block consecutive tiles; paths are
     // split over several workgroups only when the batch alone cannot fill the chip
@@ -1385,7 +1436,7 @@ hipError_t launch_sample(hipStream_t st, bool f64, int B, int W, int S, const do
     if (want_stats) (void)hipMalloc(&stats, n_waves * 4 * sizeof(long long));
 #define VAP_SAMPLE(OT_, LDS_)                                                                                      \
     hipLaunchKernelGGL((k_sample<OT_, LDS_>), grid, dim3(kSampleThreads), lds, st, W, S, tile, tiles_per_block, pw, lut, \
-                       slopes, meta, aux, (OT_ *)x, (OT_ *)y, (OT_ *)h, (OT_ *)k, (OT_ *)dth, stats)
+                       slopes, meta, aux, runs, (OT_ *)x, (OT_ *)y, (OT_ *)h, (OT_ *)k, (OT_ *)dth, stats)
     if (f64) { if (in_lds) VAP_SAMPLE(double, true); else VAP_SAMPLE(double, false); }
     else { if (in_lds) VAP_SAMPLE(float, true); else VAP_SAMPLE(float, false); }
 #undef VAP_SAMPLE

@@ -311,14 +311,18 @@ __global__ void k_route_lookup(RouteDev r, int what, int n, const double *__rest
 }
 
 // MPG:112-122 / 172-175 sampling: thread per sample
-__global__ void k_route_grid(RouteDev r, int N, double dd, double *__restrict__ t, double *__restrict__ kap,
-                             double *__restrict__ th, double *__restrict__ x, double *__restrict__ y)
+__global__ void k_route_grid(RouteDev r, int N, double dd, const double *__restrict__ runs, int n_runs, double *__restrict__ t,
+                             double *__restrict__ kap, double *__restrict__ th, double *__restrict__ x,
+                             double *__restrict__ y)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= N) return;
     const int n_spl = (int)r.info[0];
     const double total = r.info[1];
-    const double s = (k == N - 1) ? total : (double)k * dd;
+    // MPG:112-122: the reference's accumulated distance grid, exactly (vap_device.h, GridRuns)
+    int cur = grid_run_hint(dd, (long)k, n_runs);
+    const double sk = grid_s(runs, n_runs, (long)k, cur);
+    const double s = (k == N - 1) ? total : sk;
     const double tt = route_distance_to_time(r, n_spl, total, s);
     t[k] = tt;
     kap[k] = route_property(r, n_spl, tt, 1);
@@ -800,22 +804,29 @@ static int route_distance_domain(vap_route *rt, const vap_constraints *c, double
     VAP_TRY(vap_set_device(rt->ctx));
     if (!c || !(dd > 0)) return vap_fail(VAP_ERR_INVALID, "bad constraints or spacing");
     hipStream_t st = rt->ctx->stream;
-    // MPG:112-122 sample count (see k_grid)
-    long nl = (long)std::ceil(rt->total / dd);
-    if (nl < 1) nl = 1;
-    while (nl > 1 && (double)(nl - 1) * dd >= rt->total) nl--;
-    while ((double)nl * dd < rt->total) nl++;
-    N = (int)(nl + 1);
+    // MPG:112-122: sample count and grid of the accumulating loop (current_dist += dd), built on the host
+    // in closed form (vap_device.h) and handed to the device as a run table
+    std::vector<double> h_runs(vap::kGridRunDoubles, 0.0);
+    int n_runs = 1;
+    if (!(rt->total > 0) || !std::isfinite(rt->total)) return vap_fail(VAP_ERR_INVALID, "path has no length");
+    const long n_loop = vap::build_grid_runs(dd, rt->total, (long)1 << 40, h_runs.data(), n_runs);
+    if (n_loop + 1 > (long)1 << 28) return vap_fail(VAP_ERR_UNSUPPORTED, "more than 2^28 samples");
+    N = (int)(n_loop + 1);
     const size_t Np = (size_t)N + 8;
-    const size_t need = sizeof(double) * (9 * Np + (size_t)(rt->W + rt->M + 4) + 8) + sizeof(int) * Np + 64 * 16 + extra_bytes;
+    const size_t need = sizeof(double) * (9 * Np + (size_t)(rt->W + rt->M + 4) + 8 + vap::kGridRunDoubles) + sizeof(int) * Np + 64 * 17 +
+                        extra_bytes;
     VAP_TRY(ensure_work(rt, need));
     char *p = (char *)rt->work;
     a.t = carve<double>(p, Np); a.kap = carve<double>(p, Np); a.th = carve<double>(p, Np); a.x = carve<double>(p, Np);
     a.y = carve<double>(p, Np); a.vinit = carve<double>(p, Np); a.acc_f = carve<double>(p, Np);
     a.acc_b = carve<double>(p, Np); a.vel = carve<double>(p, Np); a.maxacc = carve<double>(p, rt->W + rt->M + 4);
     a.scal = carve<double>(p, 8); a.bmap = carve<int>(p, Np);
+    double *d_runs = carve<double>(p, vap::kGridRunDoubles);
     if (extra) *extra = p;
-    hipLaunchKernelGGL(vap::k_route_grid, dim3((N + 127) / 128), dim3(128), 0, st, rt->d, N, dd, a.t, a.kap, a.th, a.x, a.y);
+    HIP_TRY(hipMemcpyAsync(d_runs, h_runs.data(), sizeof(double) * vap::kGridRunDoubles, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));   // h_runs is a local
+    hipLaunchKernelGGL(vap::k_route_grid, dim3((N + 127) / 128), dim3(128), 0, st, rt->d, N, dd, d_runs, n_runs, a.t, a.kap, a.th,
+                       a.x, a.y);
     hipLaunchKernelGGL(vap::k_route_caps, dim3(1), dim3(1), 0, st, rt->d, N, a.t, c->max_vel, c->max_acc, c->max_dec, ev,
                        a.vinit, a.acc_f, a.acc_b, a.bmap, a.maxacc, a.scal);
     vap::VelConsts<double> vc;
@@ -852,11 +863,26 @@ int vap_route_forward_backward(vap_route *rt, const vap_constraints *c, double d
 int vap_route_sample_count(vap_route *rt, double dd, int *n_out)
 {
     if (!rt || !n_out || !(dd > 0)) return vap_fail(VAP_ERR_INVALID, "bad argument");
-    long nl = (long)std::ceil(rt->total / dd);
-    if (nl < 1) nl = 1;
-    while (nl > 1 && (double)(nl - 1) * dd >= rt->total) nl--;
-    while ((double)nl * dd < rt->total) nl++;
-    *n_out = (int)(nl + 1);
+    if (!(rt->total > 0) || !std::isfinite(rt->total)) return vap_fail(VAP_ERR_INVALID, "path has no length");
+    std::vector<double> runs(vap::kGridRunDoubles, 0.0);
+    int n_runs = 1;
+    const long n_loop = vap::build_grid_runs(dd, rt->total, (long)1 << 40, runs.data(), n_runs);
+    *n_out = (int)(n_loop + 1);
+    return VAP_OK;
+}
+
+int vap_grid_distances(double dd, double total_length, long capacity, double *h_s, long *n_out)
+{
+    if (!n_out || !(dd > 0) || !(total_length > 0) || !std::isfinite(total_length) || capacity < 0)
+        return vap_fail(VAP_ERR_INVALID, "bad argument");
+    std::vector<double> runs(vap::kGridRunDoubles, 0.0);
+    int n_runs = 1;
+    const long n_loop = vap::build_grid_runs(dd, total_length, (long)1 << 40, runs.data(), n_runs);
+    *n_out = n_loop;
+    if (h_s) {
+        int cur = 0;
+        for (long k = 0; k < n_loop && k < capacity; k++) h_s[k] = vap::grid_s(runs.data(), n_runs, k, cur);
+    }
     return VAP_OK;
 }
 
