@@ -17,6 +17,8 @@ and the fp64 reference see identical inputs):
   tables : strided + head/tail entries of the curvature / heading tables (spline_manager.py:477-548)
   grid   : for every distance sample of forward_backward_pass (motion_profile_generator.py:112-176)
            the parameter t, curvature, heading, point, and the final velocities it returns
+  runsum : (case runsum_w2000) the samples where the running sum current_dist += dd selects another table
+           entry than k*dd would
   profile: (case c1 only) the 9-tuple of generate_motion_profile (motion_profile_generator.py:389)
 """
 import argparse
@@ -148,6 +150,15 @@ def run_case(mods, name, wp, dd=DEFAULT_DD, samples=None, node_attrs=None, actio
     d["tab_headings"] = props["headings"][idx]
     if keep == "all":
         sel = np.arange(len(vel))
+    elif keep == "runsum":
+        # long native grid: the samples where the reference's running sum (current_dist += dd) picks another
+        # table entry than k*dd would, their neighbours, and a strided subset
+        n = len(vel)
+        k_est = np.array([float(mgr.get_curvature(mgr.distance_to_time(k * dd))) for k in range(n - 1)])
+        flips = np.nonzero(k_est != ks[:n - 1])[0]
+        d["runsum_flip_idx"] = flips
+        near = np.concatenate([flips + o for o in (-1, 0, 1)]) if len(flips) else np.array([], dtype=int)
+        sel = np.unique(np.clip(np.concatenate([near, np.arange(0, 256), np.arange(0, n, 499), np.arange(n - 256, n)]), 0, n - 1))
     else:  # large case: strided + windows
         n = len(vel)
         sel = np.unique(np.concatenate([np.arange(0, 512), np.arange(0, n, 997),
@@ -210,6 +221,10 @@ def main():
     for p in range(2):
         if want(f"c5_p{p}_S1024"):
             run_case(mods, f"c5_p{p}_S1024", c5[p], samples=1024)
+    # a long path on the reference's native grid: the running sum of dd drifts from k*dd by enough to pick
+    # other table entries (quirk: the grid is current_dist += dd, MPG:112-122)
+    if want("runsum_w2000"):
+        run_case(mods, "runsum_w2000", make_waypoints(1, 2000, 17)[0], dd=0.002, keep="runsum")
     # a 256-waypoint path on a moderate grid
     c2wp = make_waypoints(1, 256, 2)[0]
     if want("c2_w256_S20000"):

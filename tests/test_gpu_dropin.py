@@ -73,7 +73,7 @@ def test_scalar_accessors_match_reference_walk(mods, name):
     assert m.distance_to_time(1e9) == len(g["waypoints"]) - 1
 
 
-@pytest.mark.parametrize("name", gu.names(("plain_", "c1_", "cons_")))
+@pytest.mark.parametrize("name", gu.names(("plain_", "c1_", "cons_", "runsum_")))
 def test_forward_backward_pass_list(mods, name):
     _, mpg, _, _ = mods
     g = gu.load(name)

@@ -90,6 +90,34 @@ def test_reference_grid_vs_reference_golden(torch_mod, gens, name, dtype, tol):
 
 
 @pytest.mark.parametrize("dtype,tol", [("f32", 1e-5), ("f64", 1e-9)])
+def test_running_sum_grid_vs_reference_golden(torch_mod, gens, dtype, tol):
+    """MPG:112-122: the grid is the running sum current_dist += dd.  On this 2000-waypoint, 654 050-sample
+    path of the real reference the sum has drifted far enough from k*dd to select another table entry
+    (fixture field runsum_flip_idx); sample count, table entries (curvature, heading) and points must
+    follow the reference.  Velocity: fp64 only — at this curvature (|kappa| up to 14 /ft) the fp32 recurrence
+    is outside its stable range."""
+    g = gu.load("runsum_w2000")
+    N = int(g["n_samples"])
+    flips = g["runsum_flip_idx"]
+    assert len(flips) >= 1
+    r = run_gpu(torch_mod, gens[dtype], g["waypoints"][None], dd=float(g["dd"]), capacity=N + 2,
+                constraints=g["constraints"])
+    assert r["flags"][0] == 0
+    assert int(r["meta"][0, 3]) == N
+    gi = g["grid_idx"]
+    assert np.all(np.isin(flips, gi))
+    for k, ref in (("x", g["grid_x"]), ("y", g["grid_y"]), ("curvature", g["grid_curvature"])):
+        got = r[k][0][gi]
+        err = np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1.0 if k != "curvature" else 1e-2))
+        assert err <= tol, (k, err)
+    assert np.max(np.abs(r["heading"][0][gi] - g["grid_heading"])) <= tol * np.pi
+    if dtype == "f64":
+        ev = np.max(np.abs(r["velocity"][0][gi] - g["grid_velocity"]) / g["grid_velocity"])
+        print(f"runsum_w2000 f64 velocity max rel err {ev:.2e}")
+        assert ev <= 1e-9
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-5), ("f64", 1e-9)])
 @pytest.mark.parametrize("B,W,S,seed", [(64, 8, 1024, 5), (48, 32, 2000, 3), (3, 2, 300, 9), (5, 5, 257, 10)])
 def test_batch_vs_oracle(torch_mod, gens, B, W, S, seed, dtype, tol):
     from oracle import oracle

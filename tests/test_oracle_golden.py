@@ -75,6 +75,22 @@ def test_forward_backward_matches_reference(name):
     assert abs(np.sum(r["velocity"]) - float(g["velocity_sum"])) <= 1e-11 * float(g["velocity_sum"])
 
 
+def test_running_sum_fixture_has_a_decision_that_k_times_dd_gets_wrong():
+    """runsum_w2000 exists to pin MPG:112-122's current_dist += dd: at runsum_flip_idx the reference's entry
+    differs from the one k*dd selects.  The oracle (which accumulates) must give the reference's there, and
+    evaluating at k*dd must not — otherwise the fixture pins nothing."""
+    g = gu.load("runsum_w2000")
+    flips = g["runsum_flip_idx"]
+    assert len(flips) >= 1
+    p = _path(g)
+    p.rebuild_tables()
+    r = p.forward_backward(g["constraints"], float(g["dd"]), float(g["start_vel"]), float(g["end_vel"]))
+    pos = np.searchsorted(g["grid_idx"], flips)
+    np.testing.assert_allclose(r["curvature"][flips], g["grid_curvature"][pos], rtol=1e-13, atol=1e-14)
+    k_est = np.array([p.curvature(p.distance_to_time(float(k) * float(g["dd"]))) for k in flips])
+    assert np.all(np.abs(k_est - g["grid_curvature"][pos]) > 1e-9)
+
+
 @pytest.mark.parametrize("name", [n for n in SMALL if "profile_times" in gu.load(n).files])
 def test_time_domain_profile_matches_reference(name):
     g = gu.load(name)
