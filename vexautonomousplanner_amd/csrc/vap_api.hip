@@ -319,9 +319,13 @@ int vap_profile_batch(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd
     HIP_TRY(vap::launch_fit(ctx->stream, f64, B, W, d_waypoints, nullptr, nullptr, (double *)ctx->seg.ptr,
                             (double *)ctx->power.ptr, nullptr, meta, flags));
     tm.mark(VAP_T_FIT);
+    vap::GridArgs grid;     // the distance grid is defined in the tail of the table kernel
+    grid.S = S;
+    grid.dd = dd;
+    grid.aux = (double *)ctx->aux.ptr;
+    grid.runs = (double *)ctx->runs.ptr;
     HIP_TRY(vap::launch_lut(ctx->stream, B, W, (const double *)ctx->seg.ptr, (double *)ctx->lut.ptr,
-                            (double *)ctx->slopes.ptr, meta, flags));
-    HIP_TRY(vap::launch_grid(ctx->stream, B, W, S, dd, meta, (double *)ctx->aux.ptr, (double *)ctx->runs.ptr, flags));
+                            (double *)ctx->slopes.ptr, meta, flags, grid));
     tm.mark(VAP_T_LUT);
     HIP_TRY(vap::launch_sample(ctx->stream, f64, B, W, S, (const double *)ctx->power.ptr,
                                (const double *)ctx->lut.ptr, (const double *)ctx->slopes.ptr, meta,

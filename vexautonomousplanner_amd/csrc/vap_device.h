@@ -590,6 +590,34 @@ __host__ __device__ inline long grid_run_k0(const double *tab, int r)
 }
 __host__ __device__ inline void grid_run_set_k0(double *tab, int r, long k) { __builtin_memcpy(tab + 3 * r, &k, sizeof k); }
 
+// 2^e and floor(log2(x)) for normal doubles, by their bits (ldexp / ilogb cost ~40 instructions each on the
+// device); out-of-range exponents take the library route
+__host__ __device__ inline double grid_pow2(int e)
+{
+    if (e < -1000 || e > 1000) return ldexp(1.0, e);
+    const unsigned long long b = (unsigned long long)(e + 1023) << 52;
+    double v;
+    __builtin_memcpy(&v, &b, sizeof v);
+    return v;
+}
+__host__ __device__ inline int grid_exponent(double x)
+{
+    unsigned long long b;
+    __builtin_memcpy(&b, &x, sizeof b);
+    const int be = (int)((b >> 52) & 0x7ff);
+    return (be == 0 || be == 0x7ff) ? ilogb(x) : be - 1023;
+}
+// a reciprocal good enough to seed a floor() that is corrected afterwards
+__host__ __device__ inline double grid_rcp(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double r = __builtin_amdgcn_rcp(x);
+    return r * (2.0 - x * r);           // one Newton step: the corrections after floor() stay at a step or two
+#else
+    return 1.0 / x;
+#endif
+}
+
 // Builds the runs for indices 0 .. k_limit (inclusive) or until s_k >= total, whichever comes first, into
 // tab (kGridRunStride entries of {first index k0 — an int64 stored in the double's bits —, its distance s0,
 // increment D}) and returns the number of indices k with s_k < total among
@@ -613,8 +641,10 @@ __host__ __device__ inline long build_grid_runs(double dd, double total, long k_
     k = 1;
     s = dd;
     while (k <= k_limit && s < total && R < kMaxGridRuns - 2) {
-        const int e = ilogb(s);                           // s in [2^e, 2^(e+1))
-        const double top = ldexp(1.0, e + 1), ulp = ldexp(1.0, e - 52);
+        const int e = grid_exponent(s);                   // s in [2^e, 2^(e+1))
+        const double top = grid_pow2(e + 1);
+        const double up = grid_pow2(52 - e);              // 1 / ulp
+        const double ulp = grid_pow2(e - 52);
         const double s1 = s + dd;                         // hardware rounding, whichever binade it lands in
         emit(k, s, s1 - s);                               // the binade's first element: a run of one
         n_below = k + 1;
@@ -624,17 +654,15 @@ __host__ __device__ inline long build_grid_runs(double dd, double total, long k_
             s = s1;
             continue;
         }
-        // constant increment from s1 on
-        const double x = ldexp(dd, 52 - e);                // dd / ulp, exact (power-of-two scaling)
-        const double f = floor(x), fr = x - f;
-        double m = f;
-        if (fr > 0.5 || (fr == 0.5 && fmod(f, 2.0) != 0.0)) m = f + 1.0;
+        // constant increment from s1 on: dd in ulps (exact power-of-two scaling), rounded half to even —
+        // every partial sum from s1 on has an even last place when dd/ulp ends in one half
+        const double m = rint(dd * up);
         const double Dc = m * ulp;
         // elements s1 + j*Dc, j = 0..J, stay below top: J = floor(((top - s1)/ulp - 1) / m)
         double J = 0.0;
         if (m > 0.0) {
-            const double a = ldexp(top - s1, 52 - e) - 1.0; // (top - s1) / ulp - 1: integer-valued, exact
-            J = floor(a / m);
+            const double a = (top - s1) * up - 1.0;       // integer-valued, exact
+            J = floor(a * grid_rcp(m));
             while ((J + 1.0) * m <= a) J += 1.0;
             while (J > 0.0 && J * m > a) J -= 1.0;
         } else {
@@ -643,21 +671,17 @@ __host__ __device__ inline long build_grid_runs(double dd, double total, long k_
         long Jl = (J > 4.0e15) ? (long)4e15 : (long)J;
         if (k + 1 + Jl > k_limit) Jl = k_limit - (k + 1) < 0 ? 0 : k_limit - (k + 1);
         emit(k + 1, s1, Dc);
-        if (s1 < total) {
-            // run elements below total: the first j with s1 + j*Dc >= total ends the grid
-            long jt = Jl;
-            if (Dc > 0.0) {
-                double q = floor((total - s1) / Dc);
-                while (s1 + q * Dc < total) q += 1.0;
-                while (q > 0.0 && s1 + (q - 1.0) * Dc >= total) q -= 1.0;
-                if (q - 1.0 < (double)jt) jt = (long)(q - 1.0);
-            }
-            n_below = k + 1 + jt + 1;
-            if (jt < Jl) break;                           // the grid ends inside this run
-        } else {
+        if (s1 >= total) break;
+        const double s_last = s1 + (double)Jl * Dc;       // exact
+        if (s_last >= total) {
+            // the grid ends inside this run: the first j with s1 + j*Dc >= total (Dc > 0 here)
+            double q = floor((total - s1) * grid_rcp(Dc));
+            while (s1 + q * Dc < total) q += 1.0;
+            while (q > 0.0 && s1 + (q - 1.0) * Dc >= total) q -= 1.0;
+            n_below = k + 1 + (long)q;
             break;
         }
-        const double s_last = s1 + (double)Jl * Dc;       // exact
+        n_below = k + 1 + Jl + 1;
         k = k + 1 + Jl + 1;
         s = s_last + dd;                                  // crossing step: hardware rounding in the next binade
     }

@@ -20,8 +20,16 @@ constexpr int kMaxWaypoints = 2048;              // k_fit LDS: 7*W doubles
 
 hipError_t launch_fit(hipStream_t st, bool f64, int B, int W, const void *wp, const double *tin,
                       const double *tout, double *seg, double *pw, double *seglen, double *meta, uint32_t *flags);
+// When aux is set, k_lut also defines each path's distance grid (what launch_grid does) — the fused call, where
+// the spacing is known before the table exists.
+struct GridArgs {
+    int S = 0;
+    double dd = 0.0;
+    double *aux = nullptr;
+    double *runs = nullptr;
+};
 hipError_t launch_lut(hipStream_t st, int B, int W, const double *seg, double *lut, double *slopes, double *meta,
-                      uint32_t *flags);
+                      uint32_t *flags, GridArgs grid = GridArgs());
 hipError_t launch_lut_slopes(hipStream_t st, int B, const double *lut, const double *meta, double *slopes);
 hipError_t launch_grid(hipStream_t st, int B, int W, int S, double dd, double *meta, double *aux, double *runs,
                        uint32_t *flags);

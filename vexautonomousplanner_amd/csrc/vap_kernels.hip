@@ -128,6 +128,56 @@ __global__ __launch_bounds__(256) void k_fit(int W, const IT *__restrict__ waypo
     if (tid == 0 && flags) flags[b] = s_flag;
 }
 
+__device__ void grid_define(int b, int W, int S, double dd_in, double total, double t_max, double *__restrict__ meta,
+                            double *__restrict__ aux, double *__restrict__ runs, uint32_t *__restrict__ flags)
+{
+    double *tab = runs + (size_t)b * kGridRunDoubles;
+    double dd, n;
+    int n_runs = 1;
+    const bool usable = total > 0.0 && isfinite(total);
+    if (dd_in > 0) {
+        dd = dd_in;
+    } else {
+        dd = total / ((double)S - 1.5);
+    }
+    long n_loop = 1;
+    if (usable && dd > 0.0) {
+        // the reference's accumulated grid (current_dist += dd, MPG:112-122), exactly: vap_device.h
+        n_loop = build_grid_runs(dd, total, (long)S, tab, n_runs);
+    } else {
+        for (int j = 0; j < 5; j++) {     // one run that never moves, and the end markers
+            grid_run_set_k0(tab, j, j == 0 ? 0 : (long)S + 2);
+            tab[3 * j + 1] = 0.0;
+            tab[3 * j + 2] = 0.0;
+        }
+    }
+    if (dd_in > 0) {
+        long N = n_loop + 1;  // + appended end sample, MPG:172-175
+        if (N > S) {
+            N = S;
+            if (flags) atomicOr(&flags[b], VAP_FLAG_TRUNCATED_BIT);
+        }
+        n = (double)N;
+    } else {
+        n = (double)S;      // dd = total/(S-1.5): s_(S-2) < total <= s_(S-1) with half a step of margin
+    }
+    meta[(size_t)b * kMetaStride + 2] = dd;
+    meta[(size_t)b * kMetaStride + 3] = n;
+    const double tstep = (double)(W - 1) / (double)(W * kSamplesPerNode - 1);  // np.linspace step, SM:487
+    aux[(size_t)b * kAuxStride + 0] = t_max / (double)(kLutN - 1);             // SM:443
+    aux[(size_t)b * kAuxStride + 1] = tstep;
+    aux[(size_t)b * kAuxStride + 2] = 1.0 / tstep;
+    aux[(size_t)b * kAuxStride + 3] = (double)n_runs;
+}
+
+__global__ void k_grid(int B, int W, int S, double dd_in, double *__restrict__ meta, double *__restrict__ aux,
+                       double *__restrict__ runs, uint32_t *__restrict__ flags)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    grid_define(b, W, S, dd_in, meta[(size_t)b * kMetaStride + 1], meta[(size_t)b * kMetaStride + 0], meta, aux, runs, flags);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2: arc-length lookup table.  One workgroup per path.  SM:426-475.
 // 1000 uniform-parameter samples of |P'(t)| (reference basis, reference order), trapezoid, and a
@@ -137,7 +187,7 @@ template <bool SEG_LDS>
 __global__ __launch_bounds__(256) void k_lut(int W, const double *__restrict__ segments,
                                              double *__restrict__ lut, double *__restrict__ slopes,
                                              double *__restrict__ meta, uint32_t *__restrict__ flags,
-                                             long long *__restrict__ stats)
+                                             GridArgs grid, long long *__restrict__ stats)
 {
     const long long tl0 = stats ? __builtin_amdgcn_s_memtime() : 0;
     extern __shared__ __attribute__((aligned(16))) double s_seg[];   // G * 12 when SEG_LDS
@@ -188,6 +238,7 @@ __global__ __launch_bounds__(256) void k_lut(int W, const double *__restrict__ s
     // exact starting sum — the same adds in the same order, so every prefix is bit-identical to the
     // one-lane result — and stores it.
     __shared__ double s_start[kPad / 32];
+    __shared__ double s_total;
     if (tid == 0) {
         double acc = 0.0;   // cum[0] = 0: the first add is the exact 0 + 0 of partial_distances[0]
         // (+ current_dist of SM:457 is + 0.0 for a single spline: a no-op on these non-negative sums)
@@ -202,9 +253,13 @@ __global__ __launch_bounds__(256) void k_lut(int W, const double *__restrict__ s
             for (int k = 0; k < 16; k++) { acc += v[k].x; acc += v[k].y; }
         }
         meta[(size_t)b * kMetaStride + 1] = acc;   // elements past kLutN-1 are zero increments
+        s_total = acc;
         if (flags && !(acc > 0.0 && isfinite(acc))) atomicOr(&flags[b], VAP_FLAG_DEGENERATE_BIT);
     }
     __syncthreads();
+    // the fused call knows the grid spacing already: the last thread (a wave with nothing to do during the
+    // replay below) defines the path's distance grid, which would otherwise be a launch of its own
+    if (grid.aux && tid == nt - 1) grid_define(b, W, grid.S, grid.dd, s_total, t_max, meta, grid.aux, grid.runs, flags);
     if (tid < kPad / 32) {
         double acc = s_start[tid];
         double2 *cum2 = reinterpret_cast<double2 *>(cum) + tid * 16;
@@ -263,52 +318,6 @@ __global__ void k_lut_slopes(int B, const double *__restrict__ lut, const double
 // ------------------------------------------------------------------------------------------------
 // Grid definition: one thread per path.  MPG:112-122 sample count, or this build's fixed-S grid.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_grid(int B, int W, int S, double dd_in, double *__restrict__ meta, double *__restrict__ aux,
-                       double *__restrict__ runs, uint32_t *__restrict__ flags)
-{
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    const double total = meta[(size_t)b * kMetaStride + 1];
-    double *tab = runs + (size_t)b * kGridRunDoubles;
-    double dd, n;
-    int n_runs = 1;
-    const bool usable = total > 0.0 && isfinite(total);
-    if (dd_in > 0) {
-        dd = dd_in;
-    } else {
-        dd = total / ((double)S - 1.5);
-    }
-    long n_loop = 1;
-    if (usable && dd > 0.0) {
-        // the reference's accumulated grid (current_dist += dd, MPG:112-122), exactly: vap_device.h
-        n_loop = build_grid_runs(dd, total, (long)S, tab, n_runs);
-    } else {
-        for (int j = 0; j < 5; j++) {     // one run that never moves, and the end markers
-            grid_run_set_k0(tab, j, j == 0 ? 0 : (long)S + 2);
-            tab[3 * j + 1] = 0.0;
-            tab[3 * j + 2] = 0.0;
-        }
-    }
-    if (dd_in > 0) {
-        long N = n_loop + 1;  // + appended end sample, MPG:172-175
-        if (N > S) {
-            N = S;
-            if (flags) atomicOr(&flags[b], VAP_FLAG_TRUNCATED_BIT);
-        }
-        n = (double)N;
-    } else {
-        n = (double)S;      // dd = total/(S-1.5): s_(S-2) < total <= s_(S-1) with half a step of margin
-    }
-    meta[(size_t)b * kMetaStride + 2] = dd;
-    meta[(size_t)b * kMetaStride + 3] = n;
-    const double t_max = meta[(size_t)b * kMetaStride + 0];
-    const double tstep = (double)(W - 1) / (double)(W * kSamplesPerNode - 1);  // np.linspace step, SM:487
-    aux[(size_t)b * kAuxStride + 0] = t_max / (double)(kLutN - 1);             // SM:443
-    aux[(size_t)b * kAuxStride + 1] = tstep;
-    aux[(size_t)b * kAuxStride + 2] = 1.0 / tstep;
-    aux[(size_t)b * kAuxStride + 3] = (double)n_runs;
-}
-
 // ------------------------------------------------------------------------------------------------
 // K3+K4: sampling.  grid = (tiles, B); a workgroup evaluates kSampleChunk consecutive samples of one
 // path, each thread kSPT consecutive ones (so every output leaves as one 16-byte store per lane and
@@ -1379,14 +1388,14 @@ hipError_t launch_fit(hipStream_t st, bool f64, int B, int W, const void *wp, co
 }
 
 hipError_t launch_lut(hipStream_t st, int B, int W, const double *seg, double *lut, double *slopes, double *meta,
-                      uint32_t *flags)
+                      uint32_t *flags, GridArgs grid)
 {
     static const bool want_stats = getenv("VAP_LUT_STATS") != nullptr;
     long long *stats = nullptr;
     if (want_stats) (void)hipMalloc(&stats, (size_t)B * 4 * sizeof(long long));
     // 128 threads: the sequential sum keeps one lane busy, so residency (16 workgroups per CU) is what hides it
-    if (W - 1 <= 512) hipLaunchKernelGGL(k_lut<true>, dim3(B), dim3(128), sizeof(double) * 12 * (W - 1), st, W, seg, lut, slopes, meta, flags, stats);
-    else hipLaunchKernelGGL(k_lut<false>, dim3(B), dim3(128), 0, st, W, seg, lut, slopes, meta, flags, stats);
+    if (W - 1 <= 512) hipLaunchKernelGGL(k_lut<true>, dim3(B), dim3(128), sizeof(double) * 12 * (W - 1), st, W, seg, lut, slopes, meta, flags, grid, stats);
+    else hipLaunchKernelGGL(k_lut<false>, dim3(B), dim3(128), 0, st, W, seg, lut, slopes, meta, flags, grid, stats);
     if (stats) {
         std::vector<long long> h((size_t)B * 4);
         (void)hipStreamSynchronize(st);
