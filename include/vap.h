@@ -138,8 +138,11 @@ int vap_sample(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd, const
  * As in the reference, max_dec does not take part: boundary_map always contains sample 0 (MPG:110), so
  * forward_backward_pass replaces it with max_acc before its first step (MPG:194-196) and decelerates
  * with max_acc; max_dec is used by the time loop only (vap_time_profile, vap_route_motion_profile).
- * d_vcap: optional [B][S] (dtype) per-sample initial velocities (MPG:121,127,153,172; NULL = the
- * plain-node default max_vel with start/end velocities at the ends). */
+ * d_vcap: optional [B][S] (dtype) per-sample initial velocities — the `velocities` list the reference
+ * starts from (MPG:121,127,153,172: node / action-point max_velocity, 0.01 at stops); NULL = the
+ * plain-node default max_vel with start/end velocities at the ends.  Entry 0 and the end sample are
+ * taken from start_vel / end_vel.  Rows that fit the register-resident relaxation kernel (20 480
+ * samples fp32, 10 240 fp64) run there, longer ones in the one-lane sequential sweep. */
 int vap_velocity_pass(vap_ctx *ctx, vap_dtype dt, int B, int S, const vap_constraints *c,
                       double start_vel, double end_vel, const double *d_meta,
                       const void *d_curvature, const void *d_dtheta, const void *d_vcap,

@@ -117,6 +117,137 @@ def test_running_sum_grid_vs_reference_golden(torch_mod, gens, dtype, tol):
         assert ev <= 1e-9
 
 
+def _initial_velocities(t, W, max_vel, end_vel, node_max_velocity, node_stop):
+    """MPG:100-176 restricted to node max_velocity / stop: the `velocities` list forward_backward_pass starts
+    from, given the parameter t of every sample (the loop samples, then the appended end sample)."""
+    mv = node_max_velocity[0] if node_max_velocity[0] > 0 else max_vel
+    out = []
+    node, prev_t, t_end = 0, 0.0, float(W - 1)
+    for tk in t[:-1]:
+        out.append(mv)
+        if (prev_t % 1) > (tk % 1) and tk < t_end:
+            node += 1
+            if node_stop[node]:
+                out[-1] = 0.01
+            mv = node_max_velocity[node] if node_max_velocity[node] > 0 else max_vel
+        prev_t = tk
+    out.append(end_vel)
+    return np.array(out)
+
+
+def _staged_velocity(torch, dtype, wp64, cons, vcap64, dd, cap, kernel):
+    """vap_fit -> vap_build_lut -> vap_sample -> vap_velocity_pass(d_vcap) on a batch; returns velocity rows, n."""
+    import ctypes as C
+    from vexautonomousplanner_amd import _lib
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    td = torch.float32 if dtype == "f32" else torch.float64
+    vd = _lib.VAP_F32 if dtype == "f32" else _lib.VAP_F64
+    B, W = wp64.shape[:2]
+    ctx = _lib.Context(0)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    ctx.set_option(_lib.OPT_VELOCITY_KERNEL, kernel)
+    c = _lib.make_constraints(cons)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    wp = torch.tensor(wp64, device=dev, dtype=td)
+    seg = torch.empty((B, W - 1, 6, 2), dtype=torch.float64, device=dev)
+    seglen = torch.empty((B, W - 1), dtype=torch.float64, device=dev)
+    meta = torch.zeros((B, 4), dtype=torch.float64, device=dev)
+    flags = torch.zeros((B,), dtype=torch.int32, device=dev)
+    lut = torch.empty((B, _lib.LUT_SAMPLES), dtype=torch.float64, device=dev)
+    o = {k: torch.empty((B, cap), dtype=td, device=dev) for k in ("x", "y", "heading", "curvature", "dtheta", "velocity")}
+    vc = torch.tensor(vcap64, device=dev, dtype=td) if vcap64 is not None else None
+    _lib.check(L.vap_fit(ctx.handle, vd, B, W, p(wp), None, None, p(seg), p(seglen), p(meta), p(flags)), "vap_fit")
+    _lib.check(L.vap_build_lut(ctx.handle, B, W, p(seg), p(lut), p(meta), p(flags)), "vap_build_lut")
+    _lib.check(L.vap_sample(ctx.handle, vd, B, W, cap, dd, p(seg), p(lut), p(meta), p(o["x"]), p(o["y"]), p(o["heading"]),
+                            p(o["curvature"]), p(o["dtheta"]), p(flags)), "vap_sample")
+    _lib.check(L.vap_velocity_pass(ctx.handle, vd, B, cap, C.byref(c), 0.01, 0.01, p(meta), p(o["curvature"]), p(o["dtheta"]),
+                                   p(vc), p(o["velocity"]), p(flags)), "vap_velocity_pass")
+    torch.cuda.synchronize()
+    assert not flags.any().item()
+    return o["velocity"].cpu().numpy().astype(np.float64), meta[:, 3].cpu().numpy().astype(int)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("B,W,S", [(6, 8, 1000), (3, 32, 10000), (5, 5, 257), (4, 2, 64)])
+def test_initial_velocities_relaxation_equals_sequential_sweep(torch_mod, dtype, B, W, S):
+    """d_vcap (per-sample initial velocities, MPG:121,127,153,172) in the register-resident relaxation kernel
+    against the one-lane sequential sweep: bit for bit, as without them."""
+    from vexautonomousplanner_amd import _lib
+    from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
+    rng = np.random.default_rng(B * 1000 + W)
+    wp = make_waypoints(B, W, 77).astype(np.float64)
+    # piecewise-constant limits with a few "stops", like node / action-point limits mapped onto samples
+    vcap = np.empty((B, S))
+    for b in range(B):
+        edges = np.sort(rng.integers(1, S - 1, size=5))
+        vals = rng.uniform(0.8, 4.0, size=6)
+        vcap[b] = vals[np.searchsorted(edges, np.arange(S), side="right")]
+        vcap[b, rng.integers(1, S - 1, size=3)] = 0.01
+    v_seq, _ = _staged_velocity(torch_mod, dtype, wp, DEFAULT_CONSTRAINTS, vcap, 0.0, S, _lib.VELOCITY_SEQ_FAST)
+    v_rel, _ = _staged_velocity(torch_mod, dtype, wp, DEFAULT_CONSTRAINTS, vcap, 0.0, S, _lib.VELOCITY_RELAX)
+    v_plain, _ = _staged_velocity(torch_mod, dtype, wp, DEFAULT_CONSTRAINTS, None, 0.0, S, _lib.VELOCITY_RELAX)
+    assert np.array_equal(v_seq, v_rel)
+    assert np.all(v_rel[:, 1:-1] <= vcap[:, 1:-1] * (1 + 1e-6))
+    assert np.any(v_rel < v_plain * 0.99)       # the limits bind somewhere
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-5), ("f64", 1e-9)])
+def test_initial_velocities_stop_node_vs_reference_golden(torch_mod, dtype, tol):
+    """feat_stop (the real reference, a stop at node 3): the batched path with the reference's initial velocity
+    list as d_vcap reproduces forward_backward_pass."""
+    from vexautonomousplanner_amd import _lib
+    g = gu.load("feat_stop")
+    N = int(g["n_samples"])
+    assert np.array_equal(g["grid_idx"], np.arange(N))
+    W = len(g["waypoints"])
+    vcap = _initial_velocities(g["grid_t"], W, float(g["constraints"][0]), float(g["end_vel"]), g["node_max_velocity"], g["node_stop"])
+    assert np.sum(vcap == 0.01) >= 2      # the stop and the end velocity
+    cap = N + 5
+    row = np.zeros((1, cap))
+    row[0, :N] = vcap
+    for kernel in (_lib.VELOCITY_RELAX, _lib.VELOCITY_SEQ_FAST):
+        v, n = _staged_velocity(torch_mod, dtype, g["waypoints"][None], g["constraints"], row, float(g["dd"]), cap, kernel)
+        assert n[0] == N
+        err = np.max(np.abs(v[0, :N] - g["grid_velocity"]) / g["grid_velocity"])
+        print(f"feat_stop/{dtype} kernel {kernel}: velocity max rel err {err:.2e}")
+        assert err <= tol
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-5), ("f64", 1e-9)])
+def test_initial_velocities_node_limits_vs_oracle(torch_mod, dtype, tol):
+    """Per-node max_velocity and stops on random 8-waypoint routes: oracle (node semantics of MPG:100-176) against
+    the batched path fed with the initial-velocity rows."""
+    from oracle import oracle
+    from vexautonomousplanner_amd import _lib
+    from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
+    rng = np.random.default_rng(404)
+    B, W, dd = 6, 8, 0.005
+    wp = make_waypoints(B, W, 31).astype(np.float64)
+    refs, rows = [], []
+    for b in range(B):
+        mv = np.where(rng.random(W) < 0.4, rng.uniform(1.0, 3.5, W), 0.0)
+        stop = (rng.random(W) < 0.25).astype(float)
+        stop[0] = stop[-1] = 0
+        nodes = dict(is_reverse=np.zeros(W), turn=np.zeros(W), stop=stop, wait_time=np.zeros(W), max_velocity=mv,
+                     max_acceleration=np.zeros(W), tangent=np.full((W, 2), np.nan), magnitudes=np.zeros((W, 2)))
+        op = oracle.OraclePath(wp[b], nodes=nodes)
+        op.rebuild_tables()
+        r = op.forward_backward(DEFAULT_CONSTRAINTS, dd=dd)
+        refs.append(r["velocity"])
+        rows.append(_initial_velocities(r["t"], W, DEFAULT_CONSTRAINTS[0], 0.01, mv, stop))
+    cap = max(len(r) for r in refs) + 3
+    vcap = np.zeros((B, cap))
+    for b in range(B):
+        vcap[b, :len(rows[b])] = rows[b]
+    v, n = _staged_velocity(torch_mod, dtype, wp, DEFAULT_CONSTRAINTS, vcap, dd, cap, _lib.VELOCITY_RELAX)
+    for b in range(B):
+        N = len(refs[b])
+        assert n[b] == N
+        err = np.max(np.abs(v[b, :N] - refs[b]) / refs[b])
+        assert err <= tol, (b, err)
+
+
 @pytest.mark.parametrize("dtype,tol", [("f32", 1e-5), ("f64", 1e-9)])
 @pytest.mark.parametrize("B,W,S,seed", [(64, 8, 1024, 5), (48, 32, 2000, 3), (3, 2, 300, 9), (5, 5, 257, 10)])
 def test_batch_vs_oracle(torch_mod, gens, B, W, S, seed, dtype, tol):

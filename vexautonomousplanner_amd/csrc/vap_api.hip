@@ -62,11 +62,16 @@ int run_velocity(vap_ctx *ctx, bool f64, int B, int S, const double cc[6], doubl
                  const void *curv, const void *dth, const void *vcap, void *vel, uint32_t *flags)
 {
     int mode = ctx->velocity_kernel;
-    if (mode == VAP_VELOCITY_AUTO) mode = vcap ? VAP_VELOCITY_SEQ_FAST : VAP_VELOCITY_RELAX;
+    // per-sample initial velocities: the register-resident relaxation kernel takes them, the two-level one for
+    // long rows and the wave-per-path variant do not (the sequential sweep does)
+    if (mode == VAP_VELOCITY_AUTO)
+        mode = (vcap && S > vap::velocity_relax_max_samples(f64)) ? VAP_VELOCITY_SEQ_FAST : VAP_VELOCITY_RELAX;
     const int forced = mode;
     if (mode == VAP_VELOCITY_RELAX_BLOCK || mode == VAP_VELOCITY_RELAX_WAVE) mode = VAP_VELOCITY_RELAX;
     if (mode == VAP_VELOCITY_RELAX) {
-        if (vcap) return vap_fail(VAP_ERR_UNSUPPORTED, "relaxation kernel: per-sample caps are not supported yet");
+        if (vcap && (forced == VAP_VELOCITY_RELAX_WAVE || S > vap::velocity_relax_max_samples(f64)))
+            return vap_fail(VAP_ERR_UNSUPPORTED, "per-sample initial velocities: rows up to %d samples in the relaxation kernel, or the sequential sweep",
+                            vap::velocity_relax_max_samples(f64));
         if (forced == VAP_VELOCITY_RELAX_WAVE && (f64 || S > vap::velocity_relax_max_samples(f64)))
             return vap_fail(VAP_ERR_UNSUPPORTED, "wave-per-path kernel: fp32 rows up to %d samples", vap::velocity_relax_max_samples(false));
         // One wave per path (sequential windows) keeps 8 paths resident per CU instead of 2, but measured
@@ -81,7 +86,7 @@ int run_velocity(vap_ctx *ctx, bool f64, int B, int S, const double cc[6], doubl
             HIP_TRY(vap::launch_velocity_windows(ctx->stream, B, S, cc, sv, ev, meta, curv, dth, vel, flags, ctx->ufwd.ptr,
                                                  ctx->lstate.ptr, (int *)ctx->lcount.ptr));
         } else if (S <= vap::velocity_relax_max_samples(f64)) {
-            HIP_TRY(vap::launch_velocity_relax(ctx->stream, f64, B, S, cc, sv, ev, meta, curv, dth, vel, flags));
+            HIP_TRY(vap::launch_velocity_relax(ctx->stream, f64, B, S, cc, sv, ev, meta, curv, dth, vcap, vel, flags));
         } else {
             // long rows: two-level relaxation (host-synchronised super-rounds)
             VAP_TRY(ctx->ensure(ctx->ufwd, (size_t)B * S * (f64 ? 8 : 4)));

@@ -40,8 +40,9 @@ hipError_t launch_velocity_seq(hipStream_t st, bool f64, bool fast, int B, int S
                                double ev, const double *meta, const void *curv, const void *dth, const void *vcap,
                                void *vel);
 int velocity_relax_max_samples(bool f64);
+// vcap: optional [B][S] per-sample initial velocities (NULL = plain paths)
 hipError_t launch_velocity_relax(hipStream_t st, bool f64, int B, int S, const double c[6], double sv, double ev,
-                                 const double *meta, const void *curv, const void *dth, void *vel,
+                                 const double *meta, const void *curv, const void *dth, const void *vcap, void *vel,
                                  uint32_t *flags);
 // rows longer than velocity_relax_max_samples(): two-level relaxation, synchronises the stream once per super-round
 size_t velocity_long_state_bytes(bool f64, int B, int S);

@@ -759,11 +759,14 @@ __device__ __forceinline__ double wave_shift_down(double x)
     return __builtin_bit_cast(double, ((uint64_t)h2 << 32) | l2);
 }
 
-template <typename R, int L, int MAXT, int MINW>
+// VCAP: the caller gave per-sample initial velocities (MPG:121,127,153,172: node / action-point max_velocity and
+// stops); the forward step into sample j is then also limited by vcap[j]^2 — folded into that slot's cap.
+template <typename R, int L, int MAXT, int MINW, bool VCAP>
 __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<R> c, R start_u, R end_u,
                                                                const double *__restrict__ meta,
                                                                const R *__restrict__ curv,
                                                                const R *__restrict__ dtheta,
+                                                               const R *__restrict__ vcap,
                                                                R *__restrict__ vel, uint32_t *__restrict__ flags,
                                                                long long *__restrict__ stats)
 {
@@ -841,6 +844,22 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
             g[s] = opaque(valid ? gq : (R)0);
             dup |= g[s] < (R)0;
             u[s] = start_u;
+        }
+    }
+    if constexpr (VCAP) {
+        // the forward step into sample j (1 <= j <= N-2; the end sample is fixed by the backward sweep) also
+        // honours the sample's initial velocity: min(.., cap, vcap^2) — one number per slot
+        const R *VC = vcap + row;
+#pragma unroll
+        for (int s0 = 0; s0 < L; s0 += BK) {    // BK loads in flight, then BK selects (as the phases above)
+            R vc[BK];
+#pragma unroll
+            for (int i = 0; i < BK; i++) {
+                const int j = lo + s0 + i;
+                vc[i] = (j >= 1 && j <= N - 2) ? VC[j] : Huge<R>::v * (R)1e-20;   // (squares without overflow)
+            }
+#pragma unroll
+            for (int i = 0; i < BK; i++) cp[s0 + i] = opaque(vmin(cp[s0 + i], vc[i] * vc[i]));
         }
     }
     // boundary state = the last two squared velocities (u, u_prev)
@@ -1499,7 +1518,8 @@ int velocity_relax_max_samples(bool f64) { return f64 ? 512 * 20 : 512 * 40; }
 
 template <typename R, int L, int MAXT, int MINW>
 static void launch_relax_t(hipStream_t st, int B, int S, const double c[6], double sv, double ev,
-                           const double *meta, const void *curv, const void *dth, void *vel, uint32_t *flags)
+                           const double *meta, const void *curv, const void *dth, const void *vcap, void *vel,
+                           uint32_t *flags)
 {
     int T = (S + L - 1) / L;
     T = (T + 63) / 64 * 64;
@@ -1509,8 +1529,12 @@ static void launch_relax_t(hipStream_t st, int B, int S, const double c[6], doub
     long long *stats = nullptr;
     if (want_stats) (void)hipMalloc(&stats, (size_t)B * 8 * sizeof(long long));
     const size_t lds = sizeof(R) * ((size_t)T * L + T + 8);
-    hipLaunchKernelGGL((k_velocity_relax<R, L, MAXT, MINW>), dim3(B), dim3(T), lds, st, S, make_consts<R>(c), s * s,
-                       e * e, meta, (const R *)curv, (const R *)dth, (R *)vel, flags, stats);
+    if (vcap)
+        hipLaunchKernelGGL((k_velocity_relax<R, L, MAXT, MINW, true>), dim3(B), dim3(T), lds, st, S, make_consts<R>(c), s * s,
+                           e * e, meta, (const R *)curv, (const R *)dth, (const R *)vcap, (R *)vel, flags, stats);
+    else
+        hipLaunchKernelGGL((k_velocity_relax<R, L, MAXT, MINW, false>), dim3(B), dim3(T), lds, st, S, make_consts<R>(c), s * s,
+                           e * e, meta, (const R *)curv, (const R *)dth, (const R *)nullptr, (R *)vel, flags, stats);
     if (stats) {
         std::vector<long long> h((size_t)B * 8);
         (void)hipStreamSynchronize(st);
@@ -1529,10 +1553,10 @@ static void launch_relax_t(hipStream_t st, int B, int S, const double c[6], doub
 }
 
 hipError_t launch_velocity_relax(hipStream_t st, bool f64, int B, int S, const double c[6], double sv, double ev,
-                                 const double *meta, const void *curv, const void *dth, void *vel,
+                                 const double *meta, const void *curv, const void *dth, const void *vcap, void *vel,
                                  uint32_t *flags)
 {
-#define VAP_RELAX(R_, L_, MAXT_, W_) launch_relax_t<R_, L_, MAXT_, W_>(st, B, S, c, sv, ev, meta, curv, dth, vel, flags)
+#define VAP_RELAX(R_, L_, MAXT_, W_) launch_relax_t<R_, L_, MAXT_, W_>(st, B, S, c, sv, ev, meta, curv, dth, vcap, vel, flags)
     // chunk length: the longest instantiated L whose thread count still covers the row — fewer, longer
     // chunks mean fewer rounds (rounds ~ longest unclamped run / L) and fewer waves to synchronise
     if (f64) {
