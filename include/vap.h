@@ -142,11 +142,32 @@ int vap_sample(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd, const
  * starts from (MPG:121,127,153,172: node / action-point max_velocity, 0.01 at stops); NULL = the
  * plain-node default max_vel with start/end velocities at the ends.  Entry 0 and the end sample are
  * taken from start_vel / end_vel.  Rows that fit the register-resident relaxation kernel (20 480
- * samples fp32, 10 240 fp64) run there, longer ones in the one-lane sequential sweep. */
+ * samples fp32, 10 240 fp64) run there, longer ones in the one-lane sequential sweep.
+ * d_dtheta NULL = the rows the last vap_profile_batch of this shape left on the context. */
 int vap_velocity_pass(vap_ctx *ctx, vap_dtype dt, int B, int S, const vap_constraints *c,
                       double start_vel, double end_vel, const double *d_meta,
                       const void *d_curvature, const void *d_dtheta, const void *d_vcap,
                       void *d_velocity, uint32_t *d_flags);
+
+/* The `velocities` list forward_backward_pass starts from (MPG:100-176) for B routes whose nodes and
+ * action points carry max_velocity and stop — i.e. d_vcap of vap_velocity_pass — on the distance grid
+ * of the last vap_sample / vap_profile_batch call on this context (same B, W, S).
+ * An event is a node (its parameter is its index, 1 .. W-2) or an action point (its parameter t,
+ * motion_utils ActionPoint); the reference switches its running max_velocity at the first loop sample
+ * whose parameter has reached the event (MPG:125, 141-145) and writes 0.01 there for a stop.
+ *   d_first_max_velocity [B]     node 0's max_velocity (<= 0 or NULL array: max_vel)   MPG:105-106
+ *   d_event_t            [B][E]  parameters, ascending, > 0 (a node before an action point at the same
+ *                                parameter, as the reference processes them); pad with +inf
+ *   d_event_max_velocity [B][E]  <= 0: back to max_vel                                  MPG:129-132, 146-149
+ *   d_event_stop         [B][E]  int32                                                  MPG:126-127, 151-152
+ *   d_vcap               [B][S]  (dtype) out; zero past the end sample
+ *   d_event_sample       [B][E]  int32 out, optional: the sample of each event (INT_MAX: not reached)
+ * d_lut NULL = the table of the last vap_profile_batch.  Per-node max_acceleration, reverse / turn nodes
+ * and waits are not covered here (vap_route_* is the general single-route path). */
+int vap_initial_velocities(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, int E, const double *d_lut,
+                           const double *d_meta, const double *d_first_max_velocity, const double *d_event_t,
+                           const double *d_event_max_velocity, const int *d_event_stop, double max_vel,
+                           double end_vel, void *d_vcap, int *d_event_sample);
 
 /* MPG:413-628, the time-domain resample that generate_motion_profile runs after
  * forward_backward_pass, for B plain-node paths (no turn / wait / reverse nodes and no action points:

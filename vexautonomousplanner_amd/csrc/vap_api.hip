@@ -264,6 +264,10 @@ int vap_sample(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd, const
     HIP_TRY(vap::launch_sample(ctx->stream, dt == VAP_F64, B, W, S, (const double *)ctx->power.ptr, d_lut,
                                (const double *)ctx->slopes.ptr, d_meta, (const double *)ctx->aux.ptr,
                                (const double *)ctx->runs.ptr, d_x, d_y, d_heading, d_curvature, d_dtheta));
+    ctx->grid_B = B;
+    ctx->grid_W = W;
+    ctx->grid_S = S;
+    ctx->dth_valid = false;
     return VAP_OK;
 }
 
@@ -273,7 +277,12 @@ int vap_velocity_pass(vap_ctx *ctx, vap_dtype dt, int B, int S, const vap_constr
 {
     VAP_TRY(vap_set_device(ctx));
     VAP_TRY(check_shape(B, 2, S));
-    if (!c || !d_meta || !d_curvature || !d_dtheta || !d_velocity) return vap_fail(VAP_ERR_INVALID, "null buffer");
+    if (!c || !d_meta || !d_curvature || !d_velocity) return vap_fail(VAP_ERR_INVALID, "null buffer");
+    if (!d_dtheta) {    // the rows the last vap_profile_batch left on the context
+        if (!ctx->dth_valid || ctx->grid_B != B || ctx->grid_S != S || !ctx->dth.ptr)
+            return vap_fail(VAP_ERR_INVALID, "d_dtheta is NULL and the context holds no rows of this shape from vap_profile_batch");
+        d_dtheta = ctx->dth.ptr;
+    }
     // Quirk Q9: boundary_map always holds sample 0 (MPG:110), so the reference overwrites max_dec with
     // max_accels[0] — max_acc for a plain node — before the first forward step (MPG:194-196) and never
     // restores it until the pass returns: the backward sweep decelerates with max_acc.  (The time loop
@@ -342,6 +351,39 @@ int vap_profile_batch(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd
     tm.mark(VAP_T_VELOCITY);
     ctx->last_B = B;
     ctx->last_W = W;
+    ctx->grid_B = B;
+    ctx->grid_W = W;
+    ctx->grid_S = S;
+    ctx->dth_valid = true;
+    return VAP_OK;
+}
+
+int vap_initial_velocities(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, int E, const double *d_lut,
+                           const double *d_meta, const double *d_first_max_velocity, const double *d_event_t,
+                           const double *d_event_max_velocity, const int *d_event_stop, double max_vel, double end_vel,
+                           void *d_vcap, int *d_event_sample)
+{
+    VAP_TRY(vap_set_device(ctx));
+    VAP_TRY(check_shape(B, W, S));
+    if (E < 0 || !d_meta || !d_vcap || !(max_vel > 0)) return vap_fail(VAP_ERR_INVALID, "bad argument");
+    if (E > 0 && (!d_event_t || !d_event_max_velocity || !d_event_stop)) return vap_fail(VAP_ERR_INVALID, "null event array");
+    if (ctx->grid_B != B || ctx->grid_W != W || ctx->grid_S != S || !ctx->runs.ptr || !ctx->aux.ptr)
+        return vap_fail(VAP_ERR_INVALID, "no distance grid of this shape on the context (%d x %d x %d; the last sampling call left %d x %d x %d)",
+                        B, W, S, ctx->grid_B, ctx->grid_W, ctx->grid_S);
+    const double *lut = d_lut;
+    if (!lut) {
+        if (ctx->last_B != B || ctx->last_W != W || !ctx->lut.ptr)
+            return vap_fail(VAP_ERR_INVALID, "d_lut is NULL and the context holds no table of this shape");
+        lut = (const double *)ctx->lut.ptr;
+    }
+    int *ev_k = d_event_sample;
+    if (!ev_k && E > 0) {
+        VAP_TRY(ctx->ensure(ctx->small_out, (size_t)B * E * sizeof(int)));
+        ev_k = (int *)ctx->small_out.ptr;
+    }
+    HIP_TRY(vap::launch_initial_velocities(ctx->stream, dt == VAP_F64, B, W, S, E, lut, d_meta, (const double *)ctx->aux.ptr,
+                                           (const double *)ctx->runs.ptr, d_first_max_velocity, d_event_t,
+                                           d_event_max_velocity, d_event_stop, max_vel, end_vel, ev_k, d_vcap));
     return VAP_OK;
 }
 

@@ -40,6 +40,8 @@ struct vap_ctx {
     VapBuffer seg, power, lut, slopes, aux, runs, meta, dth, flags, io[8], small_in, small_out, small_seg, small_lut;
     VapBuffer ufwd, lstate, lcount;   // long-row velocity pass
     int last_B = 0, last_W = 0;       // shape of the tables the last vap_profile_batch left in seg / lut
+    int grid_B = 0, grid_W = 0, grid_S = 0;   // shape of the distance grids (aux, runs) the last sampling call left
+    bool dth_valid = false;           // ctx->dth holds the |dtheta| rows of that call (the fused call only)
 
     int ensure(VapBuffer &b, size_t bytes)
     {

@@ -59,6 +59,11 @@ hipError_t launch_power(hipStream_t st, int n_seg, const double *seg, double *pw
 hipError_t launch_time_profile(hipStream_t st, bool f64, int B, int W, int S, const double *segments, const double *lut,
                                const double *meta, const void *vel, double max_acc, double max_dec, double dt, int cap,
                                double *rows, int *counts, int *nodes_map, uint32_t *flags);
+// vap_limits.hip: sample of every event (node / action point), then the initial-velocity rows
+hipError_t launch_initial_velocities(hipStream_t st, bool f64, int B, int W, int S, int E, const double *lut,
+                                     const double *meta, const double *aux, const double *runs, const double *first_mv,
+                                     const double *ev_t, const double *ev_mv, const int *ev_stop, double max_vel,
+                                     double end_vel, int *ev_k, void *vcap);
 hipError_t launch_eval(hipStream_t st, int W, const double *seg, double t_max, int order, int n, const double *t,
                        double *out);
 hipError_t launch_lookup(hipStream_t st, int W, const double *seg, double t_max, const double *lut, int what,
