@@ -149,25 +149,42 @@ int vap_velocity_pass(vap_ctx *ctx, vap_dtype dt, int B, int S, const vap_constr
                       const void *d_curvature, const void *d_dtheta, const void *d_vcap,
                       void *d_velocity, uint32_t *d_flags);
 
-/* The `velocities` list forward_backward_pass starts from (MPG:100-176) for B routes whose nodes and
- * action points carry max_velocity and stop — i.e. d_vcap of vap_velocity_pass — on the distance grid
- * of the last vap_sample / vap_profile_batch call on this context (same B, W, S).
- * An event is a node (its parameter is its index, 1 .. W-2) or an action point (its parameter t,
- * motion_utils ActionPoint); the reference switches its running max_velocity at the first loop sample
- * whose parameter has reached the event (MPG:125, 141-145) and writes 0.01 there for a stop.
- *   d_first_max_velocity [B]     node 0's max_velocity (<= 0 or NULL array: max_vel)   MPG:105-106
- *   d_event_t            [B][E]  parameters, ascending, > 0 (a node before an action point at the same
- *                                parameter, as the reference processes them); pad with +inf
- *   d_event_max_velocity [B][E]  <= 0: back to max_vel                                  MPG:129-132, 146-149
- *   d_event_stop         [B][E]  int32                                                  MPG:126-127, 151-152
- *   d_vcap               [B][S]  (dtype) out; zero past the end sample
- *   d_event_sample       [B][E]  int32 out, optional: the sample of each event (INT_MAX: not reached)
- * d_lut NULL = the table of the last vap_profile_batch.  Per-node max_acceleration, reverse / turn nodes
- * and waits are not covered here (vap_route_* is the general single-route path). */
-int vap_initial_velocities(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, int E, const double *d_lut,
-                           const double *d_meta, const double *d_first_max_velocity, const double *d_event_t,
-                           const double *d_event_max_velocity, const int *d_event_stop, double max_vel,
-                           double end_vel, void *d_vcap, int *d_event_sample);
+/* Per-sample limits of forward_backward_pass (MPG:100-176, 194-196, 256-257) for B routes whose nodes and
+ * action points carry max_velocity, max_acceleration and stop, on the distance grid of the last
+ * vap_sample / vap_profile_batch call on this context (same B, W, S):
+ *   d_vcap          the `velocities` list the pass starts from (running max_velocity, 0.01 at stops,
+ *                   end_vel at the end sample)
+ *   d_acc_forward   max_acc (= max_dec) in force for the forward step from each sample  (boundary_map /
+ *   d_acc_backward  max_acc the backward sweep has in force for its step from each sample  max_accels,
+ *   d_dec_backward  [B] max_dec of the backward sweep: what the forward sweep left behind   incl. their quirks)
+ * An event is a node (its parameter is its index, 1 .. W-2) or an action point (its parameter t); the
+ * reference acts on it at the first loop sample whose parameter has reached it (MPG:125, 141-145).
+ *   d_first_max_velocity / d_first_max_acceleration [B]   node 0's (<= 0 or NULL array: the constraints')
+ *   d_event_t                [B][E]  parameters, ascending, > 0 (a node before an action point at the same
+ *                                    parameter, as the reference processes them); pad with +inf
+ *   d_event_max_velocity     [B][E]  <= 0: back to max_vel                               MPG:129-132, 146-149
+ *   d_event_max_acceleration [B][E]  <= 0: max_acc; NULL array: none                     MPG:134-137, 155-160
+ *   d_event_stop             [B][E]  int32                                               MPG:126-127, 151-152
+ *   d_vcap, d_acc_forward, d_acc_backward [B][S] (dtype) out; the three acceleration outputs are optional
+ *                                    as a set (routes that do not change max_acceleration need only d_vcap)
+ *   d_event_sample           [B][E]  int32 out, optional: the sample of each event (INT_MAX: not reached)
+ * d_lut NULL = the table of the last vap_profile_batch.  Reverse / turn nodes and waits are not covered
+ * here (vap_route_* is the general single-route path). */
+int vap_route_limits(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, int E, const double *d_lut,
+                     const double *d_meta, const double *d_first_max_velocity,
+                     const double *d_first_max_acceleration, const double *d_event_t,
+                     const double *d_event_max_velocity, const double *d_event_max_acceleration,
+                     const int *d_event_stop, const vap_constraints *c, double end_vel, void *d_vcap,
+                     void *d_acc_forward, void *d_acc_backward, void *d_dec_backward, int *d_event_sample);
+
+/* vap_velocity_pass with the limit rows of vap_route_limits (the three acceleration arguments NULL, or
+ * all set together with d_vcap).  With acceleration rows the register-resident kernel covers rows up to
+ * 10 240 samples (fp32) / 4096 (fp64); longer rows take the sequential sweep. */
+int vap_velocity_pass_limits(vap_ctx *ctx, vap_dtype dt, int B, int S, const vap_constraints *c,
+                             double start_vel, double end_vel, const double *d_meta,
+                             const void *d_curvature, const void *d_dtheta, const void *d_vcap,
+                             const void *d_acc_forward, const void *d_acc_backward,
+                             const void *d_dec_backward, void *d_velocity, uint32_t *d_flags);
 
 /* MPG:413-628, the time-domain resample that generate_motion_profile runs after
  * forward_backward_pass, for B plain-node paths (no turn / wait / reverse nodes and no action points:

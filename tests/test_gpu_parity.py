@@ -322,6 +322,128 @@ def test_apply_node_limits_vs_oracle(torch_mod, gens, dtype, tol, use_dd):
     assert (r["velocity"] < plain * 0.9).any().item()
 
 
+def _apply_golden_limits(torch_mod, gen, g):
+    """profile() + apply_node_limits() for a golden route fixture (node / action-point limits, no splits)."""
+    N = int(g["n_samples"])
+    W = len(g["waypoints"])
+    wp = torch_mod.tensor(g["waypoints"][None], dtype=gen.tdtype, device=gen.device)
+    r = gen.profile(wp, g["constraints"], dd=float(g["dd"]), capacity=N + 9)
+    aps = None
+    if "ap_t" in g.files:
+        aps = [[{"t": float(t), "max_velocity": float(mv), "max_acceleration": float(ma), "stop": bool(st)}
+                for t, mv, ma, st in zip(g["ap_t"], g["ap_max_velocity"], g["ap_max_acceleration"], g["ap_stop"])]]
+    gen.apply_node_limits(r, g["constraints"], node_max_velocity=g["node_max_velocity"][None], node_stop=g["node_stop"][None],
+                          node_max_acceleration=g["node_max_acceleration"][None], action_points=aps)
+    torch_mod.cuda.synchronize()
+    assert int(r["meta"][0, 3]) == N and int(r["flags"][0]) == 0
+    return r["velocity"][0, :N].cpu().numpy().astype(np.float64)
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-5), ("f64", 1e-9)])
+@pytest.mark.parametrize("name", ["feat_limits", "feat_action", "feat_stop"])
+def test_apply_node_limits_vs_reference_golden(torch_mod, gens, name, dtype, tol):
+    """Golden routes of the real reference with node max_velocity / max_acceleration (feat_limits), action points
+    with max_velocity / max_acceleration / stop (feat_action; its wait only concerns the time domain) and a stop
+    node: forward_backward_pass through the batched path (boundary_map / max_accels quirks included)."""
+    g = gu.load(name)
+    assert not g["node_is_reverse_node"].any() and not g["node_turn"].any()
+    v = _apply_golden_limits(torch_mod, gens[dtype], g)
+    err = np.max(np.abs(v - g["grid_velocity"]) / g["grid_velocity"])
+    print(f"{name}/{dtype}: velocity max rel err {err:.2e}")
+    assert err <= tol
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-5), ("f64", 1e-9)])
+def test_apply_node_limits_with_accelerations_vs_oracle(torch_mod, gens, dtype, tol):
+    """Random routes with every limit a node or action point can carry (max_velocity, max_acceleration, stop), incl.
+    an action point on a node's sample (it replaces the node's boundary_map entry, MPG:162) — against the oracle."""
+    from oracle import oracle
+    from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
+    rng = np.random.default_rng(77)
+    B, W, dd = 8, 8, 0.005
+    wp = make_waypoints(B, W, 91).astype(np.float64)
+    gen = gens[dtype]
+    mv = np.where(rng.random((B, W)) < 0.3, rng.uniform(1.0, 3.5, (B, W)), 0.0)
+    ma = np.where(rng.random((B, W)) < 0.4, rng.uniform(2.0, 12.0, (B, W)), 0.0)
+    stop = rng.random((B, W)) < 0.2
+    stop[:, 0] = stop[:, -1] = False
+    aps = []
+    for b in range(B):
+        ts = np.sort(rng.uniform(0.2, W - 1.2, size=int(rng.integers(0, 4))))
+        aps.append([{"t": float(t), "max_velocity": float(rng.uniform(1.0, 3.0)) if rng.random() < 0.5 else 0.0,
+                     "max_acceleration": float(rng.uniform(2.0, 10.0)) if rng.random() < 0.6 else 0.0,
+                     "stop": bool(rng.random() < 0.3)} for t in ts])
+    aps[0] = [{"t": 3.0, "max_velocity": 0.0, "max_acceleration": 3.0, "stop": False}]     # on node 3's sample
+    ma[0, 3] = 9.0
+    ma[1, 0], ma[1, 2], ma[2, 4] = 30.0, 40.0, 25.0   # far above max_acc: max_angular_accel/|k| (MPG:222) binds in curves
+    refs = []
+    for b in range(B):
+        nodes = dict(is_reverse=np.zeros(W), turn=np.zeros(W), stop=stop[b].astype(float), wait_time=np.zeros(W),
+                     max_velocity=mv[b], max_acceleration=ma[b], tangent=np.full((W, 2), np.nan), magnitudes=np.zeros((W, 2)))
+        actions = None
+        if aps[b]:
+            actions = dict(t=np.array([a["t"] for a in aps[b]]), stop=np.array([float(a["stop"]) for a in aps[b]]),
+                           wait_time=np.zeros(len(aps[b])), max_velocity=np.array([a["max_velocity"] for a in aps[b]]),
+                           max_acceleration=np.array([a["max_acceleration"] for a in aps[b]]))
+        op = oracle.OraclePath(wp[b], nodes=nodes, actions=actions)
+        op.rebuild_tables()
+        refs.append(op.forward_backward(DEFAULT_CONSTRAINTS, dd=dd)["velocity"])
+    t = torch_mod.tensor(wp, dtype=gen.tdtype, device=gen.device)
+    r = gen.profile(t, DEFAULT_CONSTRAINTS, dd=dd, capacity=max(len(v) for v in refs) + 4)
+    gen.apply_node_limits(r, DEFAULT_CONSTRAINTS, node_max_velocity=mv, node_stop=stop, node_max_acceleration=ma, action_points=aps)
+    torch_mod.cuda.synchronize()
+    assert not r["flags"].any().item()
+    got = r["velocity"].cpu().numpy().astype(np.float64)
+    for b in range(B):
+        N = len(refs[b])
+        assert int(r["meta"][b, 3]) == N
+        err = np.max(np.abs(got[b, :N] - refs[b]) / refs[b])
+        assert err <= tol, (b, err)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("S", [200, 3000, 9000])
+def test_acceleration_rows_relaxation_equals_sequential_sweep(torch_mod, dtype, S):
+    """vap_velocity_pass_limits with per-sample max_acceleration rows: the relaxation kernel against the one-lane
+    sequential sweep, bit for bit (fp64 rows beyond the relaxation kernel's reach take the sweep in both)."""
+    import ctypes as C
+    from vexautonomousplanner_amd import _lib
+    from vexautonomousplanner_amd.batch import BatchedTrajectoryGenerator
+    from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
+    torch = torch_mod
+    rng = np.random.default_rng(S)
+    B, W = 5, 8
+    gen = BatchedTrajectoryGenerator(0, dtype)
+    wp = torch.tensor(make_waypoints(B, W, 13), dtype=gen.tdtype, device=gen.device)
+    r = gen.profile(wp, DEFAULT_CONSTRAINTS, samples=S)
+
+    def steps(lo, hi):
+        out = np.empty((B, S))
+        for b in range(B):
+            edges = np.sort(rng.integers(1, S - 1, size=4))
+            out[b] = rng.uniform(lo, hi, size=5)[np.searchsorted(edges, np.arange(S), side="right")]
+        return out
+    rows = {"vcap": steps(1.0, 4.0), "af": steps(2.0, 12.0), "ab": steps(2.0, 12.0)}
+    dec = rng.uniform(3.0, 10.0, size=B)
+    d = {k: torch.tensor(v, dtype=gen.tdtype, device=gen.device) for k, v in rows.items()}
+    d_dec = torch.tensor(dec, dtype=gen.tdtype, device=gen.device)
+    c = _lib.make_constraints(DEFAULT_CONSTRAINTS)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    out = {}
+    for kernel in (_lib.VELOCITY_SEQ_FAST, _lib.VELOCITY_AUTO, _lib.VELOCITY_SEQ_LITERAL):
+        gen.ctx.set_option(_lib.OPT_VELOCITY_KERNEL, kernel)
+        v = torch.empty((B, S), dtype=gen.tdtype, device=gen.device)
+        _lib.check(gen._L.vap_velocity_pass_limits(gen.ctx.handle, gen.vdtype, B, S, C.byref(c), 0.01, 0.01, p(r["meta"]), p(r["curvature"]),
+                                                   None, p(d["vcap"]), p(d["af"]), p(d["ab"]), p(d_dec), p(v), p(r["flags"])), "limits")
+        torch.cuda.synchronize()
+        out[kernel] = v.cpu().numpy().astype(np.float64)
+    assert np.array_equal(out[_lib.VELOCITY_SEQ_FAST], out[_lib.VELOCITY_AUTO])
+    lit = out[_lib.VELOCITY_SEQ_LITERAL]
+    tol = 3e-5 if dtype == "f32" else 1e-9
+    assert np.max(np.abs(out[_lib.VELOCITY_AUTO] - lit) / lit) <= tol
+    assert not r["flags"].any().item()
+
+
 @pytest.mark.parametrize("dtype,tol", [("f32", 1e-5), ("f64", 1e-9)])
 @pytest.mark.parametrize("B,W,S,seed", [(64, 8, 1024, 5), (48, 32, 2000, 3), (3, 2, 300, 9), (5, 5, 257, 10)])
 def test_batch_vs_oracle(torch_mod, gens, B, W, S, seed, dtype, tol):

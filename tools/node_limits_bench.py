@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Developer tool (GPU box): cost of node limits on a config-3 batch — vap_initial_velocities + the velocity pass with
+"""Developer tool (GPU box): cost of node limits on a config-3 batch — vap_route_limits + the velocity pass with
 per-sample initial velocities (relaxation kernel), against the plain velocity stage."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -27,7 +27,7 @@ for _ in range(5):
     gen.apply_node_limits(r, DEFAULT_CONSTRAINTS, node_max_velocity=mv, node_stop=stop)
 ev[1].record()
 torch.cuda.synchronize()
-print(f"apply_node_limits (host event packing + vap_initial_velocities + velocity pass with limits): {ev[0].elapsed_time(ev[1]) / 5:.3f} ms per call")
+print(f"apply_node_limits (host event packing + vap_route_limits + velocity pass with limits): {ev[0].elapsed_time(ev[1]) / 5:.3f} ms per call")
 # device part alone: the two C calls on prepared event tensors
 import ctypes as C
 from vexautonomousplanner_amd import _lib
@@ -41,12 +41,12 @@ vcap = torch.empty((B, S), dtype=torch.float32, device="cuda:0")
 c = _lib.make_constraints(DEFAULT_CONSTRAINTS)
 p = lambda t: C.c_void_p(t.data_ptr())
 def dev_calls():
-    _lib.check(L.vap_initial_velocities(gen.ctx.handle, _lib.VAP_F32, B, W, S, E, None, p(r["meta"]), p(d_first), p(d_t), p(d_mv), p(d_stop),
-                                        4.0, 0.01, p(vcap), None), "iv")
+    _lib.check(L.vap_route_limits(gen.ctx.handle, _lib.VAP_F32, B, W, S, E, None, p(r["meta"]), p(d_first), None, p(d_t), p(d_mv), None, p(d_stop),
+                                  C.byref(c), 0.01, p(vcap), None, None, None, None), "limits")
 def vel_call():
     _lib.check(L.vap_velocity_pass(gen.ctx.handle, _lib.VAP_F32, B, S, C.byref(c), 0.01, 0.01, p(r["meta"]), p(r["curvature"]), None, p(vcap),
                                    p(r["velocity"]), p(r["flags"])), "vel")
-for name, fn in (("vap_initial_velocities", dev_calls), ("vap_velocity_pass with limits", vel_call)):
+for name, fn in (("vap_route_limits", dev_calls), ("vap_velocity_pass with limits", vel_call)):
     fn(); torch.cuda.synchronize()
     ev[0].record()
     for _ in range(10):

@@ -38,7 +38,7 @@ EXPORTS = (
     "vap_time_profile", "vap_profile_batch", "vap_profile_batch_host", "vap_eval_host", "vap_lookup_host",
     "vap_route_create", "vap_route_destroy", "vap_route_info", "vap_route_get_splines", "vap_route_eval",
     "vap_route_lookup", "vap_route_sample_count", "vap_route_forward_backward", "vap_route_motion_profile",
-    "vap_grid_distances", "vap_initial_velocities",
+    "vap_grid_distances", "vap_route_limits", "vap_velocity_pass_limits",
 )
 
 
@@ -112,8 +112,10 @@ def lib():
     L.vap_profile_batch_host.argtypes = L.vap_profile_batch.argtypes
     L.vap_time_profile.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp,
                                    C.POINTER(Constraints), C.c_double, C.c_int, vp, vp, vp, vp]
-    L.vap_initial_velocities.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp,
-                                         C.c_double, C.c_double, vp, vp]
+    L.vap_route_limits.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp,
+                                   C.POINTER(Constraints), C.c_double, vp, vp, vp, vp, vp]
+    L.vap_velocity_pass_limits.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(Constraints), C.c_double, C.c_double,
+                                           vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.vap_eval_host.argtypes = [vp, C.c_int, dp, C.c_double, C.c_int, C.c_int, dp, dp]
     L.vap_lookup_host.argtypes = [vp, C.c_int, dp, C.c_double, dp, C.c_int, C.c_int, dp, dp]
     lp = C.POINTER(C.c_long)

@@ -133,36 +133,41 @@ class BatchedTrajectoryGenerator:
         return res
 
     def apply_node_limits(self, result, constraints=DEFAULT_CONSTRAINTS, node_max_velocity=None, node_stop=None,
-                          action_points=None, start_vel=START_VEL, end_vel=END_VEL):
-        """Routes whose nodes / action points carry ``max_velocity`` and ``stop`` (motion_utils Node / ActionPoint;
-        MPG:100-176): recompute the velocity rows of the batch ``profile`` has just produced with this generator
-        under those limits.  The geometry rows (x, y, heading, curvature) do not depend on them.
+                          node_max_acceleration=None, action_points=None, start_vel=START_VEL, end_vel=END_VEL):
+        """Routes whose nodes / action points carry ``max_velocity``, ``max_acceleration`` and ``stop``
+        (motion_utils Node / ActionPoint; MPG:100-176, 194-196, 256-257): recompute the velocity rows of the
+        batch ``profile`` has just produced with this generator under those limits.  The geometry rows (x, y,
+        heading, curvature) do not depend on them.
 
-          node_max_velocity  (B, W) array-like, 0 = none            node_stop  (B, W) array-like of bool
-          action_points      optional list (per path) of lists of dicts {"t", "max_velocity", "stop"}
+          node_max_velocity, node_max_acceleration  (B, W) array-like, 0 = none
+          node_stop                                 (B, W) array-like of bool
+          action_points  optional list (per path) of lists of dicts {"t", "max_velocity", "max_acceleration", "stop"}
         Returns ``result`` with "velocity" replaced, plus "vcap" (the reference's initial velocity list per
         sample) and "event_sample" (the sample at which each node 1..W-2 and action point takes effect).
-        Per-node max_acceleration, reverse / turn nodes and waits change more than the limits: those routes go
-        through the drop-in classes (vap_route_*)."""
+        Reverse / turn nodes and waits change more than the limits: those routes go through the drop-in classes
+        (vap_route_*)."""
         vel, meta = result["velocity"], result["meta"]
         B, S = vel.shape
         last = getattr(self, "_last_shape", None)
         if last is None or (last[0], last[2]) != (B, S):
             raise ValueError("apply_node_limits needs the result of this generator's last profile() call")
         W = last[1]
-        mv = np.zeros((B, W)) if node_max_velocity is None else np.asarray(node_max_velocity, dtype=np.float64).reshape(B, W)
+        as2d = lambda a: np.zeros((B, W)) if a is None else np.asarray(a, dtype=np.float64).reshape(B, W)
+        mv, ma = as2d(node_max_velocity), as2d(node_max_acceleration)
         stop = np.zeros((B, W), dtype=bool) if node_stop is None else np.asarray(node_stop).astype(bool).reshape(B, W)
         aps = action_points if action_points is not None else None
         n_ap = max((len(a) for a in aps), default=0) if aps is not None else 0
         n_node = max(W - 2, 0)
         E = n_node + n_ap
-        ev_t = np.full((B, max(E, 1)), np.inf)
-        ev_mv = np.zeros((B, max(E, 1)))
-        ev_stop = np.zeros((B, max(E, 1)), dtype=np.int32)
-        kind = np.zeros((B, max(E, 1)), dtype=np.int8)       # 0 node, 1 action point
+        shape = (B, max(E, 1))
+        ev_t = np.full(shape, np.inf)
+        ev_mv, ev_ma = np.zeros(shape), np.zeros(shape)
+        ev_stop = np.zeros(shape, dtype=np.int32)
+        kind = np.zeros(shape, dtype=np.int8)       # 0 node, 1 action point
         if n_node:
             ev_t[:, :n_node] = np.arange(1, W - 1, dtype=np.float64)
             ev_mv[:, :n_node] = mv[:, 1:W - 1]
+            ev_ma[:, :n_node] = ma[:, 1:W - 1]
             ev_stop[:, :n_node] = stop[:, 1:W - 1]
         if n_ap:
             kind[:, n_node:] = 1
@@ -173,31 +178,35 @@ class BatchedTrajectoryGenerator:
                         raise ValueError("action point parameters must be > 0 (the reference never reaches t <= 0, MPG:141-145)")
                     ev_t[b, n_node + i] = t
                     ev_mv[b, n_node + i] = float(a.get("max_velocity", 0.0))
+                    ev_ma[b, n_node + i] = float(a.get("max_acceleration", 0.0))
                     ev_stop[b, n_node + i] = int(bool(a.get("stop", False)))
             # ascending parameter, a node before an action point at the same parameter (MPG:125 then 141)
             order = np.lexsort((kind, ev_t), axis=1)
-            ev_t = np.take_along_axis(ev_t, order, axis=1)
-            ev_mv = np.take_along_axis(ev_mv, order, axis=1)
-            ev_stop = np.take_along_axis(ev_stop, order, axis=1)
+            ev_t, ev_mv, ev_ma, ev_stop = (np.take_along_axis(a, order, axis=1) for a in (ev_t, ev_mv, ev_ma, ev_stop))
+        with_acc = bool((ma > 0).any() or (ev_ma > 0).any())
         dev = self.device
-        d_t = torch.tensor(ev_t, device=dev)
-        d_mv = torch.tensor(ev_mv, device=dev)
-        d_stop = torch.tensor(ev_stop, device=dev)
-        d_first = torch.tensor(mv[:, 0].copy(), device=dev)
+        d_t, d_mv, d_ma, d_stop = (torch.tensor(a, device=dev) for a in (ev_t, ev_mv, ev_ma, ev_stop))
+        d_first_mv = torch.tensor(mv[:, 0].copy(), device=dev)
+        d_first_ma = torch.tensor(ma[:, 0].copy(), device=dev)
         vcap = torch.empty((B, S), dtype=self.tdtype, device=dev)
-        ev_k = torch.empty((B, max(E, 1)), dtype=torch.int32, device=dev)
+        acc_f = torch.empty((B, S), dtype=self.tdtype, device=dev) if with_acc else None
+        acc_b = torch.empty((B, S), dtype=self.tdtype, device=dev) if with_acc else None
+        dec_b = torch.empty((B,), dtype=self.tdtype, device=dev) if with_acc else None
+        ev_k = torch.empty(shape, dtype=torch.int32, device=dev)
         c = _lib.make_constraints(constraints)
         self.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-        ptr = lambda t: C.c_void_p(t.data_ptr())
-        _lib.check(self._L.vap_initial_velocities(self.ctx.handle, self.vdtype, B, W, S, E, None, ptr(meta), ptr(d_first),
-                                                  ptr(d_t), ptr(d_mv), ptr(d_stop), float(c.max_vel), float(end_vel),
-                                                  ptr(vcap), ptr(ev_k)), "vap_initial_velocities")
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        _lib.check(self._L.vap_route_limits(self.ctx.handle, self.vdtype, B, W, S, E, None, ptr(meta), ptr(d_first_mv),
+                                            ptr(d_first_ma), ptr(d_t), ptr(d_mv), ptr(d_ma), ptr(d_stop), C.byref(c),
+                                            float(end_vel), ptr(vcap), ptr(acc_f), ptr(acc_b), ptr(dec_b), ptr(ev_k)),
+                   "vap_route_limits")
         curv = result.get("curvature")
         if curv is None:
             raise ValueError("apply_node_limits needs the curvature rows (profile(want=...) must include 'curvature')")
-        _lib.check(self._L.vap_velocity_pass(self.ctx.handle, self.vdtype, B, S, C.byref(c), float(start_vel), float(end_vel),
-                                             ptr(meta), ptr(curv), None, ptr(vcap), ptr(vel), ptr(result["flags"])),
-                   "vap_velocity_pass")
+        _lib.check(self._L.vap_velocity_pass_limits(self.ctx.handle, self.vdtype, B, S, C.byref(c), float(start_vel),
+                                                    float(end_vel), ptr(meta), ptr(curv), None, ptr(vcap), ptr(acc_f),
+                                                    ptr(acc_b), ptr(dec_b), ptr(vel), ptr(result["flags"])),
+                   "vap_velocity_pass_limits")
         result["vcap"] = vcap
         result["event_sample"] = ev_k[:, :E]
         return result

@@ -59,19 +59,20 @@ int check_shape(int B, int W, int S)
 
 // K5 dispatch.  auto: register-resident relaxation whenever the row fits, else the sequential sweep.
 int run_velocity(vap_ctx *ctx, bool f64, int B, int S, const double cc[6], double sv, double ev, const double *meta,
-                 const void *curv, const void *dth, const void *vcap, void *vel, uint32_t *flags)
+                 const void *curv, const void *dth, const void *vcap, const vap::AccRowsV &acc, void *vel, uint32_t *flags)
 {
     int mode = ctx->velocity_kernel;
     // per-sample initial velocities: the register-resident relaxation kernel takes them, the two-level one for
     // long rows and the wave-per-path variant do not (the sequential sweep does)
+    const int relax_limit = acc.fwd ? vap::velocity_relax_acc_max_samples(f64) : vap::velocity_relax_max_samples(f64);
     if (mode == VAP_VELOCITY_AUTO)
-        mode = (vcap && S > vap::velocity_relax_max_samples(f64)) ? VAP_VELOCITY_SEQ_FAST : VAP_VELOCITY_RELAX;
+        mode = (vcap && S > relax_limit) ? VAP_VELOCITY_SEQ_FAST : VAP_VELOCITY_RELAX;
     const int forced = mode;
     if (mode == VAP_VELOCITY_RELAX_BLOCK || mode == VAP_VELOCITY_RELAX_WAVE) mode = VAP_VELOCITY_RELAX;
     if (mode == VAP_VELOCITY_RELAX) {
-        if (vcap && (forced == VAP_VELOCITY_RELAX_WAVE || S > vap::velocity_relax_max_samples(f64)))
-            return vap_fail(VAP_ERR_UNSUPPORTED, "per-sample initial velocities: rows up to %d samples in the relaxation kernel, or the sequential sweep",
-                            vap::velocity_relax_max_samples(f64));
+        if (vcap && (forced == VAP_VELOCITY_RELAX_WAVE || S > relax_limit))
+            return vap_fail(VAP_ERR_UNSUPPORTED, "per-sample limits: rows up to %d samples in the relaxation kernel, or the sequential sweep",
+                            relax_limit);
         if (forced == VAP_VELOCITY_RELAX_WAVE && (f64 || S > vap::velocity_relax_max_samples(f64)))
             return vap_fail(VAP_ERR_UNSUPPORTED, "wave-per-path kernel: fp32 rows up to %d samples", vap::velocity_relax_max_samples(false));
         // One wave per path (sequential windows) keeps 8 paths resident per CU instead of 2, but measured
@@ -86,7 +87,7 @@ int run_velocity(vap_ctx *ctx, bool f64, int B, int S, const double cc[6], doubl
             HIP_TRY(vap::launch_velocity_windows(ctx->stream, B, S, cc, sv, ev, meta, curv, dth, vel, flags, ctx->ufwd.ptr,
                                                  ctx->lstate.ptr, (int *)ctx->lcount.ptr));
         } else if (S <= vap::velocity_relax_max_samples(f64)) {
-            HIP_TRY(vap::launch_velocity_relax(ctx->stream, f64, B, S, cc, sv, ev, meta, curv, dth, vcap, vel, flags));
+            HIP_TRY(vap::launch_velocity_relax(ctx->stream, f64, B, S, cc, sv, ev, meta, curv, dth, vcap, acc, vel, flags));
         } else {
             // long rows: two-level relaxation (host-synchronised super-rounds)
             VAP_TRY(ctx->ensure(ctx->ufwd, (size_t)B * S * (f64 ? 8 : 4)));
@@ -97,7 +98,7 @@ int run_velocity(vap_ctx *ctx, bool f64, int B, int S, const double cc[6], doubl
         }
     } else {
         HIP_TRY(vap::launch_velocity_seq(ctx->stream, f64, mode == VAP_VELOCITY_SEQ_FAST, B, S, cc, sv, ev, meta, curv,
-                                         dth, vcap, vel));
+                                         dth, vcap, acc, vel));
     }
     return VAP_OK;
 }
@@ -271,13 +272,17 @@ int vap_sample(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd, const
     return VAP_OK;
 }
 
-int vap_velocity_pass(vap_ctx *ctx, vap_dtype dt, int B, int S, const vap_constraints *c, double start_vel,
-                      double end_vel, const double *d_meta, const void *d_curvature, const void *d_dtheta,
-                      const void *d_vcap, void *d_velocity, uint32_t *d_flags)
+int vap_velocity_pass_limits(vap_ctx *ctx, vap_dtype dt, int B, int S, const vap_constraints *c, double start_vel,
+                             double end_vel, const double *d_meta, const void *d_curvature, const void *d_dtheta,
+                             const void *d_vcap, const void *d_acc_forward, const void *d_acc_backward,
+                             const void *d_dec_backward, void *d_velocity, uint32_t *d_flags)
 {
     VAP_TRY(vap_set_device(ctx));
     VAP_TRY(check_shape(B, 2, S));
     if (!c || !d_meta || !d_curvature || !d_velocity) return vap_fail(VAP_ERR_INVALID, "null buffer");
+    const bool any_acc = d_acc_forward || d_acc_backward || d_dec_backward;
+    if (any_acc && !(d_acc_forward && d_acc_backward && d_dec_backward && d_vcap))
+        return vap_fail(VAP_ERR_INVALID, "max_acceleration rows come as a set (forward, backward, dec) together with d_vcap");
     if (!d_dtheta) {    // the rows the last vap_profile_batch left on the context
         if (!ctx->dth_valid || ctx->grid_B != B || ctx->grid_S != S || !ctx->dth.ptr)
             return vap_fail(VAP_ERR_INVALID, "d_dtheta is NULL and the context holds no rows of this shape from vap_profile_batch");
@@ -288,9 +293,21 @@ int vap_velocity_pass(vap_ctx *ctx, vap_dtype dt, int B, int S, const vap_constr
     // restores it until the pass returns: the backward sweep decelerates with max_acc.  (The time loop
     // does see the caller's max_dec, MPG:572-573 — vap_time_profile.)
     const double cc[6] = {c->max_vel, c->max_acc, c->max_acc, c->friction_coef, c->max_jerk, c->track_width};
-    VAP_TRY(run_velocity(ctx, dt == VAP_F64, B, S, cc, start_vel, end_vel, d_meta, d_curvature, d_dtheta, d_vcap,
+    vap::AccRowsV acc;
+    acc.fwd = d_acc_forward;
+    acc.bwd = d_acc_backward;
+    acc.dec = d_dec_backward;
+    VAP_TRY(run_velocity(ctx, dt == VAP_F64, B, S, cc, start_vel, end_vel, d_meta, d_curvature, d_dtheta, d_vcap, acc,
                          d_velocity, d_flags));
     return VAP_OK;
+}
+
+int vap_velocity_pass(vap_ctx *ctx, vap_dtype dt, int B, int S, const vap_constraints *c, double start_vel,
+                      double end_vel, const double *d_meta, const void *d_curvature, const void *d_dtheta,
+                      const void *d_vcap, void *d_velocity, uint32_t *d_flags)
+{
+    return vap_velocity_pass_limits(ctx, dt, B, S, c, start_vel, end_vel, d_meta, d_curvature, d_dtheta, d_vcap, nullptr,
+                                    nullptr, nullptr, d_velocity, d_flags);
 }
 
 int vap_profile_batch(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd, const void *d_waypoints,
@@ -346,7 +363,7 @@ int vap_profile_batch(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd
                                (const double *)ctx->aux.ptr, (const double *)ctx->runs.ptr, d_x, d_y, d_heading, curv,
                                ctx->dth.ptr));
     tm.mark(VAP_T_SAMPLE);
-    VAP_TRY(run_velocity(ctx, f64, B, S, cc, start_vel, end_vel, meta, curv, ctx->dth.ptr, nullptr, d_velocity,
+    VAP_TRY(run_velocity(ctx, f64, B, S, cc, start_vel, end_vel, meta, curv, ctx->dth.ptr, nullptr, vap::AccRowsV(), d_velocity,
                          flags));
     tm.mark(VAP_T_VELOCITY);
     ctx->last_B = B;
@@ -358,15 +375,19 @@ int vap_profile_batch(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd
     return VAP_OK;
 }
 
-int vap_initial_velocities(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, int E, const double *d_lut,
-                           const double *d_meta, const double *d_first_max_velocity, const double *d_event_t,
-                           const double *d_event_max_velocity, const int *d_event_stop, double max_vel, double end_vel,
-                           void *d_vcap, int *d_event_sample)
+int vap_route_limits(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, int E, const double *d_lut, const double *d_meta,
+                     const double *d_first_max_velocity, const double *d_first_max_acceleration, const double *d_event_t,
+                     const double *d_event_max_velocity, const double *d_event_max_acceleration, const int *d_event_stop,
+                     const vap_constraints *c, double end_vel, void *d_vcap, void *d_acc_forward, void *d_acc_backward,
+                     void *d_dec_backward, int *d_event_sample)
 {
     VAP_TRY(vap_set_device(ctx));
     VAP_TRY(check_shape(B, W, S));
-    if (E < 0 || !d_meta || !d_vcap || !(max_vel > 0)) return vap_fail(VAP_ERR_INVALID, "bad argument");
+    if (E < 0 || !d_meta || !d_vcap || !c || !(c->max_vel > 0) || !(c->max_acc > 0)) return vap_fail(VAP_ERR_INVALID, "bad argument");
     if (E > 0 && (!d_event_t || !d_event_max_velocity || !d_event_stop)) return vap_fail(VAP_ERR_INVALID, "null event array");
+    const bool any_acc = d_acc_forward || d_acc_backward || d_dec_backward;
+    if (any_acc && !(d_acc_forward && d_acc_backward && d_dec_backward))
+        return vap_fail(VAP_ERR_INVALID, "the max_acceleration outputs come as a set (forward, backward, dec)");
     if (ctx->grid_B != B || ctx->grid_W != W || ctx->grid_S != S || !ctx->runs.ptr || !ctx->aux.ptr)
         return vap_fail(VAP_ERR_INVALID, "no distance grid of this shape on the context (%d x %d x %d; the last sampling call left %d x %d x %d)",
                         B, W, S, ctx->grid_B, ctx->grid_W, ctx->grid_S);
@@ -381,9 +402,19 @@ int vap_initial_velocities(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, int 
         VAP_TRY(ctx->ensure(ctx->small_out, (size_t)B * E * sizeof(int)));
         ev_k = (int *)ctx->small_out.ptr;
     }
-    HIP_TRY(vap::launch_initial_velocities(ctx->stream, dt == VAP_F64, B, W, S, E, lut, d_meta, (const double *)ctx->aux.ptr,
-                                           (const double *)ctx->runs.ptr, d_first_max_velocity, d_event_t,
-                                           d_event_max_velocity, d_event_stop, max_vel, end_vel, ev_k, d_vcap));
+    vap::LimitInputs in;
+    in.first_mv = d_first_max_velocity;
+    in.first_ma = d_first_max_acceleration;
+    in.ev_t = d_event_t;
+    in.ev_mv = d_event_max_velocity;
+    in.ev_ma = d_event_max_acceleration;
+    in.ev_stop = d_event_stop;
+    in.max_vel = c->max_vel;
+    in.max_acc = c->max_acc;
+    in.end_vel = end_vel;
+    HIP_TRY(vap::launch_route_limits(ctx->stream, dt == VAP_F64, B, W, S, E, lut, d_meta, (const double *)ctx->aux.ptr,
+                                     (const double *)ctx->runs.ptr, in, ev_k, d_vcap, d_acc_forward, d_acc_backward,
+                                     d_dec_backward));
     return VAP_OK;
 }
 

@@ -414,6 +414,7 @@ struct FastConsts {
     R adecp;   // 2*dd*max_dec
     R h;       // track_width/2
     R gk;      // 2*dd*track_width/4
+    R aangp;   // 2*dd*max_angular_accel = 2*dd * 2*max_acc/track_width (MPG:82, the constraints' max_acc)
 };
 
 template <typename R>
@@ -425,6 +426,7 @@ __device__ __forceinline__ FastConsts<R> make_fast(const VelConsts<R> &c, R twod
     f.adecp = twodd * c.adec;
     f.h = c.tw / (R)2;
     f.gk = twodd * c.tw / (R)4;
+    f.aangp = twodd * c.almax;
     return f;
 }
 
@@ -468,6 +470,16 @@ __device__ __forceinline__ void fast_derive_k(const FastConsts<R> &c, R kabs, R 
     R x = opaque(qp * fast_rcp(q));
     x = qp == q ? (R)1 : x;
     rho = straight ? (R)0 : x;
+}
+
+// Routes whose nodes raise max_acceleration above the constraints' (per-sample amaxp): then max_accel_ang =
+// max_angular_accel/|k| (MPG:222, 283 — fixed by the constraints' max_acc, MPG:82) can be the smaller limit, which
+// it never is for the constraints' own value (2a/(tw k) > 2a/(2 + tw k)).  Folded into the clamp A.
+template <typename R>
+__device__ __forceinline__ R fast_cap_A(const FastConsts<R> &c, R kabs, R A)
+{
+    const R a = vmin(A, c.aangp * fast_rcp(kabs));
+    return kabs < (R)1e-6 ? A : a;
 }
 
 template <typename R>
@@ -519,31 +531,44 @@ __device__ __forceinline__ double med3(double a, double lo, double hi) { return 
 // dw == 0 -> A, dw != 0 -> 0 without a special case: t is exactly zero when the table entry and the
 // velocity are unchanged (rho = 1), and any other t times kHuge exceeds amaxp.
 template <typename R>
-__device__ __forceinline__ R fast_forward(const FastConsts<R> &c, R rho, R gq, R A, R cap, R u, R &uprev, R u_next)
+__device__ __forceinline__ R fast_forward_a(R amaxp, R rho, R gq, R A, R cap, R u, R &uprev, R u_next)
 {
     const R t = fma(-rho, uprev, u);
-    const R y = fma(-fabs(t), fabs(gq), c.amaxp);
+    const R y = fma(-fabs(t), fabs(gq), amaxp);
     uprev = u;
     return vmin(vmin(u + med3(y, (R)0, A), cap), u_next);
+}
+template <typename R>
+__device__ __forceinline__ R fast_forward(const FastConsts<R> &c, R rho, R gq, R A, R cap, R u, R &uprev, R u_next)
+{
+    return fast_forward_a(c.amaxp, rho, gq, A, cap, u, uprev, u_next);
 }
 
 // Backward step, MPG:255-311.  DUP = the path has samples with a zero heading difference (gq < 0): the
 // reference's signed +-inf handling there differs from the forward one (dw > 0 -> 0, dw <= 0 -> A), i.e.
 // the penalty is max(t, 0)*kHuge where an ordinary sample has |t|*gq = max(t, -t)*gq.
+// (amaxp as an argument: routes whose nodes change max_acceleration carry it per sample, MPG:194-196, 256-257.
+// There the two limits differ — the wheel limit y comes from max_acc, the clamp A from max_dec — and a straight
+// sample, whose limit is max_dec alone (MPG:270-272), is given amaxp = A so that the clamp decides.)
 template <bool DUP, typename R>
-__device__ __forceinline__ R fast_backward(const FastConsts<R> &c, R rho, R gq, R A, R cap, R u, R &uprev, R u_prev)
+__device__ __forceinline__ R fast_backward_a(R amaxp, R rho, R gq, R A, R cap, R u, R &uprev, R u_prev)
 {
     const R t = fma(-rho, uprev, u);
     R y;
     if constexpr (DUP) {
         gq = opaque(gq);   // keep the select below inside the round loop (one register per sample otherwise)
         const R other = gq < (R)0 ? (R)0 : -t;
-        y = fma(-vmax_(t, other), fabs(gq), c.amaxp);
+        y = fma(-vmax_(t, other), fabs(gq), amaxp);
     } else {
-        y = fma(-fabs(t), gq, c.amaxp);
+        y = fma(-fabs(t), gq, amaxp);
     }
     uprev = u;
     return vmin(vmin(u + med3(y, (R)0, A), cap), u_prev);
+}
+template <bool DUP, typename R>
+__device__ __forceinline__ R fast_backward(const FastConsts<R> &c, R rho, R gq, R A, R cap, R u, R &uprev, R u_prev)
+{
+    return fast_backward_a<DUP>(c.amaxp, rho, gq, A, cap, u, uprev, u_prev);
 }
 
 // Cooperative copy of n doubles from HBM/L2 into LDS: up to ITER loads per thread are issued before

@@ -36,14 +36,21 @@ hipError_t launch_grid(hipStream_t st, int B, int W, int S, double dd, double *m
 hipError_t launch_sample(hipStream_t st, bool f64, int B, int W, int S, const double *pw, const double *lut,
                          const double *slopes, const double *meta, const double *aux, const double *runs, void *x,
                          void *y, void *h, void *k, void *dth);
+// per-sample max_acceleration rows of a batch of routes (vap_limits.hip makes them); all NULL for plain paths
+struct AccRowsV {
+    const void *fwd = nullptr;   // [B][S] dtype: max_acc (= max_dec) of the forward step from sample i, MPG:194-196
+    const void *bwd = nullptr;   // [B][S] dtype: max_acc of the backward step from sample i, MPG:256-257
+    const void *dec = nullptr;   // [B]    dtype: max_dec of the backward sweep
+};
 hipError_t launch_velocity_seq(hipStream_t st, bool f64, bool fast, int B, int S, const double c[6], double sv,
                                double ev, const double *meta, const void *curv, const void *dth, const void *vcap,
-                               void *vel);
+                               const AccRowsV &acc, void *vel);
 int velocity_relax_max_samples(bool f64);
+int velocity_relax_acc_max_samples(bool f64);
 // vcap: optional [B][S] per-sample initial velocities (NULL = plain paths)
 hipError_t launch_velocity_relax(hipStream_t st, bool f64, int B, int S, const double c[6], double sv, double ev,
-                                 const double *meta, const void *curv, const void *dth, const void *vcap, void *vel,
-                                 uint32_t *flags);
+                                 const double *meta, const void *curv, const void *dth, const void *vcap,
+                                 const AccRowsV &acc, void *vel, uint32_t *flags);
 // rows longer than velocity_relax_max_samples(): two-level relaxation, synchronises the stream once per super-round
 size_t velocity_long_state_bytes(bool f64, int B, int S);
 size_t velocity_long_counter_bytes(bool f64, int B, int S);
@@ -59,11 +66,16 @@ hipError_t launch_power(hipStream_t st, int n_seg, const double *seg, double *pw
 hipError_t launch_time_profile(hipStream_t st, bool f64, int B, int W, int S, const double *segments, const double *lut,
                                const double *meta, const void *vel, double max_acc, double max_dec, double dt, int cap,
                                double *rows, int *counts, int *nodes_map, uint32_t *flags);
-// vap_limits.hip: sample of every event (node / action point), then the initial-velocity rows
-hipError_t launch_initial_velocities(hipStream_t st, bool f64, int B, int W, int S, int E, const double *lut,
-                                     const double *meta, const double *aux, const double *runs, const double *first_mv,
-                                     const double *ev_t, const double *ev_mv, const int *ev_stop, double max_vel,
-                                     double end_vel, int *ev_k, void *vcap);
+// vap_limits.hip: sample of every event (node / action point), then the per-sample limit rows
+struct LimitInputs {
+    const double *first_mv = nullptr, *first_ma = nullptr;   // [B] node 0 (<= 0 / NULL: the constraints' value)
+    const double *ev_t = nullptr, *ev_mv = nullptr, *ev_ma = nullptr;   // [B][E]
+    const int *ev_stop = nullptr;                                      // [B][E]
+    double max_vel = 0, max_acc = 0, end_vel = 0;
+};
+hipError_t launch_route_limits(hipStream_t st, bool f64, int B, int W, int S, int E, const double *lut, const double *meta,
+                               const double *aux, const double *runs, const LimitInputs &in, int *ev_k, void *vcap,
+                               void *acc_fwd, void *acc_bwd, void *dec_bwd);
 hipError_t launch_eval(hipStream_t st, int W, const double *seg, double t_max, int order, int n, const double *t,
                        double *out);
 hipError_t launch_lookup(hipStream_t st, int W, const double *seg, double t_max, const double *lut, int what,

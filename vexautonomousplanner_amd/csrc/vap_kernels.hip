@@ -558,11 +558,22 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int 
 // FAST = true uses the collapsed limits of vap_device.h and is bit-identical to the relaxation
 // kernel below, which makes it the in-library check of that kernel.
 // ------------------------------------------------------------------------------------------------
+// Per-sample max_acceleration for routes whose nodes / action points change it (all NULL: the constraints'):
+//   fwd [B][S]  max_acc (= max_dec) in force for the forward step FROM sample i     MPG:194-196
+//   bwd [B][S]  max_acc the backward sweep has in force for its step FROM sample i  MPG:256-257
+//   dec [B]     max_dec of the whole backward sweep (what the forward sweep left)
+template <typename R>
+struct AccRows {
+    const R *fwd = nullptr;
+    const R *bwd = nullptr;
+    const R *dec = nullptr;
+};
+
 template <typename R, bool FAST>
 __global__ __launch_bounds__(64) void k_velocity_seq(int B, int S, VelConsts<R> c, R start_u, R end_u,
                                                      const double *__restrict__ meta,
                                                      const R *__restrict__ curv, const R *__restrict__ dtheta,
-                                                     const R *__restrict__ vcap, R *__restrict__ vel)
+                                                     const R *__restrict__ vcap, AccRows<R> acc, R *__restrict__ vel)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -587,13 +598,17 @@ __global__ __launch_bounds__(64) void k_velocity_seq(int B, int S, VelConsts<R> 
     V[0] = u;
     for (int i = 0; i < N - 1; i++) {
         const R un = (i + 1 == N - 1) ? end_u : (vcap ? vcap[row + i + 1] * vcap[row + i + 1] : vmax2);
+        // MPG:194-196: max_acc = max_dec = the value in force from the last boundary at or before sample i
+        const R cur = acc.fwd ? acc.fwd[row + i] : c.amax;
         if constexpr (FAST) {
             R rho, gq, A, cap;
-            fast_derive(fc, (R)fabs(K[i]), i > 0 ? (R)fabs(K[i - 1]) : (R)0, DT[i], fc.amaxp, rho, gq, A, cap);
-            u = fast_forward(fc, rho, gq, A, cap, u, wprev, un);
+            const R amaxp = acc.fwd ? twodd * cur : fc.amaxp;
+            fast_derive(fc, (R)fabs(K[i]), i > 0 ? (R)fabs(K[i - 1]) : (R)0, DT[i], amaxp, rho, gq, A, cap);
+            if (acc.fwd) A = fast_cap_A(fc, (R)fabs(K[i]), A);
+            u = fast_forward_a(amaxp, rho, gq, A, cap, u, wprev, un);
         } else {
-            const SampleLimits<R> L = sample_limits(c, (R)fabs(K[i]), c.amax, c.adec);
-            u = forward_step(c, L, c.amax, twodd, u, wprev, DT[i], un);
+            const SampleLimits<R> L = sample_limits(c, (R)fabs(K[i]), cur, acc.fwd ? cur : c.adec);
+            u = forward_step(c, L, cur, twodd, u, wprev, DT[i], un);
         }
         V[i + 1] = u;
     }
@@ -602,14 +617,23 @@ __global__ __launch_bounds__(64) void k_velocity_seq(int B, int S, VelConsts<R> 
     wprev = (R)0;
     for (int i = N - 1; i > 0; i--) {
         R up;
+        // MPG:256-257: max_acc as the backward sweep finds it at sample i; max_dec is what the forward sweep left
+        const R cur_acc = acc.bwd ? acc.bwd[row + i] : c.amax;
+        const R cur_dec = acc.dec ? acc.dec[b] : c.adec;
         if constexpr (FAST) {
             R rho, gq, A, cap;
-            fast_derive(fc, (R)fabs(K[i]), i + 1 <= N - 1 ? (R)fabs(K[i + 1]) : (R)0, DT[i - 1], fc.adecp, rho, gq, A, cap);
-            up = dup ? fast_backward<true>(fc, rho, gq, A, cap, u, wprev, V[i - 1])
-                     : fast_backward<false>(fc, rho, gq, A, cap, u, wprev, V[i - 1]);
+            const R kabs = (R)fabs(K[i]);
+            fast_derive(fc, kabs, i + 1 <= N - 1 ? (R)fabs(K[i + 1]) : (R)0, DT[i - 1], acc.bwd ? twodd * cur_dec : fc.adecp, rho, gq, A, cap);
+            if (acc.bwd) A = fast_cap_A(fc, kabs, A);
+            // a straight sample is limited by max_dec alone (MPG:270-272), and so is a sample with a zero heading
+            // difference whose angular velocity does not rise (the wheel limit is then +inf, MPG:52-59)
+            // (amaxp = A there: the clamp decides, and kHuge times any non-zero rise of the angular velocity still wins)
+            const R amaxp = acc.bwd ? ((kabs < (R)1e-6 || gq < (R)0) ? A : twodd * cur_acc) : fc.amaxp;
+            up = dup ? fast_backward_a<true>(amaxp, rho, gq, A, cap, u, wprev, V[i - 1])
+                     : fast_backward_a<false>(amaxp, rho, gq, A, cap, u, wprev, V[i - 1]);
         } else {
-            const SampleLimits<R> L = sample_limits(c, (R)fabs(K[i]), c.amax, c.adec);
-            up = backward_step(c, L, c.amax, twodd, u, wprev, DT[i - 1], V[i - 1]);
+            const SampleLimits<R> L = sample_limits(c, (R)fabs(K[i]), cur_acc, cur_dec);
+            up = backward_step(c, L, cur_acc, twodd, u, wprev, DT[i - 1], V[i - 1]);
         }
         V[i] = vel_sqrt(u);
         u = up;
@@ -761,12 +785,12 @@ __device__ __forceinline__ double wave_shift_down(double x)
 
 // VCAP: the caller gave per-sample initial velocities (MPG:121,127,153,172: node / action-point max_velocity and
 // stops); the forward step into sample j is then also limited by vcap[j]^2 — folded into that slot's cap.
-template <typename R, int L, int MAXT, int MINW, bool VCAP>
+template <typename R, int L, int MAXT, int MINW, bool VCAP, bool ACC>
 __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<R> c, R start_u, R end_u,
                                                                const double *__restrict__ meta,
                                                                const R *__restrict__ curv,
                                                                const R *__restrict__ dtheta,
-                                                               const R *__restrict__ vcap,
+                                                               const R *__restrict__ vcap, AccRows<R> acc,
                                                                R *__restrict__ vel, uint32_t *__restrict__ flags,
                                                                long long *__restrict__ stats)
 {
@@ -784,10 +808,12 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
     const size_t row = (size_t)b * S;
     const R *K = curv + row, *DT = dtheta + row;
     const FastConsts<R> fc = make_fast(c, twodd);
+    const R adecp_b = ACC ? twodd * acc.dec[b] : fc.adecp;   // ACC: the backward sweep's max_dec (AccRows)
     const int lo = tid * L;
     const int TL = T * L;
     const bool aligned = (S % (16 / (int)sizeof(R))) == 0;
     R q[L], g[L], A[L], cp[L], u[L];
+    R am[ACC ? L : 1];   // ACC: 2dd*max_acc of the slot's step (routes whose nodes change max_acceleration)
     if (tid == 0) { s_any[0] = 0; s_any[1] = 0; s_any[2] = 0; s_dup = 0; }
 
     // ---------------- forward sweep: the step (j-1 -> j) into owned sample j uses k[j-1], dth[j-1]
@@ -819,7 +845,13 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
             for (int i = 0; i < BK; i++) {
                 const int s = s0 + i, j = lo + s;
                 const bool valid = j >= 1 && j <= N - 1;
-                fast_derive_k(fc, kc, (j >= 2) ? kp : (R)0, fc.amaxp, q[s], g[s], A[s], cp[s]);   // g[s] = k^2 for now
+                R base = fc.amaxp;
+                if constexpr (ACC) {   // the step into j starts at sample j-1: its max_acc (= max_dec), MPG:194-196
+                    base = valid ? twodd * acc.fwd[row + j - 1] : fc.amaxp;
+                    am[s] = base;
+                }
+                fast_derive_k(fc, kc, (j >= 2) ? kp : (R)0, base, q[s], g[s], A[s], cp[s]);   // g[s] = k^2 for now
+                if constexpr (ACC) A[s] = fast_cap_A(fc, kc, A[s]);
                 if (!valid) idle_coef(q[s], g[s], A[s], cp[s]);
                 q[s] = opaque(q[s]);
                 kp = kc;
@@ -891,7 +923,7 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
 #pragma unroll
                 for (int s = 0; s < L; s++) {
                     if (s == 0 && tid == 0) continue;   // sample 0 is the given start velocity (MPG:189)
-                    uu = fast_forward(fc, q[s], g[s], A[s], cp[s], uu, wp, Huge<R>::v);
+                    uu = fast_forward_a(ACC ? am[ACC ? s : 0] : fc.amaxp, q[s], g[s], A[s], cp[s], uu, wp, Huge<R>::v);
                     u[s] = uu;
                 }
                 out_u = uu;
@@ -952,8 +984,20 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
                 const int s = s0 + i, j = lo + s;
                 const bool valid = j <= N - 2;
                 R qq;
-                fast_derive_k(fc, kc, (j + 2 <= N - 1) ? kn[i] : (R)0, fc.adecp, q[s], qq, A[s], cp[s]);
+                R base = fc.adecp;
+                if constexpr (ACC) {
+                    // the step into j starts at sample j+1: the clamp comes from the sweep's max_dec, the wheel limit
+                    // from the max_acc the sweep has at j+1 (MPG:256-257); a straight sample has max_dec alone
+                    base = adecp_b;
+                }
+                fast_derive_k(fc, kc, (j + 2 <= N - 1) ? kn[i] : (R)0, base, q[s], qq, A[s], cp[s]);
                 g[s] = fast_gq(fast_gg(fc, g[s]), qq);
+                if constexpr (ACC) {
+                    A[s] = fast_cap_A(fc, kc, A[s]);
+                    // (a zero heading difference, g < 0: the wheel limit is +inf unless the angular velocity rises)
+                    // — there the clamp decides: amaxp = A (kHuge times any non-zero rise still wins against it)
+                    am[s] = (valid && !(kc < (R)1e-6) && !(g[s] < (R)0)) ? twodd * acc.bwd[row + j + 1] : A[s];
+                }
                 if (!valid) { idle_coef(q[s], g[s], A[s], cp[s]); u[s] = end_u; }
                 q[s] = opaque(q[s]);
                 kc = kn[i];
@@ -981,10 +1025,10 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
                 R uu = in_u, wp = in_w;
                 if (any_dup) {
 #pragma unroll
-                    for (int s = L - 1; s >= 0; s--) uu = fast_backward<true>(fc, q[s], g[s], A[s], cp[s], uu, wp, u[s]);
+                    for (int s = L - 1; s >= 0; s--) uu = fast_backward_a<true>(ACC ? am[ACC ? s : 0] : fc.amaxp, q[s], g[s], A[s], cp[s], uu, wp, u[s]);
                 } else {
 #pragma unroll
-                    for (int s = L - 1; s >= 0; s--) uu = fast_backward<false>(fc, q[s], g[s], A[s], cp[s], uu, wp, u[s]);
+                    for (int s = L - 1; s >= 0; s--) uu = fast_backward_a<false>(ACC ? am[ACC ? s : 0] : fc.amaxp, q[s], g[s], A[s], cp[s], uu, wp, u[s]);
                 }
                 out_u = uu;
                 out_w = wp;
@@ -1023,10 +1067,10 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
         R uu = in_u, wp = in_w;
         if (any_dup) {
 #pragma unroll
-            for (int s = L - 1; s >= 0; s--) u[s] = uu = fast_backward<true>(fc, q[s], g[s], A[s], cp[s], uu, wp, u[s]);
+            for (int s = L - 1; s >= 0; s--) u[s] = uu = fast_backward_a<true>(ACC ? am[ACC ? s : 0] : fc.amaxp, q[s], g[s], A[s], cp[s], uu, wp, u[s]);
         } else {
 #pragma unroll
-            for (int s = L - 1; s >= 0; s--) u[s] = uu = fast_backward<false>(fc, q[s], g[s], A[s], cp[s], uu, wp, u[s]);
+            for (int s = L - 1; s >= 0; s--) u[s] = uu = fast_backward_a<false>(ACC ? am[ACC ? s : 0] : fc.amaxp, q[s], g[s], A[s], cp[s], uu, wp, u[s]);
         }
     }
     // velocities leave through the stage so the row is written with 16 bytes per lane
@@ -1497,30 +1541,40 @@ static VelConsts<R> make_consts(const double c[6])
 
 hipError_t launch_velocity_seq(hipStream_t st, bool f64, bool fast, int B, int S, const double c[6], double sv,
                                double ev, const double *meta, const void *curv, const void *dth, const void *vcap,
-                               void *vel)
+                               const AccRowsV &accv, void *vel)
 {
     const dim3 grid((B + 63) / 64);
     if (f64) {
+        AccRows<double> acc;
+        acc.fwd = (const double *)accv.fwd; acc.bwd = (const double *)accv.bwd; acc.dec = (const double *)accv.dec;
         auto k = fast ? k_velocity_seq<double, true> : k_velocity_seq<double, false>;
         hipLaunchKernelGGL(k, grid, dim3(64), 0, st, B, S, make_consts<double>(c), sv * sv, ev * ev, meta,
-                           (const double *)curv, (const double *)dth, (const double *)vcap, (double *)vel);
+                           (const double *)curv, (const double *)dth, (const double *)vcap, acc, (double *)vel);
     } else {
+        AccRows<float> acc;
+        acc.fwd = (const float *)accv.fwd; acc.bwd = (const float *)accv.bwd; acc.dec = (const float *)accv.dec;
         const float svf = (float)sv, evf = (float)ev;
         auto k = fast ? k_velocity_seq<float, true> : k_velocity_seq<float, false>;
         hipLaunchKernelGGL(k, grid, dim3(64), 0, st, B, S, make_consts<float>(c), svf * svf, evf * evf, meta,
-                           (const float *)curv, (const float *)dth, (const float *)vcap, (float *)vel);
+                           (const float *)curv, (const float *)dth, (const float *)vcap, acc, (float *)vel);
     }
     return hipGetLastError();
 }
 
 // Largest sample capacity the register-resident relaxation kernel covers.
 int velocity_relax_max_samples(bool f64) { return f64 ? 512 * 20 : 512 * 40; }
+// ... and with per-sample max_acceleration rows (one more register array per thread)
+int velocity_relax_acc_max_samples(bool f64) { return f64 ? 512 * 8 : 512 * 20; }
 
-template <typename R, int L, int MAXT, int MINW>
+template <typename R, int L, int MAXT, int MINW, bool ACC = false>
 static void launch_relax_t(hipStream_t st, int B, int S, const double c[6], double sv, double ev,
-                           const double *meta, const void *curv, const void *dth, const void *vcap, void *vel,
-                           uint32_t *flags)
+                           const double *meta, const void *curv, const void *dth, const void *vcap, const AccRowsV &accv,
+                           void *vel, uint32_t *flags)
 {
+    AccRows<R> acc;
+    acc.fwd = (const R *)accv.fwd;
+    acc.bwd = (const R *)accv.bwd;
+    acc.dec = (const R *)accv.dec;
     int T = (S + L - 1) / L;
     T = (T + 63) / 64 * 64;
     const R s = (R)sv, e = (R)ev;
@@ -1529,12 +1583,15 @@ static void launch_relax_t(hipStream_t st, int B, int S, const double c[6], doub
     long long *stats = nullptr;
     if (want_stats) (void)hipMalloc(&stats, (size_t)B * 8 * sizeof(long long));
     const size_t lds = sizeof(R) * ((size_t)T * L + T + 8);
-    if (vcap)
-        hipLaunchKernelGGL((k_velocity_relax<R, L, MAXT, MINW, true>), dim3(B), dim3(T), lds, st, S, make_consts<R>(c), s * s,
-                           e * e, meta, (const R *)curv, (const R *)dth, (const R *)vcap, (R *)vel, flags, stats);
+    if constexpr (ACC)
+        hipLaunchKernelGGL((k_velocity_relax<R, L, MAXT, MINW, true, true>), dim3(B), dim3(T), lds, st, S, make_consts<R>(c), s * s,
+                           e * e, meta, (const R *)curv, (const R *)dth, (const R *)vcap, acc, (R *)vel, flags, stats);
+    else if (vcap)
+        hipLaunchKernelGGL((k_velocity_relax<R, L, MAXT, MINW, true, false>), dim3(B), dim3(T), lds, st, S, make_consts<R>(c), s * s,
+                           e * e, meta, (const R *)curv, (const R *)dth, (const R *)vcap, acc, (R *)vel, flags, stats);
     else
-        hipLaunchKernelGGL((k_velocity_relax<R, L, MAXT, MINW, false>), dim3(B), dim3(T), lds, st, S, make_consts<R>(c), s * s,
-                           e * e, meta, (const R *)curv, (const R *)dth, (const R *)nullptr, (R *)vel, flags, stats);
+        hipLaunchKernelGGL((k_velocity_relax<R, L, MAXT, MINW, false, false>), dim3(B), dim3(T), lds, st, S, make_consts<R>(c), s * s,
+                           e * e, meta, (const R *)curv, (const R *)dth, (const R *)nullptr, acc, (R *)vel, flags, stats);
     if (stats) {
         std::vector<long long> h((size_t)B * 8);
         (void)hipStreamSynchronize(st);
@@ -1553,10 +1610,25 @@ static void launch_relax_t(hipStream_t st, int B, int S, const double c[6], doub
 }
 
 hipError_t launch_velocity_relax(hipStream_t st, bool f64, int B, int S, const double c[6], double sv, double ev,
-                                 const double *meta, const void *curv, const void *dth, const void *vcap, void *vel,
-                                 uint32_t *flags)
+                                 const double *meta, const void *curv, const void *dth, const void *vcap,
+                                 const AccRowsV &acc, void *vel, uint32_t *flags)
 {
-#define VAP_RELAX(R_, L_, MAXT_, W_) launch_relax_t<R_, L_, MAXT_, W_>(st, B, S, c, sv, ev, meta, curv, dth, vcap, vel, flags)
+    if (acc.fwd) {
+        // per-sample max_acceleration: one more register array per thread, so shorter chunks
+        // (velocity_relax_acc_max_samples() is the limit the caller checks)
+#define VAP_RELAX_ACC(R_, L_, MAXT_, W_) launch_relax_t<R_, L_, MAXT_, W_, true>(st, B, S, c, sv, ev, meta, curv, dth, vcap, acc, vel, flags)
+        if (f64) {
+            if (S <= 64 * 4) VAP_RELAX_ACC(double, 4, 256, 4);
+            else VAP_RELAX_ACC(double, 8, 512, 4);
+        } else {
+            if (S <= 64 * 4) VAP_RELAX_ACC(float, 4, 1024, 8);
+            else if (S <= 512 * 16) VAP_RELAX_ACC(float, 16, 512, 4);
+            else VAP_RELAX_ACC(float, 20, 512, 2);
+        }
+#undef VAP_RELAX_ACC
+        return hipGetLastError();
+    }
+#define VAP_RELAX(R_, L_, MAXT_, W_) launch_relax_t<R_, L_, MAXT_, W_>(st, B, S, c, sv, ev, meta, curv, dth, vcap, acc, vel, flags)
     // chunk length: the longest instantiated L whose thread count still covers the row — fewer, longer
     // chunks mean fewer rounds (rounds ~ longest unclamped run / L) and fewer waves to synchronise
     if (f64) {

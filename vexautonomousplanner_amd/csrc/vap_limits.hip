@@ -10,10 +10,11 @@
 //   k_event_samples   one thread per (path, event): the sample of the event — a guess from the inverse of
 //                     the arc-length table, then settled with the reference's own numbers (the path's
 //                     running-sum grid and SM:291-318 distance_to_time) on the neighbouring samples;
-//   k_vcap_fill       one thread per sample: the limit in force (events at earlier samples), 0.01 where
-//                     an event with stop falls on the sample, end_vel at the end sample.
-// Not covered here (single-route path only, vap_route_*): per-node max_acceleration (boundary_map,
-// MPG:194-196), reverse / turn nodes, waits.
+//   k_limit_fill      one thread per sample: the limit in force (events at earlier samples), 0.01 where
+//                     an event with stop falls on the sample, end_vel at the end sample;
+//   k_limit_fill      also the per-sample max_acceleration rows the two sweeps see (boundary_map / max_accels,
+//                     MPG:194-196, 256-257) when the route changes max_acceleration.
+// Not covered here (single-route path only, vap_route_*): reverse / turn nodes, waits.
 #include "vap_device.h"
 #include "vap_kernels.h"
 
@@ -58,47 +59,83 @@ __global__ void k_event_samples(int B, int W, int E, const double *__restrict__ 
     ev_k[i] = out;
 }
 
+// The reference's lists in terms of the events (sorted by sample; R of them are reached, i.e. fall on a loop
+// sample):  max_accels = [a0, acc(e_0), ..., acc(e_{R-1}), max_acc]  (MPG:100-104, 134-137, 155-160, 176) and
+// boundary_map = {0: 0} + {sample of e: 1 + index of the LAST event on that sample} (MPG:139-140, 162 — an
+// action point on a node's sample replaces the node's entry).
+//   forward  (MPG:194-196)  at a boundary: max_acc = max_dec = max_accels[boundary_map[i]]
+//                           -> step from sample i: the last event with sample <= i (a0 before the first)
+//   backward (MPG:256-257)  at a boundary: max_acc = max_accels[boundary_map[i] + 1] — the NEXT list entry, i.e. the
+//                           event after the last one on the nearest boundary at or above i (max_acc past the end);
+//                           above every boundary: what the forward sweep left; max_dec: what the forward sweep left
 template <typename R>
-__global__ void k_vcap_fill(int B, int S, int E, const double *__restrict__ meta, const double *__restrict__ first_mv,
-                            const double *__restrict__ ev_mv, const int *__restrict__ ev_stop,
-                            const int *__restrict__ ev_k, double max_vel, double end_vel, R *__restrict__ vcap)
+__global__ void k_limit_fill(int B, int S, int E, const double *__restrict__ meta, LimitInputs in,
+                             const int *__restrict__ ev_k, R *__restrict__ vcap, R *__restrict__ acc_fwd,
+                             R *__restrict__ acc_bwd, R *__restrict__ dec_bwd)
 {
     const int b = blockIdx.y;
     const int N = (int)meta[(size_t)b * kMetaStride + 3];
     const int *K = ev_k + (size_t)b * E;
-    const double *MV = ev_mv + (size_t)b * E;
-    const int *ST = ev_stop + (size_t)b * E;
-    const double m0 = (first_mv && first_mv[b] > 0.0) ? first_mv[b] : max_vel;
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < S; k += gridDim.x * blockDim.x) {
-        double v = 0.0;
-        if (k < N - 1) {
-            // events at samples <= k-1 have switched the limit; the sorted event samples make that a count
-            int lo = 0, hi = E;   // first event with K > k-1
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (K[mid] <= k - 1) lo = mid + 1; else hi = mid;
-            }
-            v = lo == 0 ? m0 : (MV[lo - 1] > 0.0 ? MV[lo - 1] : max_vel);
-            for (int e = lo; e < E && K[e] == k; e++)
-                if (ST[e]) v = 0.01;                    // MPG:127, 153
-        } else if (k == N - 1) {
-            v = end_vel;                                // MPG:172
+    const double *MV = in.ev_mv + (size_t)b * E;
+    const double *MA = in.ev_ma ? in.ev_ma + (size_t)b * E : nullptr;
+    const int *ST = in.ev_stop + (size_t)b * E;
+    const double m0 = (in.first_mv && in.first_mv[b] > 0.0) ? in.first_mv[b] : in.max_vel;
+    const double a0 = (in.first_ma && in.first_ma[b] > 0.0) ? in.first_ma[b] : in.max_acc;
+    auto acc_of = [&](int e) { return (MA && MA[e] > 0.0) ? MA[e] : in.max_acc; };
+    auto count_le = [&](int k) {    // events with sample <= k (the samples ascend; unreached ones hold INT_MAX)
+        int lo = 0, hi = E;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (K[mid] <= k) lo = mid + 1; else hi = mid;
         }
-        vcap[(size_t)b * S + k] = (R)v;
+        return lo;
+    };
+    const int reached = count_le(N - 2);
+    const double left = reached == 0 ? a0 : acc_of(reached - 1);   // what the forward sweep leaves behind
+    if (dec_bwd && blockIdx.x == 0 && threadIdx.x == 0) dec_bwd[b] = (R)left;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < S; k += gridDim.x * blockDim.x) {
+        double v = 0.0, af = 0.0, ab = 0.0;
+        if (k < N - 1) {
+            const int before = count_le(k - 1);     // events that have switched the limit before this sample
+            v = before == 0 ? m0 : (MV[before - 1] > 0.0 ? MV[before - 1] : in.max_vel);
+            int upto = before;
+            for (; upto < E && K[upto] == k; upto++)
+                if (ST[upto]) v = 0.01;              // MPG:127, 153
+            if (acc_fwd) af = upto == 0 ? a0 : acc_of(upto - 1);
+        } else if (k == N - 1) {
+            v = in.end_vel;                          // MPG:172
+        }
+        if (acc_fwd && k <= N - 1 && k >= 1) {
+            // nearest boundary at or above k: the first event with sample >= k
+            const int first = count_le(k - 1);
+            if (first >= reached) {
+                ab = left;
+            } else {
+                const int last_there = count_le(K[first]) - 1;     // the last event on that sample
+                ab = last_there + 1 < reached ? acc_of(last_there + 1) : in.max_acc;
+            }
+        }
+        const size_t o = (size_t)b * S + k;
+        vcap[o] = (R)v;
+        if (acc_fwd) {
+            acc_fwd[o] = (R)af;
+            acc_bwd[o] = (R)ab;
+        }
     }
 }
 
-hipError_t launch_initial_velocities(hipStream_t st, bool f64, int B, int W, int S, int E, const double *lut,
-                                     const double *meta, const double *aux, const double *runs, const double *first_mv,
-                                     const double *ev_t, const double *ev_mv, const int *ev_stop, double max_vel,
-                                     double end_vel, int *ev_k, void *vcap)
+hipError_t launch_route_limits(hipStream_t st, bool f64, int B, int W, int S, int E, const double *lut, const double *meta,
+                               const double *aux, const double *runs, const LimitInputs &in, int *ev_k, void *vcap,
+                               void *acc_fwd, void *acc_bwd, void *dec_bwd)
 {
-    if (E > 0) hipLaunchKernelGGL(k_event_samples, dim3((B * E + 127) / 128), dim3(128), 0, st, B, W, E, lut, meta, aux, runs, ev_t, ev_k);
+    if (E > 0) hipLaunchKernelGGL(k_event_samples, dim3((B * E + 127) / 128), dim3(128), 0, st, B, W, E, lut, meta, aux, runs, in.ev_t, ev_k);
     const dim3 grid((unsigned)((S + 255) / 256 < 64 ? (S + 255) / 256 : 64), (unsigned)B);
     if (f64)
-        hipLaunchKernelGGL(k_vcap_fill<double>, grid, dim3(256), 0, st, B, S, E, meta, first_mv, ev_mv, ev_stop, ev_k, max_vel, end_vel, (double *)vcap);
+        hipLaunchKernelGGL(k_limit_fill<double>, grid, dim3(256), 0, st, B, S, E, meta, in, ev_k, (double *)vcap, (double *)acc_fwd,
+                           (double *)acc_bwd, (double *)dec_bwd);
     else
-        hipLaunchKernelGGL(k_vcap_fill<float>, grid, dim3(256), 0, st, B, S, E, meta, first_mv, ev_mv, ev_stop, ev_k, max_vel, end_vel, (float *)vcap);
+        hipLaunchKernelGGL(k_limit_fill<float>, grid, dim3(256), 0, st, B, S, E, meta, in, ev_k, (float *)vcap, (float *)acc_fwd,
+                           (float *)acc_bwd, (float *)dec_bwd);
     return hipGetLastError();
 }
 
