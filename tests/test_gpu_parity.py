@@ -716,6 +716,38 @@ def test_time_profile_batch_matches_reference_golden(name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["feat_limits", "feat_stop"])
+def test_time_profile_of_limited_route_matches_reference_golden(name):
+    """generate_motion_profile of the real reference for routes whose nodes carry max_velocity / max_acceleration
+    (feat_limits) or a stop (feat_stop), no waits or splits: profile -> apply_node_limits -> time_profile in the
+    batched path gives the reference's rows and nodes_map."""
+    import torch
+    from vexautonomousplanner_amd.batch import BatchedTrajectoryGenerator
+    g = gu.load(name)
+    assert not g["node_wait_time"].any() and not g["node_turn"].any() and not g["node_is_reverse_node"].any()
+    cons = [float(v) for v in g["constraints"]]
+    gen = BatchedTrajectoryGenerator(0, "f64")
+    wp = torch.tensor(g["waypoints"][None], device="cuda:0", dtype=torch.float64)
+    res = gen.profile(wp, cons, dd=0.005, capacity=16384)
+    gen.apply_node_limits(res, cons, node_max_velocity=g["node_max_velocity"][None], node_stop=g["node_stop"][None],
+                          node_max_acceleration=g["node_max_acceleration"][None])
+    tp = gen.time_profile(res, cons, dt=0.01, capacity_rows=4096)
+    torch.cuda.synchronize()
+    assert not res["flags"].any().item()
+    T = len(g["profile_times"])
+    assert int(tp["counts"][0, 0]) == T
+    rows = tp["rows"][0, :T].cpu().numpy()
+    nm = g["profile_nodes_map"]
+    assert [int(v) for v in tp["nodes_map"][0, :int(tp["counts"][0, 1])]] == [int(v) for v in nm]
+    for col, key in ((0, "times"), (1, "positions"), (2, "linear_vels"), (3, "accelerations"), (4, "headings"),
+                     (5, "angular_vels")):
+        ref = g["profile_" + key]
+        err = np.max(np.abs(rows[:, col] - ref) / np.maximum(np.abs(ref), 1.0))
+        assert err <= 1e-8, (key, err)
+    assert np.max(np.abs(rows[:, 6:8] - g["profile_coords"])) <= 1e-8
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("W", [5, 8, 32])
 def test_time_profile_batch_matches_oracle(W):
     """fp64 batch vs the oracle time loop path by path: same row count, same node rows, values to 1e-7
