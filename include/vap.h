@@ -204,6 +204,26 @@ int vap_time_profile(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, const doub
                      const vap_constraints *c, double time_step, int capacity_rows, double *d_rows,
                      int *d_counts, int *d_nodes_map, uint32_t *d_flags);
 
+/* Waits and action points in the time domain (MPG:457-476, 509-518, 543-553) on top of the rows of
+ * vap_time_profile: a node or action point with wait_time inserts int(wait_time/time_step) rows (zero
+ * position / velocity / acceleration / angular velocity, the last heading and point) where it is passed,
+ * and every later row moves by as many rows and time steps; actions_map records the row count at which
+ * each action point fires (the reference's own test, MPG:546-553: one that lands exactly on a row's
+ * parameter, or shares a row interval with its predecessor, never fires and blocks the ones after it).
+ *   d_rows_in [B][capacity_in][8], d_counts_in [B][2], d_nodes_map_in [B][W]   from vap_time_profile
+ *   d_node_wait   [B][W]  seconds (NULL: none)       d_action_t / d_action_wait [B][M] (pad t with +inf)
+ *   d_rows_out    [B][capacity_out][8]  (must not alias d_rows_in)
+ *   d_counts_out  [B][3] int32: rows, nodes_map entries, actions_map entries
+ *   d_nodes_map_out [B][W], d_actions_map_out [B][M] int32
+ * Segments / table NULL = those of the last vap_profile_batch.  Turn and reverse nodes are not covered
+ * (vap_route_motion_profile). */
+int vap_time_insert_waits(vap_ctx *ctx, int B, int W, int M, int capacity_in, int capacity_out, double time_step,
+                          const double *d_segments, const double *d_lut, const double *d_meta,
+                          const double *d_rows_in, const int *d_counts_in, const int *d_nodes_map_in,
+                          const double *d_node_wait, const double *d_action_t, const double *d_action_wait,
+                          double *d_rows_out, int *d_counts_out, int *d_nodes_map_out, int *d_actions_map_out,
+                          uint32_t *d_flags);
+
 /* ---- fused hot path ------------------------------------------------------------------------ */
 
 /* rebuild_tables (SM:582-594) + forward_backward_pass (MPG:70-316) for B plain-node paths, inputs

@@ -747,6 +747,86 @@ def test_time_profile_of_limited_route_matches_reference_golden(name):
     assert np.max(np.abs(rows[:, 6:8] - g["profile_coords"])) <= 1e-8
 
 
+def _full_route_profile(torch, g_or_route, cons, dtype="f64"):
+    """profile -> apply_node_limits -> time_profile -> insert_waits for one route given as a dict of arrays
+    (waypoints, node_* , ap_*); returns rows, nodes_map, actions_map as numpy."""
+    from vexautonomousplanner_amd.batch import BatchedTrajectoryGenerator
+    r_ = g_or_route
+    gen = BatchedTrajectoryGenerator(0, dtype)
+    wp = torch.tensor(np.asarray(r_["waypoints"])[None], device="cuda:0", dtype=gen.tdtype)
+    aps = None
+    if "ap_t" in r_ and len(r_["ap_t"]):
+        aps = [[{"t": float(t), "max_velocity": float(mv), "max_acceleration": float(ma), "stop": bool(st), "wait_time": float(w)}
+                for t, mv, ma, st, w in zip(r_["ap_t"], r_["ap_max_velocity"], r_["ap_max_acceleration"], r_["ap_stop"], r_["ap_wait_time"])]]
+    res = gen.profile(wp, cons, dd=0.005, capacity=16384)
+    gen.apply_node_limits(res, cons, node_max_velocity=np.asarray(r_["node_max_velocity"])[None], node_stop=np.asarray(r_["node_stop"])[None],
+                          node_max_acceleration=np.asarray(r_["node_max_acceleration"])[None], action_points=aps)
+    tp = gen.time_profile(res, cons, dt=0.01, capacity_rows=4096)
+    out = gen.insert_waits(res, tp, node_wait_time=np.asarray(r_["node_wait_time"])[None], action_points=aps, dt=0.01)
+    torch.cuda.synchronize()
+    assert not res["flags"].any().item()
+    T, nn, na = (int(v) for v in out["counts"][0])
+    return (out["rows"][0, :T].cpu().numpy(), [int(v) for v in out["nodes_map"][0, :nn]], [int(v) for v in out["actions_map"][0, :na]])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["feat_wait", "feat_action", "feat_limits", "feat_stop"])
+def test_full_motion_profile_of_route_matches_reference_golden(name):
+    """generate_motion_profile of the real reference — rows, nodes_map, actions_map — for routes with waits at
+    nodes (feat_wait, incl. node 0) and action points with limits, a stop and a wait (feat_action), through the
+    batched path: profile -> apply_node_limits -> time_profile -> insert_waits."""
+    import torch
+    g = gu.load(name)
+    assert not g["node_turn"].any() and not g["node_is_reverse_node"].any()
+    route = {k: g[k] for k in g.files if k.startswith(("node_", "ap_")) or k == "waypoints"}
+    rows, nmap, amap = _full_route_profile(torch, route, [float(v) for v in g["constraints"]])
+    T = len(g["profile_times"])
+    assert rows.shape[0] == T
+    assert nmap == [int(v) for v in g["profile_nodes_map"]]
+    assert amap == [int(v) for v in g["profile_actions_map"]]
+    for col, key in ((0, "times"), (1, "positions"), (2, "linear_vels"), (3, "accelerations"), (4, "headings"),
+                     (5, "angular_vels")):
+        ref = g["profile_" + key]
+        err = np.max(np.abs(rows[:, col] - ref) / np.maximum(np.abs(ref), 1.0))
+        assert err <= 1e-8, (key, err)
+    assert np.max(np.abs(rows[:, 6:8] - g["profile_coords"])) <= 1e-8
+
+
+@pytest.mark.gpu
+def test_full_motion_profile_of_random_routes_matches_oracle():
+    """Random routes with every attribute the batched path covers (limits, stops, waits, action points with waits)
+    against the oracle's generate_motion_profile."""
+    import torch
+    from oracle import oracle
+    from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
+    rng = np.random.default_rng(515)
+    W = 8
+    for it in range(6):
+        wp = make_waypoints(1, W, 700 + it)[0].astype(np.float64)
+        mv = np.where(rng.random(W) < 0.3, rng.uniform(1.0, 3.5, W), 0.0)
+        ma = np.where(rng.random(W) < 0.3, rng.uniform(2.0, 12.0, W), 0.0)
+        stop = (rng.random(W) < 0.2).astype(float)
+        stop[0] = stop[-1] = 0
+        wait = np.where(rng.random(W) < 0.3, rng.uniform(0.05, 0.4, W), 0.0)
+        wait[-1] = 0
+        n_ap = int(rng.integers(0, 4))
+        ts = np.sort(rng.uniform(0.2, W - 1.2, size=n_ap))
+        ap = dict(ap_t=ts, ap_max_velocity=np.where(rng.random(n_ap) < 0.4, rng.uniform(1.0, 3.0, n_ap), 0.0),
+                  ap_max_acceleration=np.where(rng.random(n_ap) < 0.4, rng.uniform(2.0, 10.0, n_ap), 0.0),
+                  ap_stop=(rng.random(n_ap) < 0.3).astype(float), ap_wait_time=np.where(rng.random(n_ap) < 0.5, rng.uniform(0.05, 0.3, n_ap), 0.0))
+        nodes = dict(is_reverse=np.zeros(W), turn=np.zeros(W), stop=stop, wait_time=wait, max_velocity=mv, max_acceleration=ma,
+                     tangent=np.full((W, 2), np.nan), magnitudes=np.zeros((W, 2)))
+        actions = dict(t=ts, stop=ap["ap_stop"], wait_time=ap["ap_wait_time"], max_velocity=ap["ap_max_velocity"],
+                       max_acceleration=ap["ap_max_acceleration"]) if n_ap else None
+        ref_rows, ref_n, ref_a = oracle.OraclePath(wp, nodes=nodes, actions=actions).generate_motion_profile(DEFAULT_CONSTRAINTS, dt=0.01, dd=0.005)
+        route = dict(waypoints=wp, node_max_velocity=mv, node_max_acceleration=ma, node_stop=stop, node_wait_time=wait, **ap)
+        rows, nmap, amap = _full_route_profile(torch, route, DEFAULT_CONSTRAINTS)
+        assert rows.shape[0] == ref_rows.shape[0], (it, rows.shape[0], ref_rows.shape[0])
+        assert nmap == [int(v) for v in ref_n] and amap == [int(v) for v in ref_a], it
+        err = np.max(np.abs(rows - ref_rows) / np.maximum(np.abs(ref_rows), 1.0))
+        assert err <= 1e-7, (it, err)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("W", [5, 8, 32])
 def test_time_profile_batch_matches_oracle(W):

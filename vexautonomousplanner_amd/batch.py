@@ -211,5 +211,42 @@ class BatchedTrajectoryGenerator:
         result["event_sample"] = ev_k[:, :E]
         return result
 
+    def insert_waits(self, result, tp, node_wait_time=None, action_points=None, dt=0.01, capacity_rows=None):
+        """Waits of nodes / action points and ``actions_map`` on top of ``tp = time_profile(result, ...)``
+        (MPG:457-476, 509-518, 543-553): returns a new dict with
+          rows (B, capacity_rows, 8), counts (B, 3) int32 [rows, nodes_map entries, actions_map entries],
+          nodes_map (B, W), actions_map (B, M) int32.
+        ``action_points``: list (per path) of lists of dicts {"t", "wait_time"} in route order."""
+        rows_in, counts_in, nodes_in = tp["rows"], tp["counts"], tp["nodes_map"]
+        B, cap_in, _ = rows_in.shape
+        W = nodes_in.shape[1]
+        dev = self.device
+        wait = np.zeros((B, W)) if node_wait_time is None else np.asarray(node_wait_time, dtype=np.float64).reshape(B, W)
+        aps = action_points if action_points is not None else [[] for _ in range(B)]
+        M = max((len(a) for a in aps), default=0)
+        ap_t = np.full((B, max(M, 1)), np.inf)
+        ap_w = np.zeros((B, max(M, 1)))
+        for b, al in enumerate(aps):
+            for i, a in enumerate(al):
+                ap_t[b, i] = float(a["t"])
+                ap_w[b, i] = float(a.get("wait_time", 0.0))
+        extra = int(np.max(np.floor(wait / dt).sum(axis=1) + np.floor(ap_w / dt).sum(axis=1))) + 1
+        cap_out = int(capacity_rows) if capacity_rows is not None else cap_in + extra
+        out = {"rows": torch.empty((B, cap_out, 8), dtype=torch.float64, device=dev),
+               "counts": torch.zeros((B, 3), dtype=torch.int32, device=dev),
+               "nodes_map": torch.zeros((B, W), dtype=torch.int32, device=dev),
+               "actions_map": torch.zeros((B, max(M, 1)), dtype=torch.int32, device=dev)}
+        d_wait = torch.tensor(wait, device=dev)
+        d_apt = torch.tensor(ap_t, device=dev)
+        d_apw = torch.tensor(ap_w, device=dev)
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        self.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(self._L.vap_time_insert_waits(self.ctx.handle, B, W, M, cap_in, cap_out, float(dt), None, None,
+                                                 ptr(result["meta"]), ptr(rows_in), ptr(counts_in), ptr(nodes_in), ptr(d_wait),
+                                                 ptr(d_apt), ptr(d_apw), ptr(out["rows"]), ptr(out["counts"]), ptr(out["nodes_map"]),
+                                                 ptr(out["actions_map"]), ptr(result["flags"])), "vap_time_insert_waits")
+        out["actions_map"] = out["actions_map"][:, :M]
+        return out
+
     def timing(self):
         return self.ctx.last_timing()

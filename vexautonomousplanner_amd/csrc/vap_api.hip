@@ -439,6 +439,33 @@ int vap_time_profile(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, const doub
     return VAP_OK;
 }
 
+int vap_time_insert_waits(vap_ctx *ctx, int B, int W, int M, int capacity_in, int capacity_out, double time_step,
+                          const double *d_segments, const double *d_lut, const double *d_meta, const double *d_rows_in,
+                          const int *d_counts_in, const int *d_nodes_map_in, const double *d_node_wait,
+                          const double *d_action_t, const double *d_action_wait, double *d_rows_out, int *d_counts_out,
+                          int *d_nodes_map_out, int *d_actions_map_out, uint32_t *d_flags)
+{
+    VAP_TRY(vap_set_device(ctx));
+    VAP_TRY(check_shape(B, W, 2));
+    if (M < 0 || capacity_in < 1 || capacity_out < 1 || !(time_step > 0)) return vap_fail(VAP_ERR_INVALID, "bad argument");
+    if (!d_meta || !d_rows_in || !d_counts_in || !d_nodes_map_in || !d_rows_out || !d_counts_out || !d_nodes_map_out)
+        return vap_fail(VAP_ERR_INVALID, "null buffer");
+    if (M > 0 && (!d_action_t || !d_actions_map_out)) return vap_fail(VAP_ERR_INVALID, "null action-point array");
+    if (d_rows_out == d_rows_in) return vap_fail(VAP_ERR_INVALID, "the rows move: d_rows_out must not be d_rows_in");
+    if ((d_segments == nullptr) != (d_lut == nullptr)) return vap_fail(VAP_ERR_INVALID, "pass both d_segments and d_lut, or neither");
+    if (!d_segments) {
+        if (ctx->last_B != B || ctx->last_W != W || !ctx->seg.ptr || !ctx->lut.ptr)
+            return vap_fail(VAP_ERR_UNFITTED, "no tables of a %d x %d batch in this context (last vap_profile_batch: %d x %d)", B,
+                            W, ctx->last_B, ctx->last_W);
+        d_segments = (const double *)ctx->seg.ptr;
+        d_lut = (const double *)ctx->lut.ptr;
+    }
+    HIP_TRY(vap::launch_time_waits(ctx->stream, B, W, M, capacity_in, capacity_out, time_step, d_segments, d_lut, d_meta,
+                                   d_rows_in, d_counts_in, d_nodes_map_in, d_node_wait, d_action_t, d_action_wait, d_rows_out,
+                                   d_counts_out, d_nodes_map_out, d_actions_map_out, d_flags));
+    return VAP_OK;
+}
+
 int vap_profile_batch_host(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd, const void *h_waypoints,
                            const vap_constraints *c, double start_vel, double end_vel, void *h_x, void *h_y,
                            void *h_heading, void *h_curvature, void *h_velocity, double *h_meta,

@@ -76,6 +76,11 @@ struct LimitInputs {
 hipError_t launch_route_limits(hipStream_t st, bool f64, int B, int W, int S, int E, const double *lut, const double *meta,
                                const double *aux, const double *runs, const LimitInputs &in, int *ev_k, void *vcap,
                                void *acc_fwd, void *acc_bwd, void *dec_bwd);
+// waits of nodes / action points and actions_map on top of the rows of launch_time_profile (vap_time.hip)
+hipError_t launch_time_waits(hipStream_t st, int B, int W, int M, int cap_in, int cap_out, double dt, const double *segments,
+                             const double *lut, const double *meta, const double *rows_in, const int *counts_in,
+                             const int *nodes_in, const double *node_wait, const double *ap_t, const double *ap_wait,
+                             double *rows_out, int *counts_out, int *nodes_out, int *actions_out, uint32_t *flags);
 hipError_t launch_eval(hipStream_t st, int W, const double *seg, double t_max, int order, int n, const double *t,
                        double *out);
 hipError_t launch_lookup(hipStream_t st, int W, const double *seg, double t_max, const double *lut, int what,

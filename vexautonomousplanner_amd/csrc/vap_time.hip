@@ -166,4 +166,151 @@ hipError_t launch_time_profile(hipStream_t st, bool f64, int B, int W, int S, co
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Waits and action points in the time domain (MPG:457-476 the wait at node 0, 509-518 handle_wait, 543-553):
+// a wait inserts int(wait_time/dt) rows — zero position / velocity / acceleration / angular velocity, the last
+// heading and point — at the row where its node is passed or its action point fires, and everything after it
+// moves later by that many rows and time steps; the kinematic state does not change, so this is a pass over
+// the rows vap_time_profile made.  One workgroup per path:
+//   thread 0   the events in row order (a node before an action point on the same row): nodes with a wait at
+//              their nodes_map row, action points by the reference's own test — action k fires at row i iff
+//              it is the pending one and t_{i-1} < t_k < t_i, so one that lands exactly on a row's parameter, or
+//              shares a row interval with its predecessor, never fires and blocks the ones after it — and the
+//              two maps (row counts at the moment of the event, MPG:528, 549);
+//   all        copy row i to i + (rows inserted before it) and write the inserted rows.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_time_waits(int W, int M, int cap_in, int cap_out, double dt,
+                                                    const double *__restrict__ segments, const double *__restrict__ lut,
+                                                    const double *__restrict__ meta, const double *__restrict__ rows_in,
+                                                    const int *__restrict__ counts_in, const int *__restrict__ nodes_in,
+                                                    const double *__restrict__ node_wait, const double *__restrict__ ap_t,
+                                                    const double *__restrict__ ap_wait, double *__restrict__ rows_out,
+                                                    int *__restrict__ counts_out, int *__restrict__ nodes_out,
+                                                    int *__restrict__ actions_out, uint32_t *__restrict__ flags)
+{
+    extern __shared__ int s_ev[];            // [E][2]: row, steps — E = W + M events at most
+    __shared__ int s_n_ev;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int G = W - 1;
+    const double *m = meta + (size_t)b * kMetaStride;
+    const double t_max = m[0], total = m[1];
+    const double end_param = (double)(W - 1);
+    const int T = counts_in[2 * b], n_nodes = counts_in[2 * b + 1];
+    const double *in = rows_in + (size_t)b * cap_in * kRowWidth;
+    double *out = rows_out + (size_t)b * cap_out * kRowWidth;
+    const double *D = lut + (size_t)b * kLutN;
+    const double *seg = segments + (size_t)b * G * 12;
+    int *ev_row = s_ev, *ev_steps = s_ev + (W + M);
+    if (tid == 0) {
+        auto t_of_row = [&](int i) { return distance_to_time(D, total, t_max, end_param, i == 0 ? 0.0 : in[(size_t)(i - 1) * kRowWidth + 1]); };
+        const double *nw = node_wait ? node_wait + (size_t)b * W : nullptr;
+        int n_ev = 0, shift = 0, n_act = 0;
+        // the wait at node 0 comes before everything (MPG:457-476)
+        auto steps_of = [&](double w) { return w > 0.0 ? (int)(w / dt) : 0; };   // int(wait_time / dt)
+        nodes_out[(size_t)b * W] = 0;
+        {
+            const int s0 = nw ? steps_of(nw[0]) : 0;
+            if (s0 > 0) { ev_row[n_ev] = -1; ev_steps[n_ev] = s0; n_ev++; shift += s0; }   // row -1: before row 0
+        }
+        int node = 1, act = 0, last_act_row = -1;
+        bool act_blocked = false;
+        int next_act_row = -1;
+        auto find_action = [&]() {      // row at which the pending action point fires, or -1
+            next_act_row = -1;
+            if (act_blocked || act >= M) return;
+            const double Tk = ap_t[(size_t)b * M + act];
+            if (!(Tk == Tk) || Tk == INFINITY) { act_blocked = true; return; }   // padding
+            int lo = 0, hi = T;         // first row with t > Tk
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (t_of_row(mid) > Tk) hi = mid; else lo = mid + 1;
+            }
+            const double prev_t = lo == 0 ? 0.0 : t_of_row(lo - 1);
+            if (lo < T && prev_t < Tk && lo > last_act_row) next_act_row = lo;
+            else act_blocked = true;    // never fires: the reference keeps waiting for it (MPG:546-553)
+        };
+        find_action();
+        while (node < n_nodes || next_act_row >= 0) {
+            const int rn = node < n_nodes ? nodes_in[(size_t)b * W + node] : 0x7fffffff;
+            const int ra = next_act_row >= 0 ? next_act_row : 0x7fffffff;
+            if (rn <= ra) {             // node first on the same row (MPG:527 then 546)
+                nodes_out[(size_t)b * W + node] = rn + shift;
+                const int st = nw ? steps_of(nw[node]) : 0;
+                if (st > 0 && n_ev < W + M) { ev_row[n_ev] = rn; ev_steps[n_ev] = st; n_ev++; shift += st; }
+                node++;
+            } else {
+                actions_out[(size_t)b * M + n_act] = ra + shift;
+                n_act++;
+                const int st = ap_wait ? steps_of(ap_wait[(size_t)b * M + act]) : 0;
+                if (st > 0 && n_ev < W + M) { ev_row[n_ev] = ra; ev_steps[n_ev] = st; n_ev++; shift += st; }
+                last_act_row = ra;
+                act++;
+                find_action();
+            }
+        }
+        s_n_ev = n_ev;
+        counts_out[3 * b + 1] = n_nodes;
+        counts_out[3 * b + 2] = n_act;
+        int Tout = T + shift;
+        if (Tout > cap_out) {
+            Tout = cap_out;
+            if (flags) atomicOr(&flags[b], VAP_FLAG_TRUNCATED_BIT);
+        }
+        counts_out[3 * b] = Tout;
+    }
+    __syncthreads();
+    const int n_ev = s_n_ev;
+    // rows: row i moves behind every event at a row <= i
+    for (int i = tid; i < T; i += 256) {
+        int shift = 0;
+        for (int e = 0; e < n_ev && ev_row[e] <= i; e++) shift += ev_steps[e];
+        const int o = i + shift;
+        if (o >= cap_out) continue;
+        const double *q = in + (size_t)i * kRowWidth;
+        double *w = out + (size_t)o * kRowWidth;
+        w[0] = q[0] + (double)shift * dt;
+#pragma unroll
+        for (int c = 1; c < kRowWidth; c++) w[c] = q[c];
+    }
+    // inserted rows
+    int before = 0;
+    for (int e = 0; e < n_ev; e++) {
+        const int r = ev_row[e], st = ev_steps[e];
+        double h, px, py, t0;
+        if (r < 0) {                    // node 0: heading and point of the path's start (MPG:461-473)
+            double dx, dy;
+            hermite_eval_ref(seg, t_max, G, 1, 0.0, dx, dy);
+            h = -1.0 * atan2(dy, dx);
+            if (h > M_PI) h -= 2 * M_PI;
+            if (h < -M_PI) h += 2 * M_PI;
+            hermite_eval_ref(seg, t_max, G, 0, 0.0, px, py);
+            t0 = 0.0;
+        } else {                        // headings[-1], coords[-1]: the row before; current_time: this row's
+            const double *prev = in + (size_t)(r > 0 ? r - 1 : 0) * kRowWidth;
+            h = prev[4]; px = prev[6]; py = prev[7];
+            t0 = (r < T ? in[(size_t)r * kRowWidth] : in[(size_t)(T - 1) * kRowWidth] + dt) + (double)before * dt;
+        }
+        const int base = (r < 0 ? 0 : r) + before;
+        for (int j = tid; j < st; j += 256) {
+            const int o = base + j;
+            if (o >= cap_out) continue;
+            double *w = out + (size_t)o * kRowWidth;
+            w[0] = t0 + (double)j * dt;
+            w[1] = 0.0; w[2] = 0.0; w[3] = 0.0; w[4] = h; w[5] = 0.0; w[6] = px; w[7] = py;
+        }
+        before += st;
+    }
+}
+
+hipError_t launch_time_waits(hipStream_t st, int B, int W, int M, int cap_in, int cap_out, double dt, const double *segments,
+                             const double *lut, const double *meta, const double *rows_in, const int *counts_in,
+                             const int *nodes_in, const double *node_wait, const double *ap_t, const double *ap_wait,
+                             double *rows_out, int *counts_out, int *nodes_out, int *actions_out, uint32_t *flags)
+{
+    const size_t lds = sizeof(int) * 2 * (size_t)(W + M);
+    hipLaunchKernelGGL(k_time_waits, dim3(B), dim3(256), lds, st, W, M, cap_in, cap_out, dt, segments, lut, meta, rows_in, counts_in,
+                       nodes_in, node_wait, ap_t, ap_wait, rows_out, counts_out, nodes_out, actions_out, flags);
+    return hipGetLastError();
+}
+
 }  // namespace vap
