@@ -157,25 +157,27 @@ int vap_velocity_pass(vap_ctx *ctx, vap_dtype dt, int B, int S, const vap_constr
  *   d_acc_forward   max_acc (= max_dec) in force for the forward step from each sample  (boundary_map /
  *   d_acc_backward  max_acc the backward sweep has in force for its step from each sample  max_accels,
  *   d_dec_backward  [B] max_dec of the backward sweep: what the forward sweep left behind   incl. their quirks)
- * An event is a node (its parameter is its index, 1 .. W-2) or an action point (its parameter t); the
- * reference acts on it at the first loop sample whose parameter has reached it (MPG:125, 141-145).
- *   d_first_max_velocity / d_first_max_acceleration [B]   node 0's (<= 0 or NULL array: the constraints')
- *   d_event_t                [B][E]  parameters, ascending, > 0 (a node before an action point at the same
- *                                    parameter, as the reference processes them); pad with +inf
- *   d_event_max_velocity     [B][E]  <= 0: back to max_vel                               MPG:129-132, 146-149
- *   d_event_max_acceleration [B][E]  <= 0: max_acc; NULL array: none                     MPG:134-137, 155-160
- *   d_event_stop             [B][E]  int32                                               MPG:126-127, 151-152
+ * A node (parameter = its index) or action point (parameter t) takes effect at the first loop sample whose
+ * parameter has reached it (MPG:125, 141-145) — a node before an action point on the same sample, and an
+ * action point that would fall on its predecessor's sample never does, nor do those after it (the
+ * reference looks at one pending action point per sample).
+ *   d_node_max_velocity / d_node_max_acceleration [B][W]  (<= 0: none; NULL array: none)  MPG:100-107, 129-137
+ *   d_node_stop                                   [B][W]  int32 (NULL: none)              MPG:126-127
+ *   d_action_t                                    [B][M]  in route order, > 0; pad with +inf
+ *   d_action_max_velocity / _max_acceleration / _stop [B][M]  (NULL arrays: none)         MPG:146-160
  *   d_vcap, d_acc_forward, d_acc_backward [B][S] (dtype) out; the three acceleration outputs are optional
  *                                    as a set (routes that do not change max_acceleration need only d_vcap)
- *   d_event_sample           [B][E]  int32 out, optional: the sample of each event (INT_MAX: not reached)
- * d_lut NULL = the table of the last vap_profile_batch.  Reverse / turn nodes and waits are not covered
- * here (vap_route_* is the general single-route path). */
-int vap_route_limits(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, int E, const double *d_lut,
-                     const double *d_meta, const double *d_first_max_velocity,
-                     const double *d_first_max_acceleration, const double *d_event_t,
-                     const double *d_event_max_velocity, const double *d_event_max_acceleration,
-                     const int *d_event_stop, const vap_constraints *c, double end_vel, void *d_vcap,
-                     void *d_acc_forward, void *d_acc_backward, void *d_dec_backward, int *d_event_sample);
+ *   d_node_sample [B][W], d_action_sample [B][M]  int32 out, optional: the sample at which each takes
+ *                                    effect (node 0: 0; INT_MAX: never)
+ * d_lut NULL = the table of the last vap_profile_batch.  Reverse / turn nodes are not covered here
+ * (vap_route_* is the general single-route path); waits act in the time domain (vap_time_insert_waits). */
+int vap_route_limits(vap_ctx *ctx, vap_dtype dt, int B, int W, int M, int S, const double *d_lut,
+                     const double *d_meta, const double *d_node_max_velocity,
+                     const double *d_node_max_acceleration, const int *d_node_stop, const double *d_action_t,
+                     const double *d_action_max_velocity, const double *d_action_max_acceleration,
+                     const int *d_action_stop, const vap_constraints *c, double end_vel, void *d_vcap,
+                     void *d_acc_forward, void *d_acc_backward, void *d_dec_backward, int *d_node_sample,
+                     int *d_action_sample);
 
 /* vap_velocity_pass with the limit rows of vap_route_limits (the three acceleration arguments NULL, or
  * all set together with d_vcap).  With acceleration rows the register-resident kernel covers rows up to

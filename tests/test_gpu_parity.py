@@ -263,7 +263,7 @@ def test_apply_node_limits_stop_golden(torch_mod, gens, dtype, tol):
     err = np.max(np.abs(v - g["grid_velocity"]) / g["grid_velocity"])
     assert err <= tol, err
     # the stop takes effect at the first sample whose parameter has reached node 3
-    k = int(r["event_sample"][0, 2])
+    k = int(r["node_sample"][0, 3])
     assert g["grid_t"][k] >= 3.0 > g["grid_t"][k - 1]
     assert float(r["vcap"][0, k]) == pytest.approx(0.01)
 
@@ -376,6 +376,14 @@ def test_apply_node_limits_with_accelerations_vs_oracle(torch_mod, gens, dtype, 
     aps[0] = [{"t": 3.0, "max_velocity": 0.0, "max_acceleration": 3.0, "stop": False}]     # on node 3's sample
     ma[0, 3] = 9.0
     ma[1, 0], ma[1, 2], ma[2, 4] = 30.0, 40.0, 25.0   # far above max_acc: max_angular_accel/|k| (MPG:222) binds in curves
+    # cases a randomised sweep (tools/fuzz_batch_routes.py) found: two action points inside one sample interval — the
+    # reference looks at one pending action point per sample, so the second never takes effect, nor any after it —
+    # and an action point just before a node, on the node's sample: the node is handled first whatever the parameters
+    aps[3] = [{"t": 2.41490, "max_velocity": 1.2, "max_acceleration": 4.0, "stop": False},
+              {"t": 2.41492, "max_velocity": 3.0, "max_acceleration": 0.0, "stop": True},
+              {"t": 4.5, "max_velocity": 1.0, "max_acceleration": 3.0, "stop": True}]
+    aps[4] = [{"t": 2.99995, "max_velocity": 2.0, "max_acceleration": 13.9, "stop": False}]
+    stop[4, 3], mv[4, 3], ma[4, 3] = True, 3.5, 5.0
     refs = []
     for b in range(B):
         nodes = dict(is_reverse=np.zeros(W), turn=np.zeros(W), stop=stop[b].astype(float), wait_time=np.zeros(W),

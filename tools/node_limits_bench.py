@@ -32,17 +32,14 @@ print(f"apply_node_limits (host event packing + vap_route_limits + velocity pass
 import ctypes as C
 from vexautonomousplanner_amd import _lib
 L = _lib.lib()
-E = W - 2
-d_t = torch.tensor(np.tile(np.arange(1, W - 1, dtype=np.float64), (B, 1)), device="cuda:0")
-d_mv = torch.tensor(mv[:, 1:W - 1].copy(), device="cuda:0")
-d_stop = torch.tensor(stop[:, 1:W - 1].astype(np.int32), device="cuda:0")
-d_first = torch.tensor(mv[:, 0].copy(), device="cuda:0")
+d_mv = torch.tensor(mv, device="cuda:0")
+d_stop = torch.tensor(stop.astype(np.int32), device="cuda:0")
 vcap = torch.empty((B, S), dtype=torch.float32, device="cuda:0")
 c = _lib.make_constraints(DEFAULT_CONSTRAINTS)
 p = lambda t: C.c_void_p(t.data_ptr())
 def dev_calls():
-    _lib.check(L.vap_route_limits(gen.ctx.handle, _lib.VAP_F32, B, W, S, E, None, p(r["meta"]), p(d_first), None, p(d_t), p(d_mv), None, p(d_stop),
-                                  C.byref(c), 0.01, p(vcap), None, None, None, None), "limits")
+    _lib.check(L.vap_route_limits(gen.ctx.handle, _lib.VAP_F32, B, W, 0, S, None, p(r["meta"]), p(d_mv), None, p(d_stop), None, None, None, None,
+                                  C.byref(c), 0.01, p(vcap), None, None, None, None, None), "limits")
 def vel_call():
     _lib.check(L.vap_velocity_pass(gen.ctx.handle, _lib.VAP_F32, B, S, C.byref(c), 0.01, 0.01, p(r["meta"]), p(r["curvature"]), None, p(vcap),
                                    p(r["velocity"]), p(r["flags"])), "vel")

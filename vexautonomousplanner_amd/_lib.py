@@ -112,8 +112,7 @@ def lib():
     L.vap_profile_batch_host.argtypes = L.vap_profile_batch.argtypes
     L.vap_time_profile.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp,
                                    C.POINTER(Constraints), C.c_double, C.c_int, vp, vp, vp, vp]
-    L.vap_route_limits.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp,
-                                   C.POINTER(Constraints), C.c_double, vp, vp, vp, vp, vp]
+    L.vap_route_limits.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int] + [vp] * 9 + [C.POINTER(Constraints), C.c_double] + [vp] * 6
     L.vap_velocity_pass_limits.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(Constraints), C.c_double, C.c_double,
                                            vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.vap_time_insert_waits.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double] + [vp] * 14

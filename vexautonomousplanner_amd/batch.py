@@ -143,7 +143,8 @@ class BatchedTrajectoryGenerator:
           node_stop                                 (B, W) array-like of bool
           action_points  optional list (per path) of lists of dicts {"t", "max_velocity", "max_acceleration", "stop"}
         Returns ``result`` with "velocity" replaced, plus "vcap" (the reference's initial velocity list per
-        sample) and "event_sample" (the sample at which each node 1..W-2 and action point takes effect).
+        sample), "node_sample" (B, W) and "action_sample" (B, M): the sample at which each takes effect
+        (INT_MAX: never — e.g. an action point the reference skips, see include/vap.h).
         Reverse / turn nodes and waits change more than the limits: those routes go through the drop-in classes
         (vap_route_*)."""
         vel, meta = result["velocity"], result["meta"]
@@ -155,51 +156,34 @@ class BatchedTrajectoryGenerator:
         as2d = lambda a: np.zeros((B, W)) if a is None else np.asarray(a, dtype=np.float64).reshape(B, W)
         mv, ma = as2d(node_max_velocity), as2d(node_max_acceleration)
         stop = np.zeros((B, W), dtype=bool) if node_stop is None else np.asarray(node_stop).astype(bool).reshape(B, W)
-        aps = action_points if action_points is not None else None
-        n_ap = max((len(a) for a in aps), default=0) if aps is not None else 0
-        n_node = max(W - 2, 0)
-        E = n_node + n_ap
-        shape = (B, max(E, 1))
-        ev_t = np.full(shape, np.inf)
-        ev_mv, ev_ma = np.zeros(shape), np.zeros(shape)
-        ev_stop = np.zeros(shape, dtype=np.int32)
-        kind = np.zeros(shape, dtype=np.int8)       # 0 node, 1 action point
-        if n_node:
-            ev_t[:, :n_node] = np.arange(1, W - 1, dtype=np.float64)
-            ev_mv[:, :n_node] = mv[:, 1:W - 1]
-            ev_ma[:, :n_node] = ma[:, 1:W - 1]
-            ev_stop[:, :n_node] = stop[:, 1:W - 1]
-        if n_ap:
-            kind[:, n_node:] = 1
-            for b, al in enumerate(aps):
-                for i, a in enumerate(al):
-                    t = float(a["t"])
-                    if not t > 0:
-                        raise ValueError("action point parameters must be > 0 (the reference never reaches t <= 0, MPG:141-145)")
-                    ev_t[b, n_node + i] = t
-                    ev_mv[b, n_node + i] = float(a.get("max_velocity", 0.0))
-                    ev_ma[b, n_node + i] = float(a.get("max_acceleration", 0.0))
-                    ev_stop[b, n_node + i] = int(bool(a.get("stop", False)))
-            # ascending parameter, a node before an action point at the same parameter (MPG:125 then 141)
-            order = np.lexsort((kind, ev_t), axis=1)
-            ev_t, ev_mv, ev_ma, ev_stop = (np.take_along_axis(a, order, axis=1) for a in (ev_t, ev_mv, ev_ma, ev_stop))
-        with_acc = bool((ma > 0).any() or (ev_ma > 0).any())
+        aps = action_points if action_points is not None else [[] for _ in range(B)]
+        M = max((len(a) for a in aps), default=0)
+        ap_t = np.full((B, max(M, 1)), np.inf)
+        ap_mv, ap_ma = np.zeros((B, max(M, 1))), np.zeros((B, max(M, 1)))
+        ap_stop = np.zeros((B, max(M, 1)), dtype=np.int32)
+        for b, al in enumerate(aps):
+            for i, a in enumerate(al):
+                ap_t[b, i] = float(a["t"])
+                ap_mv[b, i] = float(a.get("max_velocity", 0.0))
+                ap_ma[b, i] = float(a.get("max_acceleration", 0.0))
+                ap_stop[b, i] = int(bool(a.get("stop", False)))
+        with_acc = bool((ma > 0).any() or (ap_ma > 0).any())
         dev = self.device
-        d_t, d_mv, d_ma, d_stop = (torch.tensor(a, device=dev) for a in (ev_t, ev_mv, ev_ma, ev_stop))
-        d_first_mv = torch.tensor(mv[:, 0].copy(), device=dev)
-        d_first_ma = torch.tensor(ma[:, 0].copy(), device=dev)
+        d = {k: torch.tensor(v, device=dev) for k, v in dict(mv=mv, ma=ma, stop=stop.astype(np.int32), ap_t=ap_t, ap_mv=ap_mv,
+                                                               ap_ma=ap_ma, ap_stop=ap_stop).items()}
         vcap = torch.empty((B, S), dtype=self.tdtype, device=dev)
         acc_f = torch.empty((B, S), dtype=self.tdtype, device=dev) if with_acc else None
         acc_b = torch.empty((B, S), dtype=self.tdtype, device=dev) if with_acc else None
         dec_b = torch.empty((B,), dtype=self.tdtype, device=dev) if with_acc else None
-        ev_k = torch.empty(shape, dtype=torch.int32, device=dev)
+        node_k = torch.empty((B, W), dtype=torch.int32, device=dev)
+        ap_k = torch.empty((B, max(M, 1)), dtype=torch.int32, device=dev)
         c = _lib.make_constraints(constraints)
         self.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
-        _lib.check(self._L.vap_route_limits(self.ctx.handle, self.vdtype, B, W, S, E, None, ptr(meta), ptr(d_first_mv),
-                                            ptr(d_first_ma), ptr(d_t), ptr(d_mv), ptr(d_ma), ptr(d_stop), C.byref(c),
-                                            float(end_vel), ptr(vcap), ptr(acc_f), ptr(acc_b), ptr(dec_b), ptr(ev_k)),
-                   "vap_route_limits")
+        _lib.check(self._L.vap_route_limits(self.ctx.handle, self.vdtype, B, W, M, S, None, ptr(meta), ptr(d["mv"]), ptr(d["ma"]),
+                                            ptr(d["stop"]), ptr(d["ap_t"]), ptr(d["ap_mv"]), ptr(d["ap_ma"]), ptr(d["ap_stop"]),
+                                            C.byref(c), float(end_vel), ptr(vcap), ptr(acc_f), ptr(acc_b), ptr(dec_b), ptr(node_k),
+                                            ptr(ap_k)), "vap_route_limits")
         curv = result.get("curvature")
         if curv is None:
             raise ValueError("apply_node_limits needs the curvature rows (profile(want=...) must include 'curvature')")
@@ -208,7 +192,8 @@ class BatchedTrajectoryGenerator:
                                                     ptr(acc_b), ptr(dec_b), ptr(vel), ptr(result["flags"])),
                    "vap_velocity_pass_limits")
         result["vcap"] = vcap
-        result["event_sample"] = ev_k[:, :E]
+        result["node_sample"] = node_k
+        result["action_sample"] = ap_k[:, :M]
         return result
 
     def insert_waits(self, result, tp, node_wait_time=None, action_points=None, dt=0.01, capacity_rows=None):

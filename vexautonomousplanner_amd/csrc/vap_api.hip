@@ -375,16 +375,16 @@ int vap_profile_batch(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd
     return VAP_OK;
 }
 
-int vap_route_limits(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, int E, const double *d_lut, const double *d_meta,
-                     const double *d_first_max_velocity, const double *d_first_max_acceleration, const double *d_event_t,
-                     const double *d_event_max_velocity, const double *d_event_max_acceleration, const int *d_event_stop,
-                     const vap_constraints *c, double end_vel, void *d_vcap, void *d_acc_forward, void *d_acc_backward,
-                     void *d_dec_backward, int *d_event_sample)
+int vap_route_limits(vap_ctx *ctx, vap_dtype dt, int B, int W, int M, int S, const double *d_lut, const double *d_meta,
+                     const double *d_node_max_velocity, const double *d_node_max_acceleration, const int *d_node_stop,
+                     const double *d_action_t, const double *d_action_max_velocity, const double *d_action_max_acceleration,
+                     const int *d_action_stop, const vap_constraints *c, double end_vel, void *d_vcap, void *d_acc_forward,
+                     void *d_acc_backward, void *d_dec_backward, int *d_node_sample, int *d_action_sample)
 {
     VAP_TRY(vap_set_device(ctx));
     VAP_TRY(check_shape(B, W, S));
-    if (E < 0 || !d_meta || !d_vcap || !c || !(c->max_vel > 0) || !(c->max_acc > 0)) return vap_fail(VAP_ERR_INVALID, "bad argument");
-    if (E > 0 && (!d_event_t || !d_event_max_velocity || !d_event_stop)) return vap_fail(VAP_ERR_INVALID, "null event array");
+    if (M < 0 || !d_meta || !d_vcap || !c || !(c->max_vel > 0) || !(c->max_acc > 0)) return vap_fail(VAP_ERR_INVALID, "bad argument");
+    if (M > 0 && !d_action_t) return vap_fail(VAP_ERR_INVALID, "null action-point array");
     const bool any_acc = d_acc_forward || d_acc_backward || d_dec_backward;
     if (any_acc && !(d_acc_forward && d_acc_backward && d_dec_backward))
         return vap_fail(VAP_ERR_INVALID, "the max_acceleration outputs come as a set (forward, backward, dec)");
@@ -397,24 +397,32 @@ int vap_route_limits(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, int E, con
             return vap_fail(VAP_ERR_INVALID, "d_lut is NULL and the context holds no table of this shape");
         lut = (const double *)ctx->lut.ptr;
     }
-    int *ev_k = d_event_sample;
-    if (!ev_k && E > 0) {
-        VAP_TRY(ctx->ensure(ctx->small_out, (size_t)B * E * sizeof(int)));
-        ev_k = (int *)ctx->small_out.ptr;
-    }
+    // scratch: node samples, action samples, merged event list {sample, max_velocity, max_acceleration, stop}
+    const size_t E = (size_t)(W > 2 ? W - 2 : 0) + M;
+    const size_t n_int = (size_t)B * (W + M + 2 * E), n_dbl = (size_t)B * 2 * E;
+    VAP_TRY(ctx->ensure(ctx->small_out, n_dbl * sizeof(double) + n_int * sizeof(int) + 64));
+    double *ev_mv = (double *)ctx->small_out.ptr, *ev_ma = ev_mv + (size_t)B * E;
+    int *node_k = (int *)(ev_ma + (size_t)B * E);
+    int *ap_k = node_k + (size_t)B * W;
+    int *ev_k = ap_k + (size_t)B * M;
+    int *ev_stop = ev_k + (size_t)B * E;
     vap::LimitInputs in;
-    in.first_mv = d_first_max_velocity;
-    in.first_ma = d_first_max_acceleration;
-    in.ev_t = d_event_t;
-    in.ev_mv = d_event_max_velocity;
-    in.ev_ma = d_event_max_acceleration;
-    in.ev_stop = d_event_stop;
+    in.node_mv = d_node_max_velocity;
+    in.node_ma = d_node_max_acceleration;
+    in.node_stop = d_node_stop;
+    in.ap_t = d_action_t;
+    in.ap_mv = d_action_max_velocity;
+    in.ap_ma = d_action_max_acceleration;
+    in.ap_stop = d_action_stop;
     in.max_vel = c->max_vel;
     in.max_acc = c->max_acc;
     in.end_vel = end_vel;
-    HIP_TRY(vap::launch_route_limits(ctx->stream, dt == VAP_F64, B, W, S, E, lut, d_meta, (const double *)ctx->aux.ptr,
-                                     (const double *)ctx->runs.ptr, in, ev_k, d_vcap, d_acc_forward, d_acc_backward,
-                                     d_dec_backward));
+    HIP_TRY(vap::launch_route_limits(ctx->stream, dt == VAP_F64, B, W, M, S, lut, d_meta, (const double *)ctx->aux.ptr,
+                                     (const double *)ctx->runs.ptr, in, node_k, ap_k, ev_k, ev_mv, ev_ma, ev_stop, d_vcap,
+                                     d_acc_forward, d_acc_backward, d_dec_backward));
+    if (d_node_sample) HIP_TRY(hipMemcpyAsync(d_node_sample, node_k, sizeof(int) * (size_t)B * W, hipMemcpyDeviceToDevice, ctx->stream));
+    if (d_action_sample && M > 0)
+        HIP_TRY(hipMemcpyAsync(d_action_sample, ap_k, sizeof(int) * (size_t)B * M, hipMemcpyDeviceToDevice, ctx->stream));
     return VAP_OK;
 }
 

@@ -68,14 +68,17 @@ hipError_t launch_time_profile(hipStream_t st, bool f64, int B, int W, int S, co
                                double *rows, int *counts, int *nodes_map, uint32_t *flags);
 // vap_limits.hip: sample of every event (node / action point), then the per-sample limit rows
 struct LimitInputs {
-    const double *first_mv = nullptr, *first_ma = nullptr;   // [B] node 0 (<= 0 / NULL: the constraints' value)
-    const double *ev_t = nullptr, *ev_mv = nullptr, *ev_ma = nullptr;   // [B][E]
-    const int *ev_stop = nullptr;                                      // [B][E]
+    const double *node_mv = nullptr, *node_ma = nullptr;   // [B][W] per-node max_velocity / max_acceleration (<= 0: none)
+    const int *node_stop = nullptr;                        // [B][W]
+    const double *ap_t = nullptr, *ap_mv = nullptr, *ap_ma = nullptr;   // [B][M] action points in route order (t: +inf = padding)
+    const int *ap_stop = nullptr;                          // [B][M]
     double max_vel = 0, max_acc = 0, end_vel = 0;
 };
-hipError_t launch_route_limits(hipStream_t st, bool f64, int B, int W, int S, int E, const double *lut, const double *meta,
-                               const double *aux, const double *runs, const LimitInputs &in, int *ev_k, void *vcap,
-                               void *acc_fwd, void *acc_bwd, void *dec_bwd);
+// node_k [B][W], ap_k [B][M] receive the samples (INT_MAX: never); ev_* [B][W-2+M] are scratch for the merged list
+hipError_t launch_route_limits(hipStream_t st, bool f64, int B, int W, int M, int S, const double *lut, const double *meta,
+                               const double *aux, const double *runs, const LimitInputs &in, int *node_k, int *ap_k,
+                               int *ev_k, double *ev_mv, double *ev_ma, int *ev_stop, void *vcap, void *acc_fwd,
+                               void *acc_bwd, void *dec_bwd);
 // waits of nodes / action points and actions_map on top of the rows of launch_time_profile (vap_time.hip)
 hipError_t launch_time_waits(hipStream_t st, int B, int W, int M, int cap_in, int cap_out, double dt, const double *segments,
                              const double *lut, const double *meta, const double *rows_in, const int *counts_in,

@@ -7,9 +7,11 @@
 // stop, overwrites that sample's entry with 0.01.  Both tests pick "the first loop sample k with
 // t(s_k) >= T" (T = the node's index / the action point's parameter), so the list is a step function of
 // the sample index with one event per node / action point:
-//   k_event_samples   one thread per (path, event): the sample of the event — a guess from the inverse of
-//                     the arc-length table, then settled with the reference's own numbers (the path's
-//                     running-sum grid and SM:291-318 distance_to_time) on the neighbouring samples;
+//   k_event_samples   one thread per (path, node / action point): the sample it would take effect on — a guess
+//                     from the inverse of the arc-length table, then settled with the reference's own numbers
+//                     (the path's running-sum grid and SM:291-318 distance_to_time) on the neighbouring samples;
+//   k_event_merge     one thread per path: the action points the reference never reaches (one pending action
+//                     point per sample), and one event list ordered by sample, nodes first;
 //   k_limit_fill      one thread per sample: the limit in force (events at earlier samples), 0.01 where
 //                     an event with stop falls on the sample, end_vel at the end sample;
 //   k_limit_fill      also the per-sample max_acceleration rows the two sweeps see (boundary_map / max_accels,
@@ -22,41 +24,93 @@ namespace vap {
 
 constexpr int kNever = 0x7fffffff;
 
-__global__ void k_event_samples(int B, int W, int E, const double *__restrict__ lut, const double *__restrict__ meta,
-                                const double *__restrict__ aux, const double *__restrict__ runs,
-                                const double *__restrict__ ev_t, int *__restrict__ ev_k)
+// first loop sample k (1 <= k <= N-2) whose parameter has reached T, or kNever
+__device__ int first_sample_reaching(double T, int W, const double *__restrict__ D, const double *__restrict__ m,
+                                     const double *__restrict__ tab, int n_runs)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * E) return;
-    const int b = i / E;
-    const double T = ev_t[i];
-    const double *m = meta + (size_t)b * kMetaStride;
     const double t_max = m[0], total = m[1], dd = m[2];
     const int N = (int)m[3];
     const double end_param = (double)(W - 1);
-    int out = kNever;
-    if (T > 0.0 && T < end_param && N >= 3 && total > 0.0 && dd > 0.0) {
-        const double *D = lut + (size_t)b * kLutN;
-        const double *tab = runs + (size_t)b * kGridRunDoubles;
-        const int n_runs = (int)aux[(size_t)b * kAuxStride + 3];
-        // where the table's parameter reaches T (its parameters are linspace(0, t_max, 1000), SM:443)
-        const double lstep = t_max / (double)(kLutN - 1);
-        int j = (int)floor(T / lstep);
-        j = j < 0 ? 0 : (j > kLutN - 2 ? kLutN - 2 : j);
-        const double t0 = linspace_at(t_max, kLutN, j), t1 = linspace_at(t_max, kLutN, j + 1);
-        const double s_star = D[j] + (T - t0) / (t1 - t0) * (D[j + 1] - D[j]);
-        long k = (long)floor(s_star / dd);
-        k = k < 1 ? 1 : (k > N - 2 ? N - 2 : k);
-        // settle it with the reference's own parameter of the neighbouring samples
-        auto t_of = [&](long kk) {
-            int r = grid_run_hint(dd, kk, n_runs);
-            return distance_to_time(D, total, t_max, end_param, grid_s(tab, n_runs, kk, r));
-        };
-        while (k > 1 && t_of(k - 1) >= T) k--;
-        while (k <= N - 2 && t_of(k) < T) k++;
-        if (k <= N - 2) out = (int)k;
+    if (!(T > 0.0 && T < end_param && N >= 3 && total > 0.0 && dd > 0.0)) return kNever;
+    // where the table's parameter reaches T (its parameters are linspace(0, t_max, 1000), SM:443)
+    const double lstep = t_max / (double)(kLutN - 1);
+    int j = (int)floor(T / lstep);
+    j = j < 0 ? 0 : (j > kLutN - 2 ? kLutN - 2 : j);
+    const double t0 = linspace_at(t_max, kLutN, j), t1 = linspace_at(t_max, kLutN, j + 1);
+    const double s_star = D[j] + (T - t0) / (t1 - t0) * (D[j + 1] - D[j]);
+    long k = (long)floor(s_star / dd);
+    k = k < 1 ? 1 : (k > N - 2 ? N - 2 : k);
+    // settle it with the reference's own parameter of the neighbouring samples
+    auto t_of = [&](long kk) {
+        int r = grid_run_hint(dd, kk, n_runs);
+        return distance_to_time(D, total, t_max, end_param, grid_s(tab, n_runs, kk, r));
+    };
+    while (k > 1 && t_of(k - 1) >= T) k--;
+    while (k <= N - 2 && t_of(k) < T) k++;
+    return k <= N - 2 ? (int)k : kNever;
+}
+
+// One thread per (path, node 1..W-2 or action point): the sample at which it would take effect on its own.
+__global__ void k_event_samples(int B, int W, int M, const double *__restrict__ lut, const double *__restrict__ meta,
+                                const double *__restrict__ aux, const double *__restrict__ runs,
+                                const double *__restrict__ ap_t, int *__restrict__ node_k, int *__restrict__ ap_k)
+{
+    const int per = W + M;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * per) return;
+    const int b = i / per, e = i - b * per;
+    const double *m = meta + (size_t)b * kMetaStride;
+    const double *D = lut + (size_t)b * kLutN;
+    const double *tab = runs + (size_t)b * kGridRunDoubles;
+    const int n_runs = (int)aux[(size_t)b * kAuxStride + 3];
+    if (e < W) {
+        // node e: index 0 is the start (sample 0), the last node is never passed inside the loop (MPG:125)
+        node_k[(size_t)b * W + e] = e == 0 ? 0 : (e == W - 1 ? kNever : first_sample_reaching((double)e, W, D, m, tab, n_runs));
+    } else {
+        const double T = ap_t[(size_t)b * M + (e - W)];
+        ap_k[(size_t)b * M + (e - W)] = (T == T && T != INFINITY) ? first_sample_reaching(T, W, D, m, tab, n_runs) : kNever;
     }
-    ev_k[i] = out;
+}
+
+// One thread per path: the reference looks at one pending action point per sample (MPG:141-145, 163), so an action
+// point that would take effect on the sample of its predecessor (or earlier) never does, and neither do those after
+// it; then nodes and action points merge into one list by sample, a node before an action point on the same sample
+// (the order the reference handles them in, MPG:125 then 141 — whatever their parameters).
+__global__ void k_event_merge(int B, int W, int M, const LimitInputs in, const int *__restrict__ node_k, int *__restrict__ ap_k,
+                              int *__restrict__ ev_k, double *__restrict__ ev_mv, double *__restrict__ ev_ma,
+                              int *__restrict__ ev_stop)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int E = (W > 2 ? W - 2 : 0) + M;
+    const int *NK = node_k + (size_t)b * W;
+    int *AK = ap_k + (size_t)b * M;
+    int last = -1;
+    bool blocked = false;
+    for (int a = 0; a < M; a++) {
+        if (blocked || AK[a] == kNever || AK[a] <= last) { blocked = true; AK[a] = kNever; }
+        else last = AK[a];
+    }
+    int n = 1, a = 0, o = 0;
+    const size_t base = (size_t)b * E;
+    while (o < E) {
+        const int kn = n <= W - 2 ? NK[n] : kNever, ka = a < M ? AK[a] : kNever;
+        const bool take_node = n <= W - 2 && (a >= M || kn <= ka);
+        if (take_node) {
+            ev_k[base + o] = kn;
+            ev_mv[base + o] = in.node_mv ? in.node_mv[(size_t)b * W + n] : 0.0;
+            ev_ma[base + o] = in.node_ma ? in.node_ma[(size_t)b * W + n] : 0.0;
+            ev_stop[base + o] = in.node_stop ? in.node_stop[(size_t)b * W + n] : 0;
+            n++;
+        } else {
+            ev_k[base + o] = ka;
+            ev_mv[base + o] = in.ap_mv ? in.ap_mv[(size_t)b * M + a] : 0.0;
+            ev_ma[base + o] = in.ap_ma ? in.ap_ma[(size_t)b * M + a] : 0.0;
+            ev_stop[base + o] = in.ap_stop ? in.ap_stop[(size_t)b * M + a] : 0;
+            a++;
+        }
+        o++;
+    }
 }
 
 // The reference's lists in terms of the events (sorted by sample; R of them are reached, i.e. fall on a loop
@@ -69,19 +123,21 @@ __global__ void k_event_samples(int B, int W, int E, const double *__restrict__ 
 //                           event after the last one on the nearest boundary at or above i (max_acc past the end);
 //                           above every boundary: what the forward sweep left; max_dec: what the forward sweep left
 template <typename R>
-__global__ void k_limit_fill(int B, int S, int E, const double *__restrict__ meta, LimitInputs in,
-                             const int *__restrict__ ev_k, R *__restrict__ vcap, R *__restrict__ acc_fwd,
-                             R *__restrict__ acc_bwd, R *__restrict__ dec_bwd)
+__global__ void k_limit_fill(int B, int W, int S, int E, const double *__restrict__ meta, LimitInputs in,
+                             const int *__restrict__ ev_k, const double *__restrict__ ev_mv,
+                             const double *__restrict__ ev_ma, const int *__restrict__ ev_stop, R *__restrict__ vcap,
+                             R *__restrict__ acc_fwd, R *__restrict__ acc_bwd, R *__restrict__ dec_bwd)
 {
     const int b = blockIdx.y;
     const int N = (int)meta[(size_t)b * kMetaStride + 3];
     const int *K = ev_k + (size_t)b * E;
-    const double *MV = in.ev_mv + (size_t)b * E;
-    const double *MA = in.ev_ma ? in.ev_ma + (size_t)b * E : nullptr;
-    const int *ST = in.ev_stop + (size_t)b * E;
-    const double m0 = (in.first_mv && in.first_mv[b] > 0.0) ? in.first_mv[b] : in.max_vel;
-    const double a0 = (in.first_ma && in.first_ma[b] > 0.0) ? in.first_ma[b] : in.max_acc;
-    auto acc_of = [&](int e) { return (MA && MA[e] > 0.0) ? MA[e] : in.max_acc; };
+    const double *MV = ev_mv + (size_t)b * E;
+    const double *MA = ev_ma + (size_t)b * E;
+    const int *ST = ev_stop + (size_t)b * E;
+    const double mv0 = in.node_mv ? in.node_mv[(size_t)b * W] : 0.0, ma0 = in.node_ma ? in.node_ma[(size_t)b * W] : 0.0;
+    const double m0 = mv0 > 0.0 ? mv0 : in.max_vel;     // MPG:100-107: node 0
+    const double a0 = ma0 > 0.0 ? ma0 : in.max_acc;
+    auto acc_of = [&](int e) { return MA[e] > 0.0 ? MA[e] : in.max_acc; };
     auto count_le = [&](int k) {    // events with sample <= k (the samples ascend; unreached ones hold INT_MAX)
         int lo = 0, hi = E;
         while (lo < hi) {
@@ -124,18 +180,22 @@ __global__ void k_limit_fill(int B, int S, int E, const double *__restrict__ met
     }
 }
 
-hipError_t launch_route_limits(hipStream_t st, bool f64, int B, int W, int S, int E, const double *lut, const double *meta,
-                               const double *aux, const double *runs, const LimitInputs &in, int *ev_k, void *vcap,
-                               void *acc_fwd, void *acc_bwd, void *dec_bwd)
+hipError_t launch_route_limits(hipStream_t st, bool f64, int B, int W, int M, int S, const double *lut, const double *meta,
+                               const double *aux, const double *runs, const LimitInputs &in, int *node_k, int *ap_k,
+                               int *ev_k, double *ev_mv, double *ev_ma, int *ev_stop, void *vcap, void *acc_fwd,
+                               void *acc_bwd, void *dec_bwd)
 {
-    if (E > 0) hipLaunchKernelGGL(k_event_samples, dim3((B * E + 127) / 128), dim3(128), 0, st, B, W, E, lut, meta, aux, runs, in.ev_t, ev_k);
+    const int E = (W > 2 ? W - 2 : 0) + M;
+    const int per = W + M;
+    hipLaunchKernelGGL(k_event_samples, dim3((B * per + 127) / 128), dim3(128), 0, st, B, W, M, lut, meta, aux, runs, in.ap_t, node_k, ap_k);
+    if (E > 0) hipLaunchKernelGGL(k_event_merge, dim3((B + 63) / 64), dim3(64), 0, st, B, W, M, in, node_k, ap_k, ev_k, ev_mv, ev_ma, ev_stop);
     const dim3 grid((unsigned)((S + 255) / 256 < 64 ? (S + 255) / 256 : 64), (unsigned)B);
     if (f64)
-        hipLaunchKernelGGL(k_limit_fill<double>, grid, dim3(256), 0, st, B, S, E, meta, in, ev_k, (double *)vcap, (double *)acc_fwd,
-                           (double *)acc_bwd, (double *)dec_bwd);
+        hipLaunchKernelGGL(k_limit_fill<double>, grid, dim3(256), 0, st, B, W, S, E, meta, in, ev_k, ev_mv, ev_ma, ev_stop, (double *)vcap,
+                           (double *)acc_fwd, (double *)acc_bwd, (double *)dec_bwd);
     else
-        hipLaunchKernelGGL(k_limit_fill<float>, grid, dim3(256), 0, st, B, S, E, meta, in, ev_k, (float *)vcap, (float *)acc_fwd,
-                           (float *)acc_bwd, (float *)dec_bwd);
+        hipLaunchKernelGGL(k_limit_fill<float>, grid, dim3(256), 0, st, B, W, S, E, meta, in, ev_k, ev_mv, ev_ma, ev_stop, (float *)vcap,
+                           (float *)acc_fwd, (float *)acc_bwd, (float *)dec_bwd);
     return hipGetLastError();
 }
 
