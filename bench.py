@@ -64,6 +64,35 @@ def cpu_baseline(wl, budget_s=12.0):
                       f"{cores} threads, {elapsed:.1f}s of CPU work"}
 
 
+def parity_check(out, wp, S, constraints, n_paths, dtype):
+    """Worst relative velocity error of the first n_paths paths against the oracle (the measures of
+    tests/test_gpu_parity.py); `bound` is north_star's 1e-5 for fp32 rows, 1e-7 for fp64 rows."""
+    from oracle import oracle
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    wp64 = wp[:n_paths].double().cpu().numpy()
+    ref = oracle.profile_batch(wp64, S, constraints, n_threads=max(1, min(cores, 32)))
+    bound = 1e-5 if dtype == "f32" else 1e-7
+    res = {"checked_paths": int(n_paths), "bound": bound}
+    v = out["velocity"][:n_paths].double().cpu().numpy()
+    ev = np.max(np.abs(v - ref["velocity"]) / ref["velocity"], axis=1)
+    res["frac_above_1e-5"] = float(np.mean(ev > 1e-5))
+    res["frac_above_bound"] = float(np.mean(ev > bound))
+    res["worst"] = float(ev.max())
+    res["median_path_worst"] = float(np.median(ev))
+    geo = {}
+    for k, floor in (("curvature", 1e-2), ("x", 1.0), ("y", 1.0)):
+        if k in out:
+            g = out[k][:n_paths].double().cpu().numpy()
+            geo[k] = float(np.max(np.abs(g - ref[k]) / np.maximum(np.abs(ref[k]), floor)))
+    if "heading" in out:
+        geo["heading"] = float(np.max(np.abs(out["heading"][:n_paths].double().cpu().numpy() - ref["heading"])) / np.pi)
+    res["worst_geometry"] = geo
+    return res
+
+
 def profiled_traffic(stage, workload, dtype, paths):
     """HBM bytes per launch of the stage's kernel from the committed PMC profile of this round
     (profiles/r*_traffic.json, made by tools/profile_round.sh: separate FETCH_SIZE / WRITE_SIZE passes,
@@ -87,6 +116,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--dtype", default="f32", choices=("f32", "f64"))
+    ap.add_argument("--recurrence", default="f64", choices=("f64", "f32"),
+                    help="dtype f32 only: arithmetic of the velocity recurrence behind the fp32 rows (f64 = the default "
+                         "mode of the library, the one that holds 1e-5 against the reference on every path)")
+    ap.add_argument("--parity-paths", type=int, default=128,
+                    help="paths of rank 0's batch checked against the CPU oracle after the timed region (0 = skip)")
     ap.add_argument("--paths-per-gpu", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--time-domain", action="store_true",
@@ -136,7 +170,7 @@ def main():
     wp = torch.tensor(wp_all[lo:hi], dtype=tdt, device=dev)
     del wp_all
 
-    gen = BatchedTrajectoryGenerator(local_rank, args.dtype)
+    gen = BatchedTrajectoryGenerator(local_rank, args.dtype, recurrence=args.recurrence)
     out = None
 
     def step():
@@ -197,6 +231,11 @@ def main():
     total_len = float(summ[:, 0].sum().item())
     best_time = float(summ[:, 2].min().item())
 
+    # parity of the mode just timed: the first paths of rank 0's batch against the oracle (CPU, after the timed region)
+    parity = None
+    if rank == 0 and args.parity_paths > 0:
+        parity = parity_check(out, wp, S, constraints, min(args.parity_paths, B), args.dtype)
+
     if rank == 0:
         points = B * S * world
         esz = 4 if args.dtype == "f32" else 8
@@ -216,6 +255,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": wl["name"], "paths_per_gpu": B, "waypoints": W, "samples": S,
+                       "grid": "dd_p = L_p / (S - 1.5), the reference's running sum from 0 plus its appended end sample",
+                       "recurrence": ("f64 behind fp32 rows" if args.recurrence == "f64" else "f32") if args.dtype == "f32" else "f64",
                        "global_paths": B * world, "parallelism": f"paths sharded x{world}, no data-path collective",
                        "flags_or": flags, "sum_path_length_ft": total_len,
                        "fastest_traversal_s": best_time},
@@ -227,6 +268,8 @@ def main():
                          "frac_of_hbm_peak": bytes_per_point * B * S / (acc["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "stage_ms": {k: round(v, 4) for k, v in acc.items()}},
         }
+        if parity is not None:
+            line["parity"] = parity
         if time_domain is not None:
             line["time_domain"] = time_domain
         if not args.no_cpu_baseline and world == 1:

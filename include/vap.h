@@ -17,10 +17,12 @@
  *   - units: feet, seconds, radians.
  *
  * Precision (`vap_dtype`):
- *   VAP_F32  fp32 inputs/outputs.  Parameter/index arithmetic, derivative evaluation and curvature
- *            are carried in fp64 on the device (the reference's table/step-lookup quantisation and
- *            its finite-difference angular-acceleration term are not reproducible to 1e-5 otherwise,
- *            see DESIGN.md §Numerics); headings, the velocity recurrence and all stores are fp32.
+ *   VAP_F32  fp32 inputs/outputs.  Parameter/index arithmetic, derivative evaluation, curvature, heading
+ *            differences and the velocity recurrence are carried in fp64 on the device (the reference's
+ *            table/step-lookup quantisation, its finite-difference angular-acceleration term and the
+ *            error amplification of its recurrence in tight curves are not reproducible to 1e-5
+ *            otherwise); positions, headings and all stores are fp32.
+ *            VAP_OPT_F32_RECURRENCE selects an all-fp32 recurrence instead.
  *   VAP_F64  fp64 inputs/outputs, all arithmetic fp64.
  */
 #ifndef VAP_H
@@ -88,9 +90,17 @@ int vap_ctx_synchronize(vap_ctx *ctx);
  * collapsed limits (bit-identical to RELAX).  RELAX_BLOCK is the workgroup-per-path kernel RELAX uses;
  * RELAX_WAVE (fp32) walks each path with one wave in stream-ordered windows — exact as well, kept for
  * experiments (slower on MI355X for the sizes measured). */
-enum { VAP_OPT_VELOCITY_KERNEL = 0 };
+enum { VAP_OPT_VELOCITY_KERNEL = 0, VAP_OPT_F32_RECURRENCE = 1 };
 enum { VAP_VELOCITY_AUTO = 0, VAP_VELOCITY_SEQ_LITERAL = 1, VAP_VELOCITY_SEQ_FAST = 2, VAP_VELOCITY_RELAX = 3,
        VAP_VELOCITY_RELAX_BLOCK = 4 /* workgroup per path */, VAP_VELOCITY_RELAX_WAVE = 5 /* wave per path, fp32 */ };
+/* VAP_OPT_F32_RECURRENCE: arithmetic of the forward/backward velocity recurrence in VAP_F32 calls.
+ *   VAP_RECURRENCE_F64 (default): the sampling kernel keeps fp64 curvature / heading-difference rows in
+ *     context scratch and the recurrence runs in fp64 on them; inputs and every output row stay fp32.  The
+ *     reference's recurrence amplifies a rounding error by track_width*curvature/2 per step in curves tighter
+ *     than 2/track_width, so only this mode holds 1e-5 against the reference on every path.
+ *   VAP_RECURRENCE_F32: rows and recurrence in fp32 — faster, and within 1e-5 on ~98.6 % of config-3-shaped
+ *     paths (worst sample 7e-5). */
+enum { VAP_RECURRENCE_F64 = 0, VAP_RECURRENCE_F32 = 1 };
 int vap_ctx_set_option(vap_ctx *ctx, int option, int value);
 /* Enable/disable per-stage hipEvent timing (replaces the reference's time.time() log lines,
  * SM:587-594, MPG:398-411).  Off by default. */
@@ -143,7 +153,10 @@ int vap_sample(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd, const
  * plain-node default max_vel with start/end velocities at the ends.  Entry 0 and the end sample are
  * taken from start_vel / end_vel.  Rows that fit the register-resident relaxation kernel (20 480
  * samples fp32, 10 240 fp64) run there, longer ones in the one-lane sequential sweep.
- * d_dtheta NULL = the rows the last vap_profile_batch of this shape left on the context. */
+ * d_dtheta NULL = the rows the last sampling call (vap_sample / vap_profile_batch) of this shape and dtype
+ * left on the context; for VAP_F32 with VAP_RECURRENCE_F64 these are fp64 curvature AND |dtheta| rows
+ * (d_curvature is then not read and may be NULL) and the recurrence runs in fp64.  With an explicit d_dtheta
+ * the recurrence runs in `dt` on the caller's rows. */
 int vap_velocity_pass(vap_ctx *ctx, vap_dtype dt, int B, int S, const vap_constraints *c,
                       double start_vel, double end_vel, const double *d_meta,
                       const void *d_curvature, const void *d_dtheta, const void *d_vcap,

@@ -22,10 +22,22 @@ def torch_mod():
     return torch
 
 
+def make_gen(dtype, **kw):
+    """"f32" = fp32 rows with the fp64 recurrence behind them (the default mode), "f32r32" = the all-fp32
+    recurrence (VAP_RECURRENCE_F32), "f64" = fp64 throughout."""
+    from vexautonomousplanner_amd.batch import BatchedTrajectoryGenerator
+    if dtype == "f32r32":
+        return BatchedTrajectoryGenerator(0, "f32", recurrence="f32", **kw)
+    return make_gen(dtype, **kw)
+
+
 @pytest.fixture(scope="module")
 def gens(torch_mod):
-    from vexautonomousplanner_amd.batch import BatchedTrajectoryGenerator
-    return {"f32": BatchedTrajectoryGenerator(0, "f32"), "f64": BatchedTrajectoryGenerator(0, "f64")}
+    return {k: make_gen(k) for k in ("f32", "f32r32", "f64")}
+
+
+DTYPES_TOL = [("f32", 1e-5), ("f32r32", 1e-5), ("f64", 1e-9)]
+DTYPES = ["f32", "f32r32", "f64"]
 
 
 def check_fields(got, ref, tol, what=""):
@@ -55,7 +67,7 @@ GOLDEN_FIXED = [n for n in gu.names(("c3_", "c5_", "c2_w256_S20000", "cons_")) i
 GOLDEN_DD = [n for n in gu.names(("plain_", "c1_", "cons_")) if n.startswith("cons_") is False or n.endswith("_w8")]
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 1e-5), ("f64", 1e-9)])
+@pytest.mark.parametrize("dtype,tol", DTYPES_TOL)
 @pytest.mark.parametrize("name", GOLDEN_FIXED)
 def test_fixed_grid_vs_reference_golden(torch_mod, gens, name, dtype, tol):
     g = gu.load(name)
@@ -71,7 +83,7 @@ def test_fixed_grid_vs_reference_golden(torch_mod, gens, name, dtype, tol):
     check_fields(got, ref, tol, f"{name}/{dtype}")
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 1e-5), ("f64", 1e-9)])
+@pytest.mark.parametrize("dtype,tol", DTYPES_TOL)
 @pytest.mark.parametrize("name", GOLDEN_DD)
 def test_reference_grid_vs_reference_golden(torch_mod, gens, name, dtype, tol):
     g = gu.load(name)
@@ -141,12 +153,15 @@ def _staged_velocity(torch, dtype, wp64, cons, vcap64, dd, cap, kernel):
     from vexautonomousplanner_amd import _lib
     L = _lib.lib()
     dev = torch.device("cuda:0")
-    td = torch.float32 if dtype == "f32" else torch.float64
-    vd = _lib.VAP_F32 if dtype == "f32" else _lib.VAP_F64
+    td = torch.float64 if dtype == "f64" else torch.float32
+    vd = _lib.VAP_F64 if dtype == "f64" else _lib.VAP_F32
     B, W = wp64.shape[:2]
     ctx = _lib.Context(0)
     ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     ctx.set_option(_lib.OPT_VELOCITY_KERNEL, kernel)
+    ctx.set_option(_lib.OPT_F32_RECURRENCE, _lib.RECURRENCE_F32 if dtype == "f32r32" else _lib.RECURRENCE_F64)
+    # "f32": the velocity pass takes the fp64 rows vap_sample left on the context (d_dtheta = NULL)
+    ctx_rows = dtype == "f32"
     c = _lib.make_constraints(cons)
     p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
     wp = torch.tensor(wp64, device=dev, dtype=td)
@@ -161,14 +176,14 @@ def _staged_velocity(torch, dtype, wp64, cons, vcap64, dd, cap, kernel):
     _lib.check(L.vap_build_lut(ctx.handle, B, W, p(seg), p(lut), p(meta), p(flags)), "vap_build_lut")
     _lib.check(L.vap_sample(ctx.handle, vd, B, W, cap, dd, p(seg), p(lut), p(meta), p(o["x"]), p(o["y"]), p(o["heading"]),
                             p(o["curvature"]), p(o["dtheta"]), p(flags)), "vap_sample")
-    _lib.check(L.vap_velocity_pass(ctx.handle, vd, B, cap, C.byref(c), 0.01, 0.01, p(meta), p(o["curvature"]), p(o["dtheta"]),
-                                   p(vc), p(o["velocity"]), p(flags)), "vap_velocity_pass")
+    _lib.check(L.vap_velocity_pass(ctx.handle, vd, B, cap, C.byref(c), 0.01, 0.01, p(meta), p(o["curvature"]),
+                                   None if ctx_rows else p(o["dtheta"]), p(vc), p(o["velocity"]), p(flags)), "vap_velocity_pass")
     torch.cuda.synchronize()
     assert not flags.any().item()
     return o["velocity"].cpu().numpy().astype(np.float64), meta[:, 3].cpu().numpy().astype(int)
 
 
-@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,W,S", [(6, 8, 1000), (3, 32, 10000), (5, 5, 257), (4, 2, 64)])
 def test_initial_velocities_relaxation_equals_sequential_sweep(torch_mod, dtype, B, W, S):
     """d_vcap (per-sample initial velocities, MPG:121,127,153,172) in the register-resident relaxation kernel
@@ -192,7 +207,7 @@ def test_initial_velocities_relaxation_equals_sequential_sweep(torch_mod, dtype,
     assert np.any(v_rel < v_plain * 0.99)       # the limits bind somewhere
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 1e-5), ("f64", 1e-9)])
+@pytest.mark.parametrize("dtype,tol", DTYPES_TOL)
 def test_initial_velocities_stop_node_vs_reference_golden(torch_mod, dtype, tol):
     """feat_stop (the real reference, a stop at node 3): the batched path with the reference's initial velocity
     list as d_vcap reproduces forward_backward_pass."""
@@ -214,7 +229,7 @@ def test_initial_velocities_stop_node_vs_reference_golden(torch_mod, dtype, tol)
         assert err <= tol
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 1e-5), ("f64", 1e-9)])
+@pytest.mark.parametrize("dtype,tol", DTYPES_TOL)
 def test_initial_velocities_node_limits_vs_oracle(torch_mod, dtype, tol):
     """Per-node max_velocity and stops on random 8-waypoint routes: oracle (node semantics of MPG:100-176) against
     the batched path fed with the initial-velocity rows."""
@@ -248,7 +263,7 @@ def test_initial_velocities_node_limits_vs_oracle(torch_mod, dtype, tol):
         assert err <= tol, (b, err)
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 1e-5), ("f64", 1e-9)])
+@pytest.mark.parametrize("dtype,tol", DTYPES_TOL)
 def test_apply_node_limits_stop_golden(torch_mod, gens, dtype, tol):
     """feat_stop (real reference): profile() then apply_node_limits(node_stop=...) on the reference's grid."""
     g = gu.load("feat_stop")
@@ -268,7 +283,7 @@ def test_apply_node_limits_stop_golden(torch_mod, gens, dtype, tol):
     assert float(r["vcap"][0, k]) == pytest.approx(0.01)
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 1e-5), ("f64", 1e-9)])
+@pytest.mark.parametrize("dtype,tol", DTYPES_TOL)
 @pytest.mark.parametrize("use_dd", [True, False])
 def test_apply_node_limits_vs_oracle(torch_mod, gens, dtype, tol, use_dd):
     """Random routes with node max_velocity / stop and action points (max_velocity / stop): the batched path
@@ -339,7 +354,7 @@ def _apply_golden_limits(torch_mod, gen, g):
     return r["velocity"][0, :N].cpu().numpy().astype(np.float64)
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 1e-5), ("f64", 1e-9)])
+@pytest.mark.parametrize("dtype,tol", DTYPES_TOL)
 @pytest.mark.parametrize("name", ["feat_limits", "feat_action", "feat_stop"])
 def test_apply_node_limits_vs_reference_golden(torch_mod, gens, name, dtype, tol):
     """Golden routes of the real reference with node max_velocity / max_acceleration (feat_limits), action points
@@ -409,7 +424,7 @@ def test_apply_node_limits_with_accelerations_vs_oracle(torch_mod, gens, dtype, 
         assert err <= tol, (b, err)
 
 
-@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("S", [200, 3000, 9000])
 def test_acceleration_rows_relaxation_equals_sequential_sweep(torch_mod, dtype, S):
     """vap_velocity_pass_limits with per-sample max_acceleration rows: the relaxation kernel against the one-lane
@@ -421,7 +436,7 @@ def test_acceleration_rows_relaxation_equals_sequential_sweep(torch_mod, dtype, 
     torch = torch_mod
     rng = np.random.default_rng(S)
     B, W = 5, 8
-    gen = BatchedTrajectoryGenerator(0, dtype)
+    gen = make_gen(dtype)
     wp = torch.tensor(make_waypoints(B, W, 13), dtype=gen.tdtype, device=gen.device)
     r = gen.profile(wp, DEFAULT_CONSTRAINTS, samples=S)
 
@@ -447,12 +462,12 @@ def test_acceleration_rows_relaxation_equals_sequential_sweep(torch_mod, dtype, 
         out[kernel] = v.cpu().numpy().astype(np.float64)
     assert np.array_equal(out[_lib.VELOCITY_SEQ_FAST], out[_lib.VELOCITY_AUTO])
     lit = out[_lib.VELOCITY_SEQ_LITERAL]
-    tol = 3e-5 if dtype == "f32" else 1e-9
+    tol = 3e-5 if dtype == "f32r32" else (2e-7 if dtype == "f32" else 1e-9)
     assert np.max(np.abs(out[_lib.VELOCITY_AUTO] - lit) / lit) <= tol
     assert not r["flags"].any().item()
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 1e-5), ("f64", 1e-9)])
+@pytest.mark.parametrize("dtype,tol", DTYPES_TOL)
 @pytest.mark.parametrize("B,W,S,seed", [(64, 8, 1024, 5), (48, 32, 2000, 3), (3, 2, 300, 9), (5, 5, 257, 10)])
 def test_batch_vs_oracle(torch_mod, gens, B, W, S, seed, dtype, tol):
     from oracle import oracle
@@ -484,7 +499,7 @@ def test_invalid_arguments(torch_mod, gens):
         gen.profile(wp)
 
 
-@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,W,S,seed", [(8, 32, 10000, 3), (33, 8, 1024, 5), (5, 5, 257, 10), (4, 32, 4097, 12),
                                         (3, 2, 64, 9), (2, 16, 7001, 13)])
 def test_relaxation_is_bit_identical_to_sequential_sweep(torch_mod, B, W, S, seed, dtype):
@@ -492,28 +507,26 @@ def test_relaxation_is_bit_identical_to_sequential_sweep(torch_mod, B, W, S, see
     sweep (K5a, same step arithmetic) computes: compare bit patterns, not tolerances."""
     from vexautonomousplanner_amd.batch import BatchedTrajectoryGenerator
     from vexautonomousplanner_amd.synth import make_waypoints
-    if dtype == "f64" and S > 8192:
-        pytest.skip("fp64 relaxation kernel covers S <= 8192")
     wp = make_waypoints(B, W, seed).astype(np.float64)
     outs = {}
     for which in ("relax", "seq_fast", "seq_literal"):
-        gen = BatchedTrajectoryGenerator(0, dtype, velocity_kernel=which)
+        gen = make_gen(dtype, velocity_kernel=which)
         r = run_gpu(torch_mod, gen, wp, samples=S)
         assert np.all(r["flags"] == 0), which
         outs[which] = r["velocity"]
     assert np.array_equal(outs["relax"], outs["seq_fast"])
-    tol = 5e-6 if dtype == "f32" else 1e-9  # two fp32 roundings of the same recurrence
+    tol = {"f32r32": 5e-6, "f32": 2e-7, "f64": 1e-9}[dtype]  # two fp32 roundings of the same recurrence
     assert np.max(np.abs(outs["seq_fast"] - outs["seq_literal"]) / outs["seq_literal"]) <= tol
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 1e-5), ("f64", 1e-9)])
+@pytest.mark.parametrize("dtype,tol", DTYPES_TOL)
 def test_relaxation_on_reference_grid_ragged_rows(torch_mod, dtype, tol):
     """dd-mode (ragged n_samples per path) through the relaxation kernel, against the oracle."""
     from oracle import oracle
     from vexautonomousplanner_amd.batch import BatchedTrajectoryGenerator
     from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
     wp = make_waypoints(6, 8, 21).astype(np.float64)
-    gen = BatchedTrajectoryGenerator(0, dtype, velocity_kernel="relax")
+    gen = make_gen(dtype, velocity_kernel="relax")
     r = run_gpu(torch_mod, gen, wp, dd=0.005, capacity=2048)
     for b in range(len(wp)):
         p = oracle.OraclePath(wp[b])
@@ -526,7 +539,7 @@ def test_relaxation_on_reference_grid_ragged_rows(torch_mod, dtype, tol):
         assert np.all(r["velocity"][b][N:] == 0)
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 1e-5), ("f64", 1e-9)])
+@pytest.mark.parametrize("dtype,tol", DTYPES_TOL)
 def test_config2_million_samples_vs_reference_golden(torch_mod, gens, dtype, tol):
     """BASELINE config 2: one 256-waypoint path at 1e6 samples.  Four samples share each table entry
     here, so the reference's divide-by-zero semantics (inf clamps the acceleration, NaN is skipped,
@@ -547,7 +560,7 @@ def test_config2_million_samples_vs_reference_golden(torch_mod, gens, dtype, tol
     assert np.mean(k[1:] == k[:-1]) > 0.5
 
 
-@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_dup_path_relaxation_matches_sequential(torch_mod, dtype):
     """A dense grid short enough for the relaxation kernel (samples sharing table entries): the
     DUP step forms of the relaxation and the sequential sweep must agree bit for bit."""
@@ -558,17 +571,17 @@ def test_dup_path_relaxation_matches_sequential(torch_mod, dtype):
     for w, S in ((wp3, 8000), (wp, 7000)):
         outs = {}
         for which in ("relax", "seq_fast", "seq_literal"):
-            gen = BatchedTrajectoryGenerator(0, dtype, velocity_kernel=which)
+            gen = make_gen(dtype, velocity_kernel=which)
             r = run_gpu(torch_mod, gen, w, samples=S)
             assert np.all(r["flags"] == 0)
             outs[which] = r["velocity"]
             kk = r["curvature"]
         assert np.array_equal(outs["relax"], outs["seq_fast"])
-        tol = 5e-6 if dtype == "f32" else 1e-9
+        tol = {"f32r32": 5e-6, "f32": 2e-7, "f64": 1e-9}[dtype]
         assert np.max(np.abs(outs["seq_fast"] - outs["seq_literal"]) / outs["seq_literal"]) <= tol
 
 
-@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,W,S,seed", [(2, 64, 30001, 41), (1, 32, 20481, 42), (3, 16, 45000, 43)])
 def test_long_row_relaxation_is_bit_identical_to_sequential_sweep(torch_mod, B, W, S, seed, dtype):
     """Rows beyond the register-resident kernel go through the two-level relaxation (K5c)."""
@@ -577,7 +590,7 @@ def test_long_row_relaxation_is_bit_identical_to_sequential_sweep(torch_mod, B, 
     wp = make_waypoints(B, W, seed).astype(np.float64)
     outs = {}
     for which in ("relax", "seq_fast"):
-        gen = BatchedTrajectoryGenerator(0, dtype, velocity_kernel=which)
+        gen = make_gen(dtype, velocity_kernel=which)
         r = run_gpu(torch_mod, gen, wp, samples=S)
         assert np.all(r["flags"] == 0), which
         outs[which] = r["velocity"]
@@ -657,7 +670,7 @@ def test_edge_sizes_and_degenerate_inputs(torch_mod, gens):
     assert np.all(np.isfinite(r["velocity"][:2]))
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 1e-5), ("f64", 1e-9)])
+@pytest.mark.parametrize("dtype,tol", DTYPES_TOL)
 @pytest.mark.parametrize("cons", [(4.0, 12.0, 6.0, 0.8, 16.0, 12.5 / 12), (4.0, 6.0, 12.0, 0.8, 16.0, 12.5 / 12),
                                   (7.0, 6.8, 3.7, 0.8, 16.0, 0.70), (2.2, 15.0, 5.3, 0.8, 16.0, 1.14),
                                   (5.6, 11.9, 2.8, 0.8, 16.0, 1.18)])
@@ -680,7 +693,7 @@ def test_batch_vs_oracle_other_robots(torch_mod, gens, cons, dtype, tol):
             # steps; its weight grows with max_acc, and at max_acc = 12-15 ft/s^2 the worst sample of a tight
             # curve sits right at 1e-5 (literal and fast form alike) where the default robot stays below 2.3e-6
             check_fields({k: r[k] for k in ("x", "y", "heading", "curvature", "velocity")}, ref,
-                         tol if dtype == "f64" else 3e-5, f"{cons} W={W} S={S} {mode}/{dtype}")
+                         3e-5 if dtype == "f32r32" else tol, f"{cons} W={W} S={S} {mode}/{dtype}")
 
 
 # ---- batched time-domain resample (vap_time_profile; SURVEY §8(f)-1 at batch scale) -----------------
@@ -689,7 +702,7 @@ def _time_profile(dtype, wp, dt=0.01, cap=4096, cons=None):
     from vexautonomousplanner_amd.batch import BatchedTrajectoryGenerator
     from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS
     cons = DEFAULT_CONSTRAINTS if cons is None else cons
-    gen = BatchedTrajectoryGenerator(0, dtype)
+    gen = make_gen(dtype)
     t = torch.tensor(wp, device="cuda:0", dtype=torch.float64 if dtype == "f64" else torch.float32)
     res = gen.profile(t, cons, dd=0.005, capacity=16384)
     tp = gen.time_profile(res, cons, dt=dt, capacity_rows=cap)
@@ -760,7 +773,7 @@ def _full_route_profile(torch, g_or_route, cons, dtype="f64"):
     (waypoints, node_* , ap_*); returns rows, nodes_map, actions_map as numpy."""
     from vexautonomousplanner_amd.batch import BatchedTrajectoryGenerator
     r_ = g_or_route
-    gen = BatchedTrajectoryGenerator(0, dtype)
+    gen = make_gen(dtype)
     wp = torch.tensor(np.asarray(r_["waypoints"])[None], device="cuda:0", dtype=gen.tdtype)
     aps = None
     if "ap_t" in r_ and len(r_["ap_t"]):
@@ -922,7 +935,7 @@ def test_time_profile_argument_errors(torch_mod):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_staged_api_equals_fused_call(torch_mod, dtype):
     """vap_fit -> vap_build_lut -> vap_sample -> vap_velocity_pass -> vap_time_profile with caller-owned
     buffers on a batch of 5 paths gives the fused vap_profile_batch (+ time_profile) results bit for bit."""
@@ -933,17 +946,18 @@ def test_staged_api_equals_fused_call(torch_mod, dtype):
     torch = torch_mod
     L = _lib.lib()
     dev = torch.device("cuda:0")
-    td = torch.float32 if dtype == "f32" else torch.float64
-    vd = _lib.VAP_F32 if dtype == "f32" else _lib.VAP_F64
+    td = torch.float64 if dtype == "f64" else torch.float32
+    vd = _lib.VAP_F64 if dtype == "f64" else _lib.VAP_F32
     B, W, S, cap_rows = 5, 8, 2000, 1024
     wp = torch.tensor(make_waypoints(B, W, 41), device=dev, dtype=td)
-    gen = BatchedTrajectoryGenerator(0, dtype)
+    gen = make_gen(dtype)
     fused = gen.profile(wp, DEFAULT_CONSTRAINTS, samples=S)
     fused_tp = gen.time_profile(fused, DEFAULT_CONSTRAINTS, capacity_rows=cap_rows)
     torch.cuda.synchronize()
 
     ctx = _lib.Context(0)
     ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    ctx.set_option(_lib.OPT_F32_RECURRENCE, _lib.RECURRENCE_F32 if dtype == "f32r32" else _lib.RECURRENCE_F64)
     c = _lib.make_constraints(DEFAULT_CONSTRAINTS)
     p = lambda t: C.c_void_p(t.data_ptr())
     seg = torch.empty((B, W - 1, 6, 2), dtype=torch.float64, device=dev)
@@ -956,8 +970,16 @@ def test_staged_api_equals_fused_call(torch_mod, dtype):
     _lib.check(L.vap_build_lut(ctx.handle, B, W, p(seg), p(lut), p(meta), p(flags)), "vap_build_lut")
     _lib.check(L.vap_sample(ctx.handle, vd, B, W, S, 0.0, p(seg), p(lut), p(meta), p(out["x"]), p(out["y"]), p(out["heading"]),
                             p(out["curvature"]), p(out["dtheta"]), p(flags)), "vap_sample")
-    _lib.check(L.vap_velocity_pass(ctx.handle, vd, B, S, C.byref(c), 0.01, 0.01, p(meta), p(out["curvature"]), p(out["dtheta"]),
-                                   None, p(out["velocity"]), p(flags)), "vap_velocity_pass")
+    # "f32": the fp64 recurrence reads the fp64 rows vap_sample left on the context (d_dtheta = NULL)
+    _lib.check(L.vap_velocity_pass(ctx.handle, vd, B, S, C.byref(c), 0.01, 0.01, p(meta), p(out["curvature"]),
+                                   None if dtype == "f32" else p(out["dtheta"]), None, p(out["velocity"]), p(flags)), "vap_velocity_pass")
+    if dtype == "f32":
+        # ... and with explicit fp32 rows the same call runs the all-fp32 recurrence: close, not identical
+        v32 = torch.empty_like(out["velocity"])
+        _lib.check(L.vap_velocity_pass(ctx.handle, vd, B, S, C.byref(c), 0.01, 0.01, p(meta), p(out["curvature"]), p(out["dtheta"]),
+                                       None, p(v32), p(flags)), "vap_velocity_pass")
+        torch.cuda.synchronize()
+        assert float(((v32 - out["velocity"]).abs() / out["velocity"]).max()) < 1e-4
     rows = torch.zeros((B, cap_rows, 8), dtype=torch.float64, device=dev)
     counts = torch.zeros((B, 2), dtype=torch.int32, device=dev)
     nmap = torch.zeros((B, W), dtype=torch.int32, device=dev)

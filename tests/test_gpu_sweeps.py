@@ -1,0 +1,192 @@
+"""GPU parity at scale: the rate of paths outside the bound on random sweeps, and every BASELINE config at its
+per-GPU size.
+
+The curated cases of test_gpu_parity.py say "these paths hold the bound"; the tests here say how many random ones
+do (north_star: <= 1e-5 relative against the reference, point for point):
+
+  * config-3 shape (32 waypoints x 10 000 samples), 2048 random paths against the oracle, per mode:
+      "f32"    fp32 rows, fp64 recurrence (the default, the mode bench.py quotes `value` on): EVERY path inside
+      "f32r32" all-fp32 recurrence: the rate is recorded and bounded (1.4 % of paths when this was written:
+               the reference's recurrence amplifies rounding errors in curves tighter than 2/track_width)
+      "f64"    1e-7 (rounding-level differences of the inputs, amplified by the same mechanism; median 1e-12)
+  * a seeded slice of tools/fuzz_parity.py (random shapes, robots, grids, start / end velocities)
+  * config 3, config 4's per-GPU share, config 5's per-GPU share: flags, bounds on every velocity, traversal times,
+    and a random 64-path subset against the oracle.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+def make_gen(dtype, **kw):
+    from vexautonomousplanner_amd.batch import BatchedTrajectoryGenerator
+    if dtype == "f32r32":
+        return BatchedTrajectoryGenerator(0, "f32", recurrence="f32", **kw)
+    return BatchedTrajectoryGenerator(0, dtype, **kw)
+
+
+def per_path_errors(got, ref):
+    """Worst sample of every path, the measures of test_gpu_parity.py."""
+    e = {"velocity": np.max(np.abs(got["velocity"] - ref["velocity"]) / np.abs(ref["velocity"]), axis=1),
+         "curvature": np.max(np.abs(got["curvature"] - ref["curvature"]) / np.maximum(np.abs(ref["curvature"]), 1e-2), axis=1),
+         "heading": np.max(np.abs(got["heading"] - ref["heading"]), axis=1) / np.pi,
+         "x": np.max(np.abs(got["x"] - ref["x"]) / np.maximum(np.abs(ref["x"]), 1.0), axis=1),
+         "y": np.max(np.abs(got["y"] - ref["y"]) / np.maximum(np.abs(ref["y"]), 1.0), axis=1)}
+    return e
+
+
+def run(torch, gen, wp64, **kw):
+    wp = torch.tensor(wp64, dtype=gen.tdtype, device=gen.device)
+    r = gen.profile(wp, **kw)
+    torch.cuda.synchronize()
+    return {k: (v.cpu().numpy().astype(np.float64) if k != "flags" else v.cpu().numpy()) for k, v in r.items()}
+
+
+SWEEP_PATHS = 2048
+
+
+@pytest.fixture(scope="module")
+def config3_sweep():
+    """2048 random config-3-shaped paths (the generator of SURVEY 8(d), a seed no fixture uses) and the oracle's rows."""
+    from oracle import oracle
+    from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
+    wp = make_waypoints(SWEEP_PATHS, 32, 12345).astype(np.float32).astype(np.float64)   # what an fp32 caller hands over
+    ref = oracle.profile_batch(wp, 10000, DEFAULT_CONSTRAINTS, n_threads=16)
+    return wp, ref
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f32r32", "f64"])
+def test_config3_sweep_rate_of_paths_outside_the_bound(torch_mod, config3_sweep, dtype):
+    wp, ref = config3_sweep
+    gen = make_gen(dtype)
+    got = run(torch_mod, gen, wp, samples=10000)
+    assert not got["flags"].any()
+    e = per_path_errors(got, ref)
+    worst = {k: float(v.max()) for k, v in e.items()}
+    bound = 1e-7 if dtype == "f64" else 1e-5
+    frac = float(np.mean(e["velocity"] > bound))
+    print(f"config-3 sweep {dtype}: {SWEEP_PATHS} paths, velocity worst {worst['velocity']:.2e} median {np.median(e['velocity']):.2e} "
+          f"frac above {bound:g}: {frac:.4f}; curvature {worst['curvature']:.2e} heading {worst['heading']:.2e} x {worst['x']:.2e} y {worst['y']:.2e}")
+    geo = 1e-9 if dtype == "f64" else 1e-5
+    assert worst["curvature"] <= geo and worst["heading"] <= geo and worst["x"] <= geo and worst["y"] <= geo
+    if dtype == "f32r32":
+        # the all-fp32 recurrence: recorded, and bounded so that it cannot get worse unnoticed
+        assert frac <= 0.03 and worst["velocity"] <= 5e-4
+    else:
+        assert frac == 0.0, f"{int(frac * SWEEP_PATHS)} paths above {bound:g} (worst {worst['velocity']:.2e})"
+        if dtype == "f32":
+            assert worst["velocity"] <= 2e-6    # far inside: output rounding plus the amplified input differences
+
+
+FUZZ_CASES = 160
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-5), ("f64", 1e-7)])
+def test_fuzz_slice_random_shapes_robots_grids(torch_mod, dtype, tol):
+    """A seeded slice of tools/fuzz_parity.py: random W, S, batch, robot, start / end velocity, fixed-S grid or the
+    reference's own dd grid (ragged rows) — every case inside the bound, sample counts equal."""
+    from oracle import oracle
+    from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
+    torch = torch_mod
+    rng = np.random.default_rng(20261004)
+    gen = make_gen(dtype)
+    worst = {}
+    fails = []
+    for case in range(FUZZ_CASES):
+        W = int(rng.choice([2, 3, 4, 5, 8, 13, 32, 57, 113]))
+        S = int(rng.choice([2, 3, 7, 64, 255, 256, 257, 1000, 1024, 1025, 4096, 4097, 10000, 20481]))
+        B = int(rng.integers(1, 9)) if S <= 10000 else 1
+        seed = int(rng.integers(0, 1 << 30))
+        cons = list(DEFAULT_CONSTRAINTS)
+        if rng.random() < 0.5:
+            cons[0] = float(rng.uniform(1.0, 8.0))
+            cons[1] = float(rng.uniform(2.0, 16.0))
+            cons[2] = float(rng.uniform(2.0, 16.0))
+            cons[5] = float(rng.uniform(0.5, 2.0))
+        wp = make_waypoints(B, W, seed).astype(np.float32).astype(np.float64)
+        sv, ev = 0.01, 0.01
+        if rng.random() < 0.3:
+            sv, ev = float(rng.uniform(0.01, 2.0)), float(rng.uniform(0.01, 2.0))
+        use_dd = S <= 4097 and rng.random() < 0.3
+        if use_dd:
+            dd = float(rng.uniform(0.002, 0.02))
+            per = []
+            for b in range(B):
+                op = oracle.OraclePath(wp[b])
+                op.rebuild_tables()
+                per.append(op.forward_backward(cons, dd=dd, start_vel=sv, end_vel=ev))
+            cap = max(len(p["velocity"]) for p in per) + 3
+            ref = {k: np.zeros((B, cap)) for k in ("x", "y", "heading", "curvature", "velocity")}
+            for b, pth in enumerate(per):
+                for k in ref:
+                    ref[k][b, :len(pth[k])] = pth[k]
+            pad = ref["velocity"] == 0
+            ref["velocity"][pad] = 1.0
+            got = run(torch, gen, wp, constraints=cons, dd=dd, capacity=cap, start_vel=sv, end_vel=ev)
+            n_ref = np.array([len(p["velocity"]) for p in per])
+            assert np.array_equal(got["meta"][:, 3].astype(int), n_ref), (case, W, dd, seed)
+            assert np.all(got["velocity"][pad] == 0)
+            got["velocity"][pad] = 1.0
+        else:
+            ref = oracle.profile_batch(wp, S, cons, start_vel=sv, end_vel=ev, n_threads=8)
+            got = run(torch, gen, wp, constraints=cons, samples=S, start_vel=sv, end_vel=ev)
+        assert not got["flags"].any(), (case, got["flags"])
+        e = {k: float(v.max()) for k, v in per_path_errors(got, ref).items()}
+        for k, v in e.items():
+            worst[k] = max(worst.get(k, 0.0), v)
+        geo = 1e-9 if dtype == "f64" else 1e-5
+        if not (e["velocity"] <= tol and all(e[k] <= geo for k in ("curvature", "heading", "x", "y"))):
+            fails.append((case, B, W, S, "dd" if use_dd else "fixed", seed, cons, e))
+    print(f"fuzz slice {dtype}: {FUZZ_CASES} cases, worst " + " ".join(f"{k} {v:.2e}" for k, v in worst.items()))
+    assert not fails, fails
+
+
+CONFIGS = {
+    "c3": dict(paths=4096, W=32, S=10000, seed=3),          # BASELINE config 3
+    "c4_share": dict(paths=8192, W=32, S=10000, seed=4),    # config 4: 65 536 paths over 8 GPUs
+    "c5_share": dict(paths=131072, W=8, S=1024, seed=5),    # config 5: 1 M paths over 8 GPUs
+}
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("cfg", sorted(CONFIGS))
+def test_config_at_per_gpu_size(torch_mod, cfg, dtype):
+    """Every batched BASELINE config at the size one GPU sees: no flags, every velocity finite and inside
+    [0.01, max_vel], positive traversal times, and 64 random paths of the batch against the oracle."""
+    from oracle import oracle
+    from vexautonomousplanner_amd import dist as vdist
+    from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
+    torch = torch_mod
+    c = CONFIGS[cfg]
+    B, W, S = c["paths"], c["W"], c["S"]
+    gen = make_gen(dtype)
+    wp64 = make_waypoints(B, W, c["seed"]).astype(np.float32).astype(np.float64)
+    wp = torch.tensor(wp64, dtype=gen.tdtype, device=gen.device)
+    r = gen.profile(wp, DEFAULT_CONSTRAINTS, samples=S)
+    torch.cuda.synchronize()
+    assert int(r["flags"].abs().max().item()) == 0
+    v = r["velocity"]
+    assert bool(torch.isfinite(v).all().item())
+    vmax = DEFAULT_CONSTRAINTS[0]
+    assert float(v.min().item()) >= 0.01 * (1 - 1e-5) and float(v.max().item()) <= vmax * (1 + 1e-6)
+    for k in ("x", "y", "heading", "curvature"):
+        assert bool(torch.isfinite(r[k]).all().item()), k
+    summ = vdist.path_summaries(r["meta"], v)
+    assert float(summ[:, 2].min().item()) > 0.0 and bool(torch.isfinite(summ).all().item())
+    assert bool((r["meta"][:, 3] == S).all().item())
+    idx = np.sort(np.random.default_rng(c["seed"]).choice(B, size=64, replace=False))
+    ref = oracle.profile_batch(wp64[idx], S, DEFAULT_CONSTRAINTS, n_threads=16)
+    tidx = torch.tensor(idx, device=gen.device)
+    got = {k: r[k][tidx].cpu().numpy().astype(np.float64) for k in ("x", "y", "heading", "curvature", "velocity")}
+    e = {k: float(val.max()) for k, val in per_path_errors(got, ref).items()}
+    print(f"{cfg}/{dtype}: {B} x {W} x {S}; 64-path subset worst " + " ".join(f"{k} {val:.2e}" for k, val in e.items()))
+    tol_v, tol_g = (1e-7, 1e-9) if dtype == "f64" else (1e-5, 1e-5)
+    assert e["velocity"] <= tol_v and all(e[k] <= tol_g for k in ("curvature", "heading", "x", "y")), e

@@ -24,6 +24,8 @@ FLAG_TRUNCATED = 2
 FLAG_NOCONVERGE = 4
 T_FIT, T_LUT, T_SAMPLE, T_VELOCITY, T_TOTAL, T_COUNT = 0, 1, 2, 3, 4, 8
 OPT_VELOCITY_KERNEL = 0
+OPT_F32_RECURRENCE = 1
+RECURRENCE_F64, RECURRENCE_F32 = 0, 1
 VELOCITY_AUTO, VELOCITY_SEQ_LITERAL, VELOCITY_SEQ_FAST, VELOCITY_RELAX = 0, 1, 2, 3
 VELOCITY_RELAX_BLOCK, VELOCITY_RELAX_WAVE = 4, 5
 LUT_SAMPLES = 1000

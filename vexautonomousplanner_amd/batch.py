@@ -26,7 +26,11 @@ class BatchedTrajectoryGenerator:
     """rebuild_tables + forward_backward_pass (SM:582-594, MPG:70-316) for B independent
     plain-node paths per call, outputs resident in HBM as (B, S) tensors."""
 
-    def __init__(self, device=0, dtype="f32", timing=False, velocity_kernel="auto"):
+    def __init__(self, device=0, dtype="f32", timing=False, velocity_kernel="auto", recurrence="f64"):
+        """dtype "f32" | "f64": type of inputs and outputs.  recurrence (dtype "f32" only): "f64" (default) carries
+        the velocity recurrence and its curvature / heading-difference rows in fp64 behind the fp32 outputs — the
+        mode that holds 1e-5 against the reference on every path; "f32" is the all-fp32 recurrence (faster,
+        ~1.4 % of config-3-shaped paths have a sample above 1e-5)."""
         if not torch.cuda.is_available():
             raise RuntimeError("no HIP device visible: vexautonomousplanner_amd has no CPU path")
         self.device = torch.device("cuda", device)
@@ -36,6 +40,13 @@ class BatchedTrajectoryGenerator:
             self.ctx.set_timing(True)
         self._L = _lib.lib()
         self.set_velocity_kernel(velocity_kernel)
+        self.set_recurrence(recurrence)
+
+    def set_recurrence(self, which):
+        """"f64" | "f32" (VAP_OPT_F32_RECURRENCE; only matters for dtype "f32")."""
+        self.recurrence = {"f64": "f64", "f32": "f32", "fp64": "f64", "fp32": "f32"}[which]
+        self.ctx.set_option(_lib.OPT_F32_RECURRENCE,
+                            _lib.RECURRENCE_F64 if self.recurrence == "f64" else _lib.RECURRENCE_F32)
 
     def set_velocity_kernel(self, which):
         """"auto" | "seq_literal" | "seq_fast" | "relax" | "relax_block" | "relax_wave" (VAP_OPT_VELOCITY_KERNEL)."""
@@ -185,7 +196,8 @@ class BatchedTrajectoryGenerator:
                                             C.byref(c), float(end_vel), ptr(vcap), ptr(acc_f), ptr(acc_b), ptr(dec_b), ptr(node_k),
                                             ptr(ap_k)), "vap_route_limits")
         curv = result.get("curvature")
-        if curv is None:
+        ctx_rows = self.vdtype == _lib.VAP_F32 and self.recurrence == "f64"   # the context holds the fp64 rows itself
+        if curv is None and not ctx_rows:
             raise ValueError("apply_node_limits needs the curvature rows (profile(want=...) must include 'curvature')")
         _lib.check(self._L.vap_velocity_pass_limits(self.ctx.handle, self.vdtype, B, S, C.byref(c), float(start_vel),
                                                     float(end_vel), ptr(meta), ptr(curv), None, ptr(vcap), ptr(acc_f),

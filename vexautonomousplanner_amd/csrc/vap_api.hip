@@ -58,7 +58,9 @@ int check_shape(int B, int W, int S)
 
 
 // K5 dispatch.  auto: register-resident relaxation whenever the row fits, else the sequential sweep.
-int run_velocity(vap_ctx *ctx, bool f64, int B, int S, const double cc[6], double sv, double ev, const double *meta,
+// f64 = arithmetic type of the recurrence = type of the curv / dth rows; io64 = type of the caller's rows (vcap,
+// acc, vel).  f64 && !io64: the fp64 recurrence behind fp32 outputs (VAP_F32 with VAP_RECURRENCE_F64).
+int run_velocity(vap_ctx *ctx, bool f64, bool io64, int B, int S, const double cc[6], double sv, double ev, const double *meta,
                  const void *curv, const void *dth, const void *vcap, const vap::AccRowsV &acc, void *vel, uint32_t *flags)
 {
     int mode = ctx->velocity_kernel;
@@ -74,7 +76,7 @@ int run_velocity(vap_ctx *ctx, bool f64, int B, int S, const double cc[6], doubl
             return vap_fail(VAP_ERR_UNSUPPORTED, "per-sample limits: rows up to %d samples in the relaxation kernel, or the sequential sweep",
                             relax_limit);
         if (forced == VAP_VELOCITY_RELAX_WAVE && (f64 || S > vap::velocity_relax_max_samples(f64)))
-            return vap_fail(VAP_ERR_UNSUPPORTED, "wave-per-path kernel: fp32 rows up to %d samples", vap::velocity_relax_max_samples(false));
+            return vap_fail(VAP_ERR_UNSUPPORTED, "wave-per-path kernel: fp32 recurrence, rows up to %d samples", vap::velocity_relax_max_samples(false));
         // One wave per path (sequential windows) keeps 8 paths resident per CU instead of 2, but measured
         // 2x slower than the workgroup-per-path kernel on config 3 (every wave is then busy every round and
         // two latency-bound waves per SIMD slow each other down): kept selectable, not the default.
@@ -87,18 +89,23 @@ int run_velocity(vap_ctx *ctx, bool f64, int B, int S, const double cc[6], doubl
             HIP_TRY(vap::launch_velocity_windows(ctx->stream, B, S, cc, sv, ev, meta, curv, dth, vel, flags, ctx->ufwd.ptr,
                                                  ctx->lstate.ptr, (int *)ctx->lcount.ptr));
         } else if (S <= vap::velocity_relax_max_samples(f64)) {
-            HIP_TRY(vap::launch_velocity_relax(ctx->stream, f64, B, S, cc, sv, ev, meta, curv, dth, vcap, acc, vel, flags));
+            HIP_TRY(vap::launch_velocity_relax(ctx->stream, f64, io64, B, S, cc, sv, ev, meta, curv, dth, vcap, acc, vel, flags));
         } else {
             // long rows: two-level relaxation (host-synchronised super-rounds)
             VAP_TRY(ctx->ensure(ctx->ufwd, (size_t)B * S * (f64 ? 8 : 4)));
             VAP_TRY(ctx->ensure(ctx->lstate, vap::velocity_long_state_bytes(f64, B, S)));
             VAP_TRY(ctx->ensure(ctx->lcount, vap::velocity_long_counter_bytes(f64, B, S)));
-            HIP_TRY(vap::launch_velocity_long(ctx->stream, f64, B, S, cc, sv, ev, meta, curv, dth, vel, flags,
+            HIP_TRY(vap::launch_velocity_long(ctx->stream, f64, io64, B, S, cc, sv, ev, meta, curv, dth, vel, flags,
                                               ctx->ufwd.ptr, ctx->lstate.ptr, (int *)ctx->lcount.ptr));
         }
     } else {
-        HIP_TRY(vap::launch_velocity_seq(ctx->stream, f64, mode == VAP_VELOCITY_SEQ_FAST, B, S, cc, sv, ev, meta, curv,
-                                         dth, vcap, acc, vel));
+        void *usq = nullptr;
+        if (f64 != io64) {   // the sweeps then run in a scratch row of the arithmetic type
+            VAP_TRY(ctx->ensure(ctx->ufwd, (size_t)B * S * 8));
+            usq = ctx->ufwd.ptr;
+        }
+        HIP_TRY(vap::launch_velocity_seq(ctx->stream, f64, io64, mode == VAP_VELOCITY_SEQ_FAST, B, S, cc, sv, ev, meta, curv,
+                                         dth, vcap, acc, vel, usq));
     }
     return VAP_OK;
 }
@@ -163,7 +170,7 @@ int vap_ctx_destroy(vap_ctx *ctx)
     if (!ctx) return VAP_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    VapBuffer *bufs[] = {&ctx->ufwd, &ctx->lstate, &ctx->lcount, &ctx->seg, &ctx->power, &ctx->lut, &ctx->slopes, &ctx->aux, &ctx->runs, &ctx->meta, &ctx->dth, &ctx->flags, &ctx->small_in,
+    VapBuffer *bufs[] = {&ctx->k64, &ctx->dth64, &ctx->ufwd, &ctx->lstate, &ctx->lcount, &ctx->seg, &ctx->power, &ctx->lut, &ctx->slopes, &ctx->aux, &ctx->runs, &ctx->meta, &ctx->dth, &ctx->flags, &ctx->small_in,
                       &ctx->small_out, &ctx->small_seg, &ctx->small_lut};
     for (VapBuffer *b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
@@ -195,6 +202,11 @@ int vap_ctx_set_option(vap_ctx *ctx, int option, int value)
     if (!ctx) return vap_fail(VAP_ERR_INVALID, "null context");
     if (option == VAP_OPT_VELOCITY_KERNEL && value >= VAP_VELOCITY_AUTO && value <= VAP_VELOCITY_RELAX_WAVE) {
         ctx->velocity_kernel = value;
+        return VAP_OK;
+    }
+    if (option == VAP_OPT_F32_RECURRENCE && (value == VAP_RECURRENCE_F64 || value == VAP_RECURRENCE_F32)) {
+        ctx->f32_recurrence = value;
+        ctx->rows_valid = false;   // rows left by an earlier call belong to the other mode
         return VAP_OK;
     }
     return vap_fail(VAP_ERR_INVALID, "unknown option %d / value %d", option, value);
@@ -262,13 +274,21 @@ int vap_sample(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd, const
     HIP_TRY(vap::launch_power(ctx->stream, (int)n_seg, d_segments, (double *)ctx->power.ptr));
     HIP_TRY(vap::launch_lut_slopes(ctx->stream, B, d_lut, d_meta, (double *)ctx->slopes.ptr));
     HIP_TRY(vap::launch_grid(ctx->stream, B, W, S, dd, d_meta, (double *)ctx->aux.ptr, (double *)ctx->runs.ptr, d_flags));
+    const bool hi = dt == VAP_F32 && ctx->f32_recurrence == VAP_RECURRENCE_F64;
+    if (hi) {
+        VAP_TRY(ctx->ensure(ctx->k64, (size_t)B * S * sizeof(double)));
+        VAP_TRY(ctx->ensure(ctx->dth64, (size_t)B * S * sizeof(double)));
+    }
     HIP_TRY(vap::launch_sample(ctx->stream, dt == VAP_F64, B, W, S, (const double *)ctx->power.ptr, d_lut,
                                (const double *)ctx->slopes.ptr, d_meta, (const double *)ctx->aux.ptr,
-                               (const double *)ctx->runs.ptr, d_x, d_y, d_heading, d_curvature, d_dtheta));
+                               (const double *)ctx->runs.ptr, d_x, d_y, d_heading, d_curvature, d_dtheta,
+                               hi ? (double *)ctx->k64.ptr : nullptr, hi ? (double *)ctx->dth64.ptr : nullptr));
     ctx->grid_B = B;
     ctx->grid_W = W;
     ctx->grid_S = S;
-    ctx->dth_valid = false;
+    ctx->rows_valid = hi;
+    ctx->rows_hi = hi;
+    ctx->rows_dt = dt;
     return VAP_OK;
 }
 
@@ -279,15 +299,25 @@ int vap_velocity_pass_limits(vap_ctx *ctx, vap_dtype dt, int B, int S, const vap
 {
     VAP_TRY(vap_set_device(ctx));
     VAP_TRY(check_shape(B, 2, S));
-    if (!c || !d_meta || !d_curvature || !d_velocity) return vap_fail(VAP_ERR_INVALID, "null buffer");
+    if (!c || !d_meta || !d_velocity) return vap_fail(VAP_ERR_INVALID, "null buffer");
     const bool any_acc = d_acc_forward || d_acc_backward || d_dec_backward;
     if (any_acc && !(d_acc_forward && d_acc_backward && d_dec_backward && d_vcap))
         return vap_fail(VAP_ERR_INVALID, "max_acceleration rows come as a set (forward, backward, dec) together with d_vcap");
-    if (!d_dtheta) {    // the rows the last vap_profile_batch left on the context
-        if (!ctx->dth_valid || ctx->grid_B != B || ctx->grid_S != S || !ctx->dth.ptr)
-            return vap_fail(VAP_ERR_INVALID, "d_dtheta is NULL and the context holds no rows of this shape from vap_profile_batch");
-        d_dtheta = ctx->dth.ptr;
+    bool r64 = dt == VAP_F64;
+    if (!d_dtheta) {    // the rows the last sampling call of this shape and dtype left on the context
+        if (!ctx->rows_valid || ctx->grid_B != B || ctx->grid_S != S || ctx->rows_dt != (int)dt)
+            return vap_fail(VAP_ERR_INVALID, "d_dtheta is NULL and the context holds no rows of this shape and dtype (%d x %d, dtype %d; "
+                            "the last sampling call left %s %d x %d, dtype %d)", B, S, (int)dt, ctx->rows_valid ? "rows of" : "no rows;",
+                            ctx->grid_B, ctx->grid_S, ctx->rows_dt);
+        if (ctx->rows_hi) {   // VAP_F32 with the fp64 recurrence: both rows come from the context, in fp64
+            d_curvature = ctx->k64.ptr;
+            d_dtheta = ctx->dth64.ptr;
+            r64 = true;
+        } else {
+            d_dtheta = ctx->dth.ptr;
+        }
     }
+    if (!d_curvature) return vap_fail(VAP_ERR_INVALID, "null curvature row");
     // Quirk Q9: boundary_map always holds sample 0 (MPG:110), so the reference overwrites max_dec with
     // max_accels[0] — max_acc for a plain node — before the first forward step (MPG:194-196) and never
     // restores it until the pass returns: the backward sweep decelerates with max_acc.  (The time loop
@@ -297,7 +327,7 @@ int vap_velocity_pass_limits(vap_ctx *ctx, vap_dtype dt, int B, int S, const vap
     acc.fwd = d_acc_forward;
     acc.bwd = d_acc_backward;
     acc.dec = d_dec_backward;
-    VAP_TRY(run_velocity(ctx, dt == VAP_F64, B, S, cc, start_vel, end_vel, d_meta, d_curvature, d_dtheta, d_vcap, acc,
+    VAP_TRY(run_velocity(ctx, r64, dt == VAP_F64, B, S, cc, start_vel, end_vel, d_meta, d_curvature, d_dtheta, d_vcap, acc,
                          d_velocity, d_flags));
     return VAP_OK;
 }
@@ -325,7 +355,14 @@ int vap_profile_batch(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd
     VAP_TRY(ctx->ensure(ctx->slopes, (size_t)B * VAP_LUT_SAMPLES * sizeof(double)));
     VAP_TRY(ctx->ensure(ctx->aux, (size_t)B * 4 * sizeof(double)));
     VAP_TRY(ctx->ensure(ctx->runs, (size_t)B * vap::kGridRunBlockDoubles * sizeof(double)));
-    VAP_TRY(ctx->ensure(ctx->dth, n_pts * esz(dt)));
+    // VAP_F32 with the fp64 recurrence (the default): the velocity pass reads fp64 curvature / |dtheta| rows
+    const bool hi = !f64 && ctx->f32_recurrence == VAP_RECURRENCE_F64;
+    if (hi) {
+        VAP_TRY(ctx->ensure(ctx->k64, n_pts * sizeof(double)));
+        VAP_TRY(ctx->ensure(ctx->dth64, n_pts * sizeof(double)));
+    } else {
+        VAP_TRY(ctx->ensure(ctx->dth, n_pts * esz(dt)));
+    }
     double *meta = d_meta;
     if (!meta) {
         VAP_TRY(ctx->ensure(ctx->meta, (size_t)B * 4 * sizeof(double)));
@@ -337,7 +374,7 @@ int vap_profile_batch(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd
         flags = (uint32_t *)ctx->flags.ptr;
     }
     void *curv = d_curvature;
-    if (!curv) {
+    if (!curv && !hi) {
         VAP_TRY(ctx->ensure(ctx->io[7], n_pts * esz(dt)));
         curv = ctx->io[7].ptr;
     }
@@ -361,17 +398,24 @@ int vap_profile_batch(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd
     HIP_TRY(vap::launch_sample(ctx->stream, f64, B, W, S, (const double *)ctx->power.ptr,
                                (const double *)ctx->lut.ptr, (const double *)ctx->slopes.ptr, meta,
                                (const double *)ctx->aux.ptr, (const double *)ctx->runs.ptr, d_x, d_y, d_heading, curv,
-                               ctx->dth.ptr));
+                               hi ? nullptr : ctx->dth.ptr, hi ? (double *)ctx->k64.ptr : nullptr,
+                               hi ? (double *)ctx->dth64.ptr : nullptr));
     tm.mark(VAP_T_SAMPLE);
-    VAP_TRY(run_velocity(ctx, f64, B, S, cc, start_vel, end_vel, meta, curv, ctx->dth.ptr, nullptr, vap::AccRowsV(), d_velocity,
-                         flags));
+    if (hi)
+        VAP_TRY(run_velocity(ctx, true, false, B, S, cc, start_vel, end_vel, meta, ctx->k64.ptr, ctx->dth64.ptr, nullptr,
+                             vap::AccRowsV(), d_velocity, flags));
+    else
+        VAP_TRY(run_velocity(ctx, f64, f64, B, S, cc, start_vel, end_vel, meta, curv, ctx->dth.ptr, nullptr, vap::AccRowsV(),
+                             d_velocity, flags));
     tm.mark(VAP_T_VELOCITY);
     ctx->last_B = B;
     ctx->last_W = W;
     ctx->grid_B = B;
     ctx->grid_W = W;
     ctx->grid_S = S;
-    ctx->dth_valid = true;
+    ctx->rows_valid = true;
+    ctx->rows_hi = hi;
+    ctx->rows_dt = dt;
     return VAP_OK;
 }
 

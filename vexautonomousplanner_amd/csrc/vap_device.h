@@ -291,6 +291,31 @@ __device__ __forceinline__ float dtheta_f32(double ax, double ay, double bx, dou
     return fabsf(fmaf(n, 6.283185307179586f, dl));
 }
 
+// The same difference in fp64 for the fp64 recurrence behind fp32 outputs ("strict" VAP_F32):
+// the angle between the two fp64 derivative vectors from atan's series in z = cross/dot (|z| < 0.06 for any
+// pair of neighbouring table entries of a smooth path: truncation < 1e-17), plus the 2*pi multiple of the raw
+// headings.  Relative error ~1e-16, i.e. tighter than the reference's own difference of two rounded atan2 values.
+__device__ __forceinline__ double dtheta_f64(double ax, double ay, double bx, double by, float tha, float thb)
+{
+    const double cr = fma(ax, by, -(ay * bx));
+    const double dt = fma(ax, bx, ay * by);
+    double dl;
+    double r = __builtin_amdgcn_rcp(dt);
+    r = fma(r, fma(-dt, r, 1.0), r);
+    r = fma(r, fma(-dt, r, 1.0), r);
+    const double z = cr * r;
+    if (dt > 0.0 && fabs(z) < 0.06) {
+        const double z2 = z * z;
+        // z - z^3/3 + z^5/5 - z^7/7 + z^9/9 - z^11/11
+        const double p = fma(fma(fma(fma(fma(-1.0 / 11.0, z2, 1.0 / 9.0), z2, -1.0 / 7.0), z2, 1.0 / 5.0), z2, -1.0 / 3.0), z2, 1.0);
+        dl = z * p;
+    } else {
+        dl = atan2(cr, dt);
+    }
+    const double n = rint(((double)(thb - tha) - dl) * 0.15915494309189535);
+    return fabs(fma(n, 6.283185307179586, dl));
+}
+
 // Python's min(a, b): keeps a unless b < a (a NaN in b is skipped).
 template <typename R>
 __device__ __forceinline__ R pymin(R a, R b) { return b < a ? b : a; }
@@ -431,7 +456,17 @@ __device__ __forceinline__ FastConsts<R> make_fast(const VelConsts<R> &c, R twod
 }
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-__device__ __forceinline__ double fast_rcp(double x) { return 1.0 / x; }
+// fp64 reciprocal for the step coefficients: the hardware estimate (v_rcp_f64, ~2^-26) and two Newton steps
+// — five instructions, relative error ~2^-52 — instead of the IEEE division's fifteen.  Every velocity kernel
+// derives its coefficients through this one function, so they stay bit-identical to each other; against the
+// oracle the difference (one ulp of a coefficient) is far inside the fp64 bound.
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(r, fma(-x, r, 1.0), r);
+    r = fma(r, fma(-x, r, 1.0), r);
+    return r;
+}
 __device__ __forceinline__ float vmin(float a, float b) { return fminf(a, b); }
 __device__ __forceinline__ double vmin(double a, double b) { return fmin(a, b); }
 __device__ __forceinline__ float vmax_(float a, float b) { return fmaxf(a, b); }

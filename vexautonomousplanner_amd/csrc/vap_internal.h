@@ -34,14 +34,20 @@ struct vap_ctx {
     hipStream_t stream = nullptr;
     bool timing = false;
     int velocity_kernel = 0;  // VAP_OPT_VELOCITY_KERNEL
+    int f32_recurrence = 0;   // VAP_OPT_F32_RECURRENCE (VAP_RECURRENCE_F64 = 0: the default)
     hipEvent_t ev[VAP_T_COUNT + 1] = {};
     float ms[VAP_T_COUNT] = {};
     // scratch arena (grow-only, reused across calls)
     VapBuffer seg, power, lut, slopes, aux, runs, meta, dth, flags, io[8], small_in, small_out, small_seg, small_lut;
     VapBuffer ufwd, lstate, lcount;   // long-row velocity pass
+    VapBuffer k64, dth64;             // fp64 curvature / |dtheta| rows behind fp32 outputs (VAP_RECURRENCE_F64)
     int last_B = 0, last_W = 0;       // shape of the tables the last vap_profile_batch left in seg / lut
     int grid_B = 0, grid_W = 0, grid_S = 0;   // shape of the distance grids (aux, runs) the last sampling call left
-    bool dth_valid = false;           // ctx->dth holds the |dtheta| rows of that call (the fused call only)
+    // rows the last sampling call left for a velocity pass with d_dtheta == NULL:
+    //   rows_hi:  k64 / dth64 hold the fp64 curvature and |dtheta| rows of a VAP_F32 call (fused or staged)
+    //   !rows_hi: dth holds the |dtheta| rows in rows_dt (the fused call only; curvature comes from the caller)
+    bool rows_valid = false, rows_hi = false;
+    int rows_dt = 0;
 
     int ensure(VapBuffer &b, size_t bytes)
     {

@@ -35,26 +35,28 @@ hipError_t launch_grid(hipStream_t st, int B, int W, int S, double dd, double *m
                        uint32_t *flags);
 hipError_t launch_sample(hipStream_t st, bool f64, int B, int W, int S, const double *pw, const double *lut,
                          const double *slopes, const double *meta, const double *aux, const double *runs, void *x,
-                         void *y, void *h, void *k, void *dth);
+                         void *y, void *h, void *k, void *dth, double *k64 = nullptr, double *dth64 = nullptr);
 // per-sample max_acceleration rows of a batch of routes (vap_limits.hip makes them); all NULL for plain paths
 struct AccRowsV {
     const void *fwd = nullptr;   // [B][S] dtype: max_acc (= max_dec) of the forward step from sample i, MPG:194-196
     const void *bwd = nullptr;   // [B][S] dtype: max_acc of the backward step from sample i, MPG:256-257
     const void *dec = nullptr;   // [B]    dtype: max_dec of the backward sweep
 };
-hipError_t launch_velocity_seq(hipStream_t st, bool f64, bool fast, int B, int S, const double c[6], double sv,
+// Velocity kernels: r64 = arithmetic (and the curvature / dtheta rows) in fp64; io64 = the caller's rows (vcap,
+// acc, vel) are fp64.  r64 && !io64 is the fp64 recurrence behind fp32 outputs.
+hipError_t launch_velocity_seq(hipStream_t st, bool r64, bool io64, bool fast, int B, int S, const double c[6], double sv,
                                double ev, const double *meta, const void *curv, const void *dth, const void *vcap,
-                               const AccRowsV &acc, void *vel);
+                               const AccRowsV &acc, void *vel, void *usq);
 int velocity_relax_max_samples(bool f64);
 int velocity_relax_acc_max_samples(bool f64);
 // vcap: optional [B][S] per-sample initial velocities (NULL = plain paths)
-hipError_t launch_velocity_relax(hipStream_t st, bool f64, int B, int S, const double c[6], double sv, double ev,
+hipError_t launch_velocity_relax(hipStream_t st, bool r64, bool io64, int B, int S, const double c[6], double sv, double ev,
                                  const double *meta, const void *curv, const void *dth, const void *vcap,
                                  const AccRowsV &acc, void *vel, uint32_t *flags);
 // rows longer than velocity_relax_max_samples(): two-level relaxation, synchronises the stream once per super-round
 size_t velocity_long_state_bytes(bool f64, int B, int S);
 size_t velocity_long_counter_bytes(bool f64, int B, int S);
-hipError_t launch_velocity_long(hipStream_t st, bool f64, int B, int S, const double c[6], double sv, double ev,
+hipError_t launch_velocity_long(hipStream_t st, bool f64, bool io64, int B, int S, const double c[6], double sv, double ev,
                                 const double *meta, const void *curv, const void *dth, void *vel, uint32_t *flags,
                                 void *ufwd, void *state, int *counters);
 // fp32, one wave per path, one launch per window of 2560 samples and direction (no host synchronisation)

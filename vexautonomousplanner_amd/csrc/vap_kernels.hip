@@ -346,7 +346,9 @@ __device__ __forceinline__ double curvature_of(double num, double ss)
     return num * r * r * r;
 }
 
-template <typename OT, bool COEF_LDS>
+// HI (fp32 outputs only): also write the curvature and |dtheta| rows in fp64 (ok64, odth64) for the fp64
+// velocity recurrence behind fp32 outputs; the fp32 |dtheta| row is then optional (odth may be NULL).
+template <typename OT, bool COEF_LDS, bool HI>
 __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int tile, int tiles_per_block,
                                                            const double *__restrict__ power,
                                                            const double *__restrict__ lut,
@@ -356,8 +358,10 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int 
                                                            const double *__restrict__ runs,
                                                            OT *__restrict__ ox, OT *__restrict__ oy,
                                                            OT *__restrict__ oh, OT *__restrict__ ok,
-                                                           OT *__restrict__ odth, long long *__restrict__ stats)
+                                                           OT *__restrict__ odth, double *__restrict__ ok64,
+                                                           double *__restrict__ odth64, long long *__restrict__ stats)
 {
+    static_assert(!HI || sizeof(OT) == 4, "the fp64 side rows belong to the fp32 output mode");
     extern __shared__ __attribute__((aligned(16))) double s_coef[];   // G * kCoefDoubles when COEF_LDS
     __shared__ double sD[kLutN], sWt[kLutN];
     // neighbour exchange, double-buffered by tile parity (one barrier per tile)
@@ -444,13 +448,29 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int 
                     if (kbase + i < S) dst[row + kbase + i] = v[i];
             }
         };
+        auto store_hi = [&](double *dst, const double v[kSPT]) {   // rows of S doubles: 16-byte aligned when S is even
+            if (!writer) return;
+            if ((S & 1) == 0 && kbase + kSPT <= S) {
+                *reinterpret_cast<double2 *>(dst + row + kbase) = make_double2(v[0], v[1]);
+                *reinterpret_cast<double2 *>(dst + row + kbase + 2) = make_double2(v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < kSPT; i++)
+                    if (kbase + i < S) dst[row + kbase + i] = v[i];
+            }
+        };
         if (k0 >= N) {
             // past this path's grid (ragged dd mode): zero-fill so every output element is defined
             const OT z[kSPT] = {(OT)0, (OT)0, (OT)0, (OT)0};
             store_vec(ox, z); store_vec(oy, z); store_vec(oh, z); store_vec(ok, z); store_vec(odth, z);
+            if constexpr (HI) {
+                const double zd[kSPT] = {0.0, 0.0, 0.0, 0.0};
+                store_hi(ok64, zd); store_hi(odth64, zd);
+            }
             continue;
         }
         OT vx[kSPT], vy[kSPT], vh[kSPT], vk[kSPT], vd[kSPT];
+        double vk64[HI ? kSPT : 1], vd64[HI ? kSPT : 1];
         // MPG:112-122 distance grid: the reference accumulates current_dist += dd.  The thread's first
         // sample comes from the path's run table (that sum in closed form), the following ones by the
         // reference's own addition.  The wave's kSPT*64 consecutive samples almost always lie in one run,
@@ -493,7 +513,9 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int 
             const double fx = horner3(c + kCoefD2, lt), fy = horner3(c + kCoefD2 + 4, lt);     // P''
             const double ss = fma(ex, ex, ey * ey);                               // SM:517
             const double num = fma(ex, fy, -(ey * fx));                           // SM:523
-            vk[i] = (OT)((ss >= 1e-10) ? curvature_of(num, ss) : 0.0);            // SM:526-527
+            const double kap = (ss >= 1e-10) ? curvature_of(num, ss) : 0.0;       // SM:526-527
+            vk[i] = (OT)kap;
+            if constexpr (HI) { vk64[i] = kap; vd64[i] = 0.0; }
             vh[i] = heading_of<OT>(ey, ex);                                       // SM:536
             d1x[i] = ex;
             d1y[i] = ey;
@@ -530,6 +552,9 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int 
                     const OT nth = (i + 1 < kSPT) ? vh[(i + 1) % kSPT] : s_th[pb][tid + 1];
                     if constexpr (sizeof(OT) == 8) {
                         vd[i] = fabs(nth - vh[i]);
+                    } else if constexpr (HI) {
+                        if (nj != jjv[i]) vd64[i] = dtheta_f64(d1x[i], d1y[i], nx, ny, vh[i], nth);
+                        vd[i] = (OT)vd64[i];   // (only stored when the staged API asked for the fp32 row as well)
                     } else {
                         if (nj != jjv[i]) vd[i] = dtheta_f32(d1x[i], d1y[i], nx, ny, vh[i], nth);
                     }
@@ -538,9 +563,14 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int 
             if (k0 + kSampleChunk > N) {   // only the path's last tile has samples to blank
 #pragma unroll
                 for (int i = 0; i < kSPT; i++)
-                    if (kbase + i >= N) vx[i] = vy[i] = vh[i] = vk[i] = vd[i] = (OT)0;
+                    if (kbase + i >= N) {
+                        vx[i] = vy[i] = vh[i] = vk[i] = vd[i] = (OT)0;
+                        if constexpr (HI) { vk64[i] = 0.0; vd64[i] = 0.0; }
+                    }
             }
-            store_vec(ox, vx); store_vec(oy, vy); store_vec(oh, vh); store_vec(ok, vk); store_vec(odth, vd);
+            store_vec(ox, vx); store_vec(oy, vy); store_vec(oh, vh); store_vec(ok, vk);
+            if constexpr (HI) { store_hi(ok64, vk64); store_hi(odth64, vd64); }
+            store_vec(odth, vd);
         }
     }
     if (stats && (tid & 63) == 0) {
@@ -569,11 +599,15 @@ struct AccRows {
     const R *dec = nullptr;
 };
 
-template <typename R, bool FAST>
+// R = arithmetic type (and type of the curvature / dtheta rows), IO = type of the caller's rows (initial
+// velocities, max_acceleration rows, the velocity output): IO = float with R = double is the fp64 recurrence
+// behind fp32 outputs.
+template <typename R, typename IO, bool FAST>
 __global__ __launch_bounds__(64) void k_velocity_seq(int B, int S, VelConsts<R> c, R start_u, R end_u,
                                                      const double *__restrict__ meta,
                                                      const R *__restrict__ curv, const R *__restrict__ dtheta,
-                                                     const R *__restrict__ vcap, AccRows<R> acc, R *__restrict__ vel)
+                                                     const IO *__restrict__ vcap, AccRows<IO> acc, IO *__restrict__ vel,
+                                                     R *__restrict__ usq)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -582,7 +616,11 @@ __global__ __launch_bounds__(64) void k_velocity_seq(int B, int S, VelConsts<R> 
     const int N = (int)m[3];
     const size_t row = (size_t)b * S;
     const R *K = curv + row, *DT = dtheta + row;
-    R *V = vel + row;
+    // the sweeps run on squared velocities in the arithmetic type: in place when the output row has that type,
+    // otherwise in the scratch row `usq`
+    R *V;
+    if constexpr (std::is_same<R, IO>::value) V = vel + row;
+    else V = usq + row;
     const R vmax2 = c.vmax * c.vmax;
     const FastConsts<R> fc = make_fast(c, twodd);
     // same per-path decision as the relaxation kernel: does any step have a zero heading difference?
@@ -597,9 +635,9 @@ __global__ __launch_bounds__(64) void k_velocity_seq(int B, int S, VelConsts<R> 
     R u = start_u, wprev = (R)0;   // FAST: wprev carries the previous squared velocity instead
     V[0] = u;
     for (int i = 0; i < N - 1; i++) {
-        const R un = (i + 1 == N - 1) ? end_u : (vcap ? vcap[row + i + 1] * vcap[row + i + 1] : vmax2);
+        const R un = (i + 1 == N - 1) ? end_u : (vcap ? (R)vcap[row + i + 1] * (R)vcap[row + i + 1] : vmax2);
         // MPG:194-196: max_acc = max_dec = the value in force from the last boundary at or before sample i
-        const R cur = acc.fwd ? acc.fwd[row + i] : c.amax;
+        const R cur = acc.fwd ? (R)acc.fwd[row + i] : c.amax;
         if constexpr (FAST) {
             R rho, gq, A, cap;
             const R amaxp = acc.fwd ? twodd * cur : fc.amaxp;
@@ -618,8 +656,8 @@ __global__ __launch_bounds__(64) void k_velocity_seq(int B, int S, VelConsts<R> 
     for (int i = N - 1; i > 0; i--) {
         R up;
         // MPG:256-257: max_acc as the backward sweep finds it at sample i; max_dec is what the forward sweep left
-        const R cur_acc = acc.bwd ? acc.bwd[row + i] : c.amax;
-        const R cur_dec = acc.dec ? acc.dec[b] : c.adec;
+        const R cur_acc = acc.bwd ? (R)acc.bwd[row + i] : c.amax;
+        const R cur_dec = acc.dec ? (R)acc.dec[b] : c.adec;
         if constexpr (FAST) {
             R rho, gq, A, cap;
             const R kabs = (R)fabs(K[i]);
@@ -635,11 +673,11 @@ __global__ __launch_bounds__(64) void k_velocity_seq(int B, int S, VelConsts<R> 
             const SampleLimits<R> L = sample_limits(c, (R)fabs(K[i]), cur_acc, cur_dec);
             up = backward_step(c, L, cur_acc, twodd, u, wprev, DT[i - 1], V[i - 1]);
         }
-        V[i] = vel_sqrt(u);
+        vel[row + i] = (IO)vel_sqrt(u);
         u = up;
     }
-    V[0] = vel_sqrt(u);
-    for (int i = N; i < S; i++) V[i] = (R)0;
+    vel[row] = (IO)vel_sqrt(u);
+    for (int i = N; i < S; i++) vel[row + i] = (IO)0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -785,13 +823,14 @@ __device__ __forceinline__ double wave_shift_down(double x)
 
 // VCAP: the caller gave per-sample initial velocities (MPG:121,127,153,172: node / action-point max_velocity and
 // stops); the forward step into sample j is then also limited by vcap[j]^2 — folded into that slot's cap.
-template <typename R, int L, int MAXT, int MINW, bool VCAP, bool ACC>
+// R = arithmetic type and type of the curvature / dtheta rows; IO = type of the caller's rows (vcap, acc, vel).
+template <typename R, typename IO, int L, int MAXT, int MINW, bool VCAP, bool ACC>
 __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<R> c, R start_u, R end_u,
                                                                const double *__restrict__ meta,
                                                                const R *__restrict__ curv,
                                                                const R *__restrict__ dtheta,
-                                                               const R *__restrict__ vcap, AccRows<R> acc,
-                                                               R *__restrict__ vel, uint32_t *__restrict__ flags,
+                                                               const IO *__restrict__ vcap, AccRows<IO> acc,
+                                                               IO *__restrict__ vel, uint32_t *__restrict__ flags,
                                                                long long *__restrict__ stats)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -808,7 +847,7 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
     const size_t row = (size_t)b * S;
     const R *K = curv + row, *DT = dtheta + row;
     const FastConsts<R> fc = make_fast(c, twodd);
-    const R adecp_b = ACC ? twodd * acc.dec[b] : fc.adecp;   // ACC: the backward sweep's max_dec (AccRows)
+    const R adecp_b = ACC ? twodd * (R)acc.dec[b] : fc.adecp;   // ACC: the backward sweep's max_dec (AccRows)
     const int lo = tid * L;
     const int TL = T * L;
     const bool aligned = (S % (16 / (int)sizeof(R))) == 0;
@@ -847,7 +886,7 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
                 const bool valid = j >= 1 && j <= N - 1;
                 R base = fc.amaxp;
                 if constexpr (ACC) {   // the step into j starts at sample j-1: its max_acc (= max_dec), MPG:194-196
-                    base = valid ? twodd * acc.fwd[row + j - 1] : fc.amaxp;
+                    base = valid ? twodd * (R)acc.fwd[row + j - 1] : fc.amaxp;
                     am[s] = base;
                 }
                 fast_derive_k(fc, kc, (j >= 2) ? kp : (R)0, base, q[s], g[s], A[s], cp[s]);   // g[s] = k^2 for now
@@ -881,14 +920,14 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
     if constexpr (VCAP) {
         // the forward step into sample j (1 <= j <= N-2; the end sample is fixed by the backward sweep) also
         // honours the sample's initial velocity: min(.., cap, vcap^2) — one number per slot
-        const R *VC = vcap + row;
+        const IO *VC = vcap + row;
 #pragma unroll
         for (int s0 = 0; s0 < L; s0 += BK) {    // BK loads in flight, then BK selects (as the phases above)
             R vc[BK];
 #pragma unroll
             for (int i = 0; i < BK; i++) {
                 const int j = lo + s0 + i;
-                vc[i] = (j >= 1 && j <= N - 2) ? VC[j] : Huge<R>::v * (R)1e-20;   // (squares without overflow)
+                vc[i] = (j >= 1 && j <= N - 2) ? (R)VC[j] : Huge<R>::v * (R)1e-20;   // (squares without overflow)
             }
 #pragma unroll
             for (int i = 0; i < BK; i++) cp[s0 + i] = opaque(vmin(cp[s0 + i], vc[i] * vc[i]));
@@ -996,7 +1035,7 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
                     A[s] = fast_cap_A(fc, kc, A[s]);
                     // (a zero heading difference, g < 0: the wheel limit is +inf unless the angular velocity rises)
                     // — there the clamp decides: amaxp = A (kHuge times any non-zero rise still wins against it)
-                    am[s] = (valid && !(kc < (R)1e-6) && !(g[s] < (R)0)) ? twodd * acc.bwd[row + j + 1] : A[s];
+                    am[s] = (valid && !(kc < (R)1e-6) && !(g[s] < (R)0)) ? twodd * (R)acc.bwd[row + j + 1] : A[s];
                 }
                 if (!valid) { idle_coef(q[s], g[s], A[s], cp[s]); u[s] = end_u; }
                 q[s] = opaque(q[s]);
@@ -1073,36 +1112,38 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
             for (int s = L - 1; s >= 0; s--) u[s] = uu = fast_backward_a<false>(ACC ? am[ACC ? s : 0] : fc.amaxp, q[s], g[s], A[s], cp[s], uu, wp, u[s]);
         }
     }
-    // velocities leave through the stage so the row is written with 16 bytes per lane
+    // velocities leave through the stage (as IO elements, same padded positions) so the row is written with
+    // 16 bytes per lane
     __syncthreads();
+    IO *ostage = reinterpret_cast<IO *>(smem_raw);
 #pragma unroll
     for (int s = 0; s < L; s++) {
         const int j = lo + s;
-        stage[cpos(s)] = j < N ? vel_sqrt(u[s]) : (R)0;
+        ostage[cpos(s)] = j < N ? (IO)vel_sqrt(u[s]) : (IO)0;
     }
     __syncthreads();
-    R *V = vel + row;
+    IO *V = vel + row;
     {
-        constexpr int VW = 16 / sizeof(R);
+        constexpr int VW = 16 / sizeof(IO);
         const int n = S < TL ? S : TL;
-        if (aligned) {
-            using VT = typename std::conditional<sizeof(R) == 4, float4, double2>::type;
+        if ((S % VW) == 0) {
+            using VT = typename std::conditional<sizeof(IO) == 4, float4, double2>::type;
             VT *dst = reinterpret_cast<VT *>(V);
             for (int i = tid; i < n / VW; i += T) {
                 VT v;
-                R *e = reinterpret_cast<R *>(&v);
-                const int p0 = stage_pos<R, L>(i * VW);
+                IO *e = reinterpret_cast<IO *>(&v);
+                const int p0 = stage_pos<IO, L>(i * VW);
 #pragma unroll
                 for (int k = 0; k < VW; k++)   // L % VW == 0: the VW elements share a chunk
-                    e[k] = stage[(L % VW == 0) ? p0 + k : stage_pos<R, L>(i * VW + k)];
+                    e[k] = ostage[(L % VW == 0) ? p0 + k : stage_pos<IO, L>(i * VW + k)];
                 dst[i] = v;
             }
-            for (int i = (n / VW) * VW + tid; i < n; i += T) V[i] = stage[stage_pos<R, L>(i)];
+            for (int i = (n / VW) * VW + tid; i < n; i += T) V[i] = ostage[stage_pos<IO, L>(i)];
         } else {
-            for (int i = tid; i < n; i += T) V[i] = stage[stage_pos<R, L>(i)];
+            for (int i = tid; i < n; i += T) V[i] = ostage[stage_pos<IO, L>(i)];
         }
     }
-    for (int j = TL + tid; j < S; j += T) V[j] = (R)0;
+    for (int j = TL + tid; j < S; j += T) V[j] = (IO)0;
     if (stats && tid == 0) {
         long long *st = stats + (size_t)b * 8;
         st[0] = fwd_rounds;
@@ -1142,12 +1183,12 @@ __global__ void k_dup_scan(int B, int S, VelConsts<R> c, const double *__restric
     if (__syncthreads_or(any ? 1 : 0) && threadIdx.x == 0) atomicOr(&dup[b], 1);
 }
 
-template <typename R, int L, int MAXT, int MINW, bool BWD>
+template <typename R, typename IO, int L, int MAXT, int MINW, bool BWD>
 __global__ __launch_bounds__(MAXT, MINW) void k_velocity_long(int S, int nsc, int round, int seq_sc, VelConsts<R> c, R start_u,
                                                               R end_u, const double *__restrict__ meta,
                                                               const R *__restrict__ curv,
                                                               const R *__restrict__ dtheta, R *__restrict__ ufwd,
-                                                              R *__restrict__ vel, R *__restrict__ bnd,
+                                                              IO *__restrict__ vel, R *__restrict__ bnd,
                                                               R *__restrict__ used, R *__restrict__ outst,
                                                               const int *__restrict__ dupflag,
                                                               int *__restrict__ changed, uint32_t *__restrict__ flags)
@@ -1360,18 +1401,27 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_long(int S, int nsc, in
     }
     // rows leave through the stage: forward -> u (squared velocity) scratch, backward -> final velocity
     __syncthreads();
-#pragma unroll
-    for (int s = 0; s < L; s++) {
-        const int j = base + lo + s;
-        stage[stage_pos<R, L>(lo + s)] = BWD ? (j < N ? vel_sqrt(u[s]) : (R)0) : u[s];
-    }
-    __syncthreads();
-    R *dst = (BWD ? vel : ufwd) + row + base;
     int n = S - base;
     n = n > SC ? SC : n;
-    for (int i = tid; i < n; i += T) dst[i] = stage[stage_pos<R, L>(i)];
-    if (BWD && sc == last_sc)
-        for (int j = (last_sc + 1) * SC + tid; j < S; j += T) vel[row + j] = (R)0;
+    if constexpr (BWD) {
+        IO *ostage = reinterpret_cast<IO *>(smem_raw);
+#pragma unroll
+        for (int s = 0; s < L; s++) {
+            const int j = base + lo + s;
+            ostage[stage_pos<IO, L>(lo + s)] = j < N ? (IO)vel_sqrt(u[s]) : (IO)0;
+        }
+        __syncthreads();
+        IO *dst = vel + row + base;
+        for (int i = tid; i < n; i += T) dst[i] = ostage[stage_pos<IO, L>(i)];
+        if (sc == last_sc)
+            for (int j = (last_sc + 1) * SC + tid; j < S; j += T) vel[row + j] = (IO)0;
+    } else {
+#pragma unroll
+        for (int s = 0; s < L; s++) stage[stage_pos<R, L>(lo + s)] = u[s];
+        __syncthreads();
+        R *dst = ufwd + row + base;
+        for (int i = tid; i < n; i += T) dst[i] = stage[stage_pos<R, L>(i)];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1487,8 +1537,9 @@ hipError_t launch_grid(hipStream_t st, int B, int W, int S, double dd, double *m
 
 hipError_t launch_sample(hipStream_t st, bool f64, int B, int W, int S, const double *pw, const double *lut,
                          const double *slopes, const double *meta, const double *aux, const double *runs, void *x,
-                         void *y, void *h, void *k, void *dth)
+                         void *y, void *h, void *k, void *dth, double *k64, double *dth64)
 {
+    const bool hi = !f64 && k64 && dth64;
     // one workgroup stages a path's tables once and walks tiles_per_block consecutive tiles; paths are
     // split over several workgroups only when the batch alone cannot fill the chip
     // a tile is kSampleTile samples (the last thread only feeds its neighbour's |dtheta|) unless the whole
@@ -1506,11 +1557,12 @@ hipError_t launch_sample(hipStream_t st, bool f64, int B, int W, int S, const do
     long long *stats = nullptr;
     const size_t n_waves = (size_t)grid.x * grid.y * 4;
     if (want_stats) (void)hipMalloc(&stats, n_waves * 4 * sizeof(long long));
-#define VAP_SAMPLE(OT_, LDS_)                                                                                      \
-    hipLaunchKernelGGL((k_sample<OT_, LDS_>), grid, dim3(kSampleThreads), lds, st, W, S, tile, tiles_per_block, pw, lut, \
-                       slopes, meta, aux, runs, (OT_ *)x, (OT_ *)y, (OT_ *)h, (OT_ *)k, (OT_ *)dth, stats)
-    if (f64) { if (in_lds) VAP_SAMPLE(double, true); else VAP_SAMPLE(double, false); }
-    else { if (in_lds) VAP_SAMPLE(float, true); else VAP_SAMPLE(float, false); }
+#define VAP_SAMPLE(OT_, LDS_, HI_)                                                                                 \
+    hipLaunchKernelGGL((k_sample<OT_, LDS_, HI_>), grid, dim3(kSampleThreads), lds, st, W, S, tile, tiles_per_block, pw, lut, \
+                       slopes, meta, aux, runs, (OT_ *)x, (OT_ *)y, (OT_ *)h, (OT_ *)k, (OT_ *)dth, k64, dth64, stats)
+    if (f64) { if (in_lds) VAP_SAMPLE(double, true, false); else VAP_SAMPLE(double, false, false); }
+    else if (hi) { if (in_lds) VAP_SAMPLE(float, true, true); else VAP_SAMPLE(float, false, true); }
+    else { if (in_lds) VAP_SAMPLE(float, true, false); else VAP_SAMPLE(float, false, false); }
 #undef VAP_SAMPLE
     if (stats) {
         std::vector<long long> h(n_waves * 4);
@@ -1539,25 +1591,28 @@ static VelConsts<R> make_consts(const double c[6])
     return v;
 }
 
-hipError_t launch_velocity_seq(hipStream_t st, bool f64, bool fast, int B, int S, const double c[6], double sv,
-                               double ev, const double *meta, const void *curv, const void *dth, const void *vcap,
-                               const AccRowsV &accv, void *vel)
+template <typename R, typename IO>
+static void launch_seq_t(hipStream_t st, bool fast, int B, int S, const double c[6], double sv, double ev, const double *meta,
+                         const void *curv, const void *dth, const void *vcap, const AccRowsV &accv, void *vel, void *usq)
 {
     const dim3 grid((B + 63) / 64);
-    if (f64) {
-        AccRows<double> acc;
-        acc.fwd = (const double *)accv.fwd; acc.bwd = (const double *)accv.bwd; acc.dec = (const double *)accv.dec;
-        auto k = fast ? k_velocity_seq<double, true> : k_velocity_seq<double, false>;
-        hipLaunchKernelGGL(k, grid, dim3(64), 0, st, B, S, make_consts<double>(c), sv * sv, ev * ev, meta,
-                           (const double *)curv, (const double *)dth, (const double *)vcap, acc, (double *)vel);
-    } else {
-        AccRows<float> acc;
-        acc.fwd = (const float *)accv.fwd; acc.bwd = (const float *)accv.bwd; acc.dec = (const float *)accv.dec;
-        const float svf = (float)sv, evf = (float)ev;
-        auto k = fast ? k_velocity_seq<float, true> : k_velocity_seq<float, false>;
-        hipLaunchKernelGGL(k, grid, dim3(64), 0, st, B, S, make_consts<float>(c), svf * svf, evf * evf, meta,
-                           (const float *)curv, (const float *)dth, (const float *)vcap, acc, (float *)vel);
-    }
+    AccRows<IO> acc;
+    acc.fwd = (const IO *)accv.fwd; acc.bwd = (const IO *)accv.bwd; acc.dec = (const IO *)accv.dec;
+    const R s = (R)sv, e = (R)ev;
+    auto k = fast ? k_velocity_seq<R, IO, true> : k_velocity_seq<R, IO, false>;
+    hipLaunchKernelGGL(k, grid, dim3(64), 0, st, B, S, make_consts<R>(c), s * s, e * e, meta, (const R *)curv,
+                       (const R *)dth, (const IO *)vcap, acc, (IO *)vel, (R *)usq);
+}
+
+// r64: arithmetic (and curvature / dtheta rows) in fp64; io64: the caller's rows (vcap, acc, vel) are fp64.
+// usq: [B][S] scratch of the arithmetic type, needed when the two differ.
+hipError_t launch_velocity_seq(hipStream_t st, bool r64, bool io64, bool fast, int B, int S, const double c[6], double sv,
+                               double ev, const double *meta, const void *curv, const void *dth, const void *vcap,
+                               const AccRowsV &accv, void *vel, void *usq)
+{
+    if (r64 && io64) launch_seq_t<double, double>(st, fast, B, S, c, sv, ev, meta, curv, dth, vcap, accv, vel, usq);
+    else if (r64) launch_seq_t<double, float>(st, fast, B, S, c, sv, ev, meta, curv, dth, vcap, accv, vel, usq);
+    else launch_seq_t<float, float>(st, fast, B, S, c, sv, ev, meta, curv, dth, vcap, accv, vel, usq);
     return hipGetLastError();
 }
 
@@ -1566,15 +1621,15 @@ int velocity_relax_max_samples(bool f64) { return f64 ? 512 * 20 : 512 * 40; }
 // ... and with per-sample max_acceleration rows (one more register array per thread)
 int velocity_relax_acc_max_samples(bool f64) { return f64 ? 512 * 8 : 512 * 20; }
 
-template <typename R, int L, int MAXT, int MINW, bool ACC = false>
+template <typename R, typename IO, int L, int MAXT, int MINW, bool ACC = false>
 static void launch_relax_t(hipStream_t st, int B, int S, const double c[6], double sv, double ev,
                            const double *meta, const void *curv, const void *dth, const void *vcap, const AccRowsV &accv,
                            void *vel, uint32_t *flags)
 {
-    AccRows<R> acc;
-    acc.fwd = (const R *)accv.fwd;
-    acc.bwd = (const R *)accv.bwd;
-    acc.dec = (const R *)accv.dec;
+    AccRows<IO> acc;
+    acc.fwd = (const IO *)accv.fwd;
+    acc.bwd = (const IO *)accv.bwd;
+    acc.dec = (const IO *)accv.dec;
     int T = (S + L - 1) / L;
     T = (T + 63) / 64 * 64;
     const R s = (R)sv, e = (R)ev;
@@ -1584,14 +1639,14 @@ static void launch_relax_t(hipStream_t st, int B, int S, const double c[6], doub
     if (want_stats) (void)hipMalloc(&stats, (size_t)B * 8 * sizeof(long long));
     const size_t lds = sizeof(R) * ((size_t)T * L + T + 8);
     if constexpr (ACC)
-        hipLaunchKernelGGL((k_velocity_relax<R, L, MAXT, MINW, true, true>), dim3(B), dim3(T), lds, st, S, make_consts<R>(c), s * s,
-                           e * e, meta, (const R *)curv, (const R *)dth, (const R *)vcap, acc, (R *)vel, flags, stats);
+        hipLaunchKernelGGL((k_velocity_relax<R, IO, L, MAXT, MINW, true, true>), dim3(B), dim3(T), lds, st, S, make_consts<R>(c), s * s,
+                           e * e, meta, (const R *)curv, (const R *)dth, (const IO *)vcap, acc, (IO *)vel, flags, stats);
     else if (vcap)
-        hipLaunchKernelGGL((k_velocity_relax<R, L, MAXT, MINW, true, false>), dim3(B), dim3(T), lds, st, S, make_consts<R>(c), s * s,
-                           e * e, meta, (const R *)curv, (const R *)dth, (const R *)vcap, acc, (R *)vel, flags, stats);
+        hipLaunchKernelGGL((k_velocity_relax<R, IO, L, MAXT, MINW, true, false>), dim3(B), dim3(T), lds, st, S, make_consts<R>(c), s * s,
+                           e * e, meta, (const R *)curv, (const R *)dth, (const IO *)vcap, acc, (IO *)vel, flags, stats);
     else
-        hipLaunchKernelGGL((k_velocity_relax<R, L, MAXT, MINW, false, false>), dim3(B), dim3(T), lds, st, S, make_consts<R>(c), s * s,
-                           e * e, meta, (const R *)curv, (const R *)dth, (const R *)nullptr, acc, (R *)vel, flags, stats);
+        hipLaunchKernelGGL((k_velocity_relax<R, IO, L, MAXT, MINW, false, false>), dim3(B), dim3(T), lds, st, S, make_consts<R>(c), s * s,
+                           e * e, meta, (const R *)curv, (const R *)dth, (const IO *)nullptr, acc, (IO *)vel, flags, stats);
     if (stats) {
         std::vector<long long> h((size_t)B * 8);
         (void)hipStreamSynchronize(st);
@@ -1609,48 +1664,57 @@ static void launch_relax_t(hipStream_t st, int B, int S, const double c[6], doub
     }
 }
 
-hipError_t launch_velocity_relax(hipStream_t st, bool f64, int B, int S, const double c[6], double sv, double ev,
+hipError_t launch_velocity_relax(hipStream_t st, bool r64, bool io64, int B, int S, const double c[6], double sv, double ev,
                                  const double *meta, const void *curv, const void *dth, const void *vcap,
                                  const AccRowsV &acc, void *vel, uint32_t *flags)
 {
     if (acc.fwd) {
         // per-sample max_acceleration: one more register array per thread, so shorter chunks
         // (velocity_relax_acc_max_samples() is the limit the caller checks)
-#define VAP_RELAX_ACC(R_, L_, MAXT_, W_) launch_relax_t<R_, L_, MAXT_, W_, true>(st, B, S, c, sv, ev, meta, curv, dth, vcap, acc, vel, flags)
-        if (f64) {
-            if (S <= 64 * 4) VAP_RELAX_ACC(double, 4, 256, 4);
-            else VAP_RELAX_ACC(double, 8, 512, 4);
+#define VAP_RELAX_ACC(R_, IO_, L_, MAXT_, W_) launch_relax_t<R_, IO_, L_, MAXT_, W_, true>(st, B, S, c, sv, ev, meta, curv, dth, vcap, acc, vel, flags)
+        if (r64 && io64) {
+            if (S <= 64 * 4) VAP_RELAX_ACC(double, double, 4, 256, 4);
+            else VAP_RELAX_ACC(double, double, 8, 512, 4);
+        } else if (r64) {
+            if (S <= 64 * 4) VAP_RELAX_ACC(double, float, 4, 256, 4);
+            else VAP_RELAX_ACC(double, float, 8, 512, 4);
         } else {
-            if (S <= 64 * 4) VAP_RELAX_ACC(float, 4, 1024, 8);
-            else if (S <= 512 * 16) VAP_RELAX_ACC(float, 16, 512, 4);
-            else VAP_RELAX_ACC(float, 20, 512, 2);
+            if (S <= 64 * 4) VAP_RELAX_ACC(float, float, 4, 1024, 8);
+            else if (S <= 512 * 16) VAP_RELAX_ACC(float, float, 16, 512, 4);
+            else VAP_RELAX_ACC(float, float, 20, 512, 2);
         }
 #undef VAP_RELAX_ACC
         return hipGetLastError();
     }
-#define VAP_RELAX(R_, L_, MAXT_, W_) launch_relax_t<R_, L_, MAXT_, W_>(st, B, S, c, sv, ev, meta, curv, dth, vcap, acc, vel, flags)
+#define VAP_RELAX(R_, IO_, L_, MAXT_, W_) launch_relax_t<R_, IO_, L_, MAXT_, W_>(st, B, S, c, sv, ev, meta, curv, dth, vcap, acc, vel, flags)
     // chunk length: the longest instantiated L whose thread count still covers the row — fewer, longer
     // chunks mean fewer rounds (rounds ~ longest unclamped run / L) and fewer waves to synchronise
-    if (f64) {
-        if (S <= 64 * 4) VAP_RELAX(double, 4, 256, 4);
-        else if (S <= 512 * 8) VAP_RELAX(double, 8, 512, 4);
-        else VAP_RELAX(double, 20, 512, 2);
+    if (r64 && io64) {
+        if (S <= 64 * 4) VAP_RELAX(double, double, 4, 256, 4);
+        else if (S <= 512 * 8) VAP_RELAX(double, double, 8, 512, 4);
+        else VAP_RELAX(double, double, 20, 512, 2);
+        return hipGetLastError();
+    }
+    if (r64) {
+        if (S <= 64 * 4) VAP_RELAX(double, float, 4, 256, 4);
+        else if (S <= 512 * 8) VAP_RELAX(double, float, 8, 512, 4);
+        else VAP_RELAX(double, float, 20, 512, 2);
         return hipGetLastError();
     }
     // developer knob (tuning only): VAP_RELAX_CFG=<L>, one of the instantiated chunk lengths
     static const char *cfg = getenv("VAP_RELAX_CFG");
     int L = cfg ? atoi(cfg) : 0;
     if (L == 0) L = S <= 64 * 4 ? 4 : (S <= 256 * 16 ? 16 : 40);
-    if (L == 4 && S <= 1024 * 4) VAP_RELAX(float, 4, 1024, 8);
-    else if (L == 10 && S <= 1024 * 10) VAP_RELAX(float, 10, 1024, 4);
-    else if (L == 16 && S <= 512 * 16) VAP_RELAX(float, 16, 512, 4);
-    else if (L == 20 && S <= 512 * 20) VAP_RELAX(float, 20, 512, 4);
-    else VAP_RELAX(float, 40, 512, 2);
+    if (L == 4 && S <= 1024 * 4) VAP_RELAX(float, float, 4, 1024, 8);
+    else if (L == 10 && S <= 1024 * 10) VAP_RELAX(float, float, 10, 1024, 4);
+    else if (L == 16 && S <= 512 * 16) VAP_RELAX(float, float, 16, 512, 4);
+    else if (L == 20 && S <= 512 * 20) VAP_RELAX(float, float, 20, 512, 4);
+    else VAP_RELAX(float, float, 40, 512, 2);
 #undef VAP_RELAX
     return hipGetLastError();
 }
 
-template <typename R, int L, int MAXT, int MINW>
+template <typename R, typename IO, int L, int MAXT, int MINW>
 static hipError_t velocity_long_t(hipStream_t st, int B, int S, const double c[6], double sv, double ev,
                                   const double *meta, const void *curv, const void *dth, void *vel, uint32_t *flags,
                                   void *ufwd, void *state, int *counters)
@@ -1680,13 +1744,13 @@ static hipError_t velocity_long_t(hipStream_t st, int B, int S, const double c[6
             for (int k = 0; k < kRoundsPerCheck && round <= nsc + 1; k++, round++) {
                 ch = changed + dir * (nsc + 2) + round;
                 if (dir == 0)
-                    hipLaunchKernelGGL((k_velocity_long<R, L, MAXT, MINW, false>), dim3(nsc, B), dim3(MAXT), lds, st, S, nsc,
+                    hipLaunchKernelGGL((k_velocity_long<R, IO, L, MAXT, MINW, false>), dim3(nsc, B), dim3(MAXT), lds, st, S, nsc,
                                        round, -1, make_consts<R>(c), s * s, e * e, meta, (const R *)curv, (const R *)dth,
-                                       (R *)ufwd, (R *)vel, bnd, used, outst, dup, ch, flags);
+                                       (R *)ufwd, (IO *)vel, bnd, used, outst, dup, ch, flags);
                 else
-                    hipLaunchKernelGGL((k_velocity_long<R, L, MAXT, MINW, true>), dim3(nsc, B), dim3(MAXT), lds, st, S, nsc,
+                    hipLaunchKernelGGL((k_velocity_long<R, IO, L, MAXT, MINW, true>), dim3(nsc, B), dim3(MAXT), lds, st, S, nsc,
                                        round, -1, make_consts<R>(c), s * s, e * e, meta, (const R *)curv, (const R *)dth,
-                                       (R *)ufwd, (R *)vel, bnd, used, outst, dup, ch, flags);
+                                       (R *)ufwd, (IO *)vel, bnd, used, outst, dup, ch, flags);
                 if ((err = hipGetLastError()) != hipSuccess) return err;
             }
             int h = 0;
@@ -1711,19 +1775,20 @@ size_t velocity_long_counter_bytes(bool f64, int B, int S)
     return sizeof(int) * ((size_t)B + 2 * (nsc + 2)) + 64;
 }
 
-hipError_t launch_velocity_long(hipStream_t st, bool f64, int B, int S, const double c[6], double sv, double ev,
+hipError_t launch_velocity_long(hipStream_t st, bool f64, bool io64, int B, int S, const double c[6], double sv, double ev,
                                 const double *meta, const void *curv, const void *dth, void *vel, uint32_t *flags,
                                 void *ufwd, void *state, int *counters)
 {
-    if (f64) return velocity_long_t<double, 16, 512, 2>(st, B, S, c, sv, ev, meta, curv, dth, vel, flags, ufwd, state, counters);
+    if (f64 && io64) return velocity_long_t<double, double, 16, 512, 2>(st, B, S, c, sv, ev, meta, curv, dth, vel, flags, ufwd, state, counters);
+    if (f64) return velocity_long_t<double, float, 16, 512, 2>(st, B, S, c, sv, ev, meta, curv, dth, vel, flags, ufwd, state, counters);
     // super-chunk = 256 or 64 threads x 40 samples: few long rows (config 2: one) are cut finer so that the
     // chip has more workgroups to run and a super-round is shorter
     static const char *cfg = getenv("VAP_LONG_T");   // developer knob (tuning only): 64 or 256
     const int forced = cfg ? atoi(cfg) : 0;
     const long blocks256 = (long)B * ((S + 256 * 40 - 1) / (256 * 40));
     if (forced == 64 || (forced != 256 && blocks256 < 512))
-        return velocity_long_t<float, 40, 64, 2>(st, B, S, c, sv, ev, meta, curv, dth, vel, flags, ufwd, state, counters);
-    return velocity_long_t<float, 40, 256, 2>(st, B, S, c, sv, ev, meta, curv, dth, vel, flags, ufwd, state, counters);
+        return velocity_long_t<float, float, 40, 64, 2>(st, B, S, c, sv, ev, meta, curv, dth, vel, flags, ufwd, state, counters);
+    return velocity_long_t<float, float, 40, 256, 2>(st, B, S, c, sv, ev, meta, curv, dth, vel, flags, ufwd, state, counters);
 }
 
 // K5b': many paths, fp32: one wave per path walks the row in windows of 64*L samples, one launch per
@@ -1754,11 +1819,11 @@ hipError_t launch_velocity_windows(hipStream_t st, int B, int S, const double c[
     hipLaunchKernelGGL(k_dup_scan<R>, dim3(8, B), dim3(256), 0, st, B, S, make_consts<R>(c), meta, (const R *)curv,
                        (const R *)dth, dup);
     for (int sc = 0; sc < nsc; sc++)
-        hipLaunchKernelGGL((k_velocity_long<R, L, T, 2, false>), dim3(1, B), dim3(T), lds, st, S, nsc, 0, sc,
+        hipLaunchKernelGGL((k_velocity_long<R, R, L, T, 2, false>), dim3(1, B), dim3(T), lds, st, S, nsc, 0, sc,
                            make_consts<R>(c), s * s, e * e, meta, (const R *)curv, (const R *)dth, (R *)ufwd, (R *)vel, bnd,
                            used, outst, dup, changed, flags);
     for (int sc = nsc - 1; sc >= 0; sc--)
-        hipLaunchKernelGGL((k_velocity_long<R, L, T, 2, true>), dim3(1, B), dim3(T), lds, st, S, nsc, 0, sc,
+        hipLaunchKernelGGL((k_velocity_long<R, R, L, T, 2, true>), dim3(1, B), dim3(T), lds, st, S, nsc, 0, sc,
                            make_consts<R>(c), s * s, e * e, meta, (const R *)curv, (const R *)dth, (R *)ufwd, (R *)vel, bnd,
                            used, outst, dup, changed, flags);
     return hipGetLastError();
