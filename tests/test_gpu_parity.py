@@ -28,7 +28,7 @@ def make_gen(dtype, **kw):
     from vexautonomousplanner_amd.batch import BatchedTrajectoryGenerator
     if dtype == "f32r32":
         return BatchedTrajectoryGenerator(0, "f32", recurrence="f32", **kw)
-    return make_gen(dtype, **kw)
+    return BatchedTrajectoryGenerator(0, dtype, **kw)
 
 
 @pytest.fixture(scope="module")
@@ -606,7 +606,7 @@ def test_wave_per_path_relaxation_is_bit_identical(torch_mod, B, W, S, seed):
     wp = make_waypoints(B, W, seed).astype(np.float64)
     outs = {}
     for which in ("relax_wave", "relax_block", "seq_fast"):
-        gen = BatchedTrajectoryGenerator(0, "f32", velocity_kernel=which)
+        gen = make_gen("f32r32", velocity_kernel=which)
         r = run_gpu(torch_mod, gen, wp, samples=S)
         assert np.all(r["flags"] == 0), which
         outs[which] = r["velocity"]
@@ -620,7 +620,7 @@ def test_wave_per_path_ragged_rows(torch_mod):
     wp = make_waypoints(6, 8, 21).astype(np.float64)
     outs = {}
     for which in ("relax_wave", "seq_fast"):
-        gen = BatchedTrajectoryGenerator(0, "f32", velocity_kernel=which)
+        gen = make_gen("f32r32", velocity_kernel=which)
         r = run_gpu(torch_mod, gen, wp, dd=0.002, capacity=4000)
         assert np.all(r["flags"] == 0)
         outs[which] = r["velocity"]

@@ -66,7 +66,7 @@ int run_velocity(vap_ctx *ctx, bool f64, bool io64, int B, int S, const double c
     int mode = ctx->velocity_kernel;
     // per-sample initial velocities: the register-resident relaxation kernel takes them, the two-level one for
     // long rows and the wave-per-path variant do not (the sequential sweep does)
-    const int relax_limit = acc.fwd ? vap::velocity_relax_acc_max_samples(f64) : vap::velocity_relax_max_samples(f64);
+    const int relax_limit = acc.fwd ? vap::velocity_relax_acc_max_samples(f64) : vap::velocity_relax_max_samples(f64, vcap != nullptr);
     if (mode == VAP_VELOCITY_AUTO)
         mode = (vcap && S > relax_limit) ? VAP_VELOCITY_SEQ_FAST : VAP_VELOCITY_RELAX;
     const int forced = mode;
@@ -75,21 +75,26 @@ int run_velocity(vap_ctx *ctx, bool f64, bool io64, int B, int S, const double c
         if (vcap && (forced == VAP_VELOCITY_RELAX_WAVE || S > relax_limit))
             return vap_fail(VAP_ERR_UNSUPPORTED, "per-sample limits: rows up to %d samples in the relaxation kernel, or the sequential sweep",
                             relax_limit);
-        if (forced == VAP_VELOCITY_RELAX_WAVE && (f64 || S > vap::velocity_relax_max_samples(f64)))
+        if (forced == VAP_VELOCITY_RELAX_WAVE && (f64 || S > vap::velocity_relax_max_samples(false)))
             return vap_fail(VAP_ERR_UNSUPPORTED, "wave-per-path kernel: fp32 recurrence, rows up to %d samples", vap::velocity_relax_max_samples(false));
         // One wave per path (sequential windows) keeps 8 paths resident per CU instead of 2, but measured
         // 2x slower than the workgroup-per-path kernel on config 3 (every wave is then busy every round and
         // two latency-bound waves per SIMD slow each other down): kept selectable, not the default.
         const bool use_wave = forced == VAP_VELOCITY_RELAX_WAVE;
-        if (use_wave && S <= vap::velocity_relax_max_samples(f64)) {
+        if (use_wave) {
             // many paths: one wave per path keeps 8 paths resident per CU
             VAP_TRY(ctx->ensure(ctx->ufwd, (size_t)B * S * 4));
             VAP_TRY(ctx->ensure(ctx->lstate, vap::velocity_windows_state_bytes(B, S)));
             VAP_TRY(ctx->ensure(ctx->lcount, sizeof(int) * ((size_t)B + 64)));
             HIP_TRY(vap::launch_velocity_windows(ctx->stream, B, S, cc, sv, ev, meta, curv, dth, vel, flags, ctx->ufwd.ptr,
                                                  ctx->lstate.ptr, (int *)ctx->lcount.ptr));
-        } else if (S <= vap::velocity_relax_max_samples(f64)) {
-            HIP_TRY(vap::launch_velocity_relax(ctx->stream, f64, io64, B, S, cc, sv, ev, meta, curv, dth, vcap, acc, vel, flags));
+        } else if (S <= vap::velocity_relax_max_samples(f64, vcap != nullptr)) {
+            void *ufwd = nullptr;
+            if (vap::velocity_relax_uses_windows(f64, S, vcap != nullptr || acc.fwd != nullptr)) {
+                VAP_TRY(ctx->ensure(ctx->ufwd, (size_t)B * S * (f64 ? 8 : 4)));
+                ufwd = ctx->ufwd.ptr;
+            }
+            HIP_TRY(vap::launch_velocity_relax(ctx->stream, f64, io64, B, S, cc, sv, ev, meta, curv, dth, vcap, acc, vel, flags, ufwd));
         } else {
             // long rows: two-level relaxation (host-synchronised super-rounds)
             VAP_TRY(ctx->ensure(ctx->ufwd, (size_t)B * S * (f64 ? 8 : 4)));

@@ -477,6 +477,7 @@ __device__ __forceinline__ double clamp0(double x, double hi) { return fmin(fmax
 // Hides a value from code motion (loop-invariant hoisting, sinking into branches).
 __device__ __forceinline__ float opaque(float x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ double opaque(double x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
 
 // Per-sample step coefficients.  With w_i = u_i*q_i (q = k^2, the squared angular velocity) the
 // reference's dw = w_i - w_{i-1} is formed as  q_i*(u_i - rho_i*u_{i-1}),  rho_i = q_{i-1}/q_i, so the
@@ -565,18 +566,82 @@ __device__ __forceinline__ double med3(double a, double lo, double hi) { return 
 // Forward step, MPG:193-249.  A zero heading difference (|gq| = kHuge) gives the reference's
 // dw == 0 -> A, dw != 0 -> 0 without a special case: t is exactly zero when the table entry and the
 // velocity are unchanged (rho = 1), and any other t times kHuge exceeds amaxp.
-template <typename R>
-__device__ __forceinline__ R fast_forward_a(R amaxp, R rho, R gq, R A, R cap, R u, R &uprev, R u_next)
+// fp32:  am = 2dd*max_acc of the step, g = gq:   u' = min(u + med3(am - |t|*|g|, 0, A), cap, u_next)   (5 instructions)
+// fp64:  the same step scaled by 1/A, so that the clamp to [0, A] becomes the free clamp-to-[0,1] output modifier of
+//        the FMA (there is no v_med3_f64, and fmin / fmax cost a canonicalising v_max each on top — nine instructions
+//        for the unscaled form):  am = 2dd*max_acc/A, g = gq/A (fast_scale below; the sign marker of g survives),
+//            c = clamp01(am - |t|*|g|);   u' = min(A*c + u, cap [, u_next])                              (4 instructions)
+//        c is exactly 0 / exactly 1 where the unscaled form clamps, so the clamped branches are bit-identical to it;
+//        in between the two differ by one rounding of the increment (~1e-16 of u).
+__device__ __forceinline__ double fma_nabs_clamp(double t, double g, double a)   // clamp01(a - |t|*|g|)
 {
-    const R t = fma(-rho, uprev, u);
-    const R y = fma(-fabs(t), fabs(gq), amaxp);
-    uprev = u;
-    return vmin(vmin(u + med3(y, (R)0, A), cap), u_next);
+    double c;
+    asm("v_fma_f64 %0, -|%1|, |%2|, %3 clamp" : "=v"(c) : "v"(t), "v"(g), "v"(a));
+    return c;
 }
-template <typename R>
-__device__ __forceinline__ R fast_forward(const FastConsts<R> &c, R rho, R gq, R A, R cap, R u, R &uprev, R u_next)
+__device__ __forceinline__ double fma_n_clamp(double p, double g, double a)      // clamp01(a - p*|g|)
 {
-    return fast_forward_a(c.amaxp, rho, gq, A, cap, u, uprev, u_next);
+    double c;
+    asm("v_fma_f64 %0, -%1, |%2|, %3 clamp" : "=v"(c) : "v"(p), "v"(g), "v"(a));
+    return c;
+}
+// v_min_f64 / v_max_f64 as they are: fmin() / fmax() put a canonicalising v_max in front of every operand the
+// compiler cannot prove quiet (anything that went through opaque() or memory), doubling their cost
+__device__ __forceinline__ double min_raw(double a, double b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double max_raw(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// what the step functions take as (am, g) for a slot with acceleration budget amaxp, wheel term gq and clamp A
+__device__ __forceinline__ void fast_scale(float amaxp, float gq, float A, float &am, float &g)
+{
+    (void)A;
+    am = amaxp;
+    g = gq;
+}
+__device__ __forceinline__ void fast_scale(double amaxp, double gq, double A, double &am, double &g)
+{
+    const double inv = fast_rcp(A);
+    am = amaxp * inv;
+    g = gq * inv;      // (A > 0: a negative gq, the zero-heading-difference marker, stays negative)
+}
+
+__device__ __forceinline__ float fast_forward_a(float amaxp, float rho, float gq, float A, float cap, float u, float &uprev, float u_next)
+{
+    const float t = fma(-rho, uprev, u);
+    const float y = fma(-fabs(t), fabs(gq), amaxp);
+    uprev = u;
+    return vmin(vmin(u + med3(y, 0.0f, A), cap), u_next);
+}
+// u_next = +huge (no initial-velocity row): pass HAS_NEXT = false and the last min disappears
+// (the four instructions of a step as ONE asm statement: between separate ones hipcc puts an s_nop, which costs a
+// wave on a dependent chain as much as half an instruction)
+__device__ __forceinline__ double step4(double am, double rho, double g, double A, double cap, double u, double uprev)
+{
+    double r;
+    asm("v_fma_f64 %0, -%2, %3, %1\n\t"
+        "v_fma_f64 %0, -|%0|, |%4|, %5 clamp\n\t"
+        "v_fma_f64 %0, %6, %0, %1\n\t"
+        "v_min_f64 %0, %0, %7"
+        : "=&v"(r)
+        : "v"(u), "v"(rho), "v"(uprev), "v"(g), "v"(am), "v"(A), "v"(cap));
+    return r;
+}
+template <bool HAS_NEXT = true>
+__device__ __forceinline__ double fast_forward_a(double am, double rho, double g, double A, double cap, double u, double &uprev, double u_next)
+{
+    const double r = step4(am, rho, g, A, cap, u, uprev);
+    uprev = u;
+    if constexpr (HAS_NEXT) return min_raw(r, u_next);
+    else return r;
 }
 
 // Backward step, MPG:255-311.  DUP = the path has samples with a zero heading difference (gq < 0): the
@@ -585,25 +650,51 @@ __device__ __forceinline__ R fast_forward(const FastConsts<R> &c, R rho, R gq, R
 // (amaxp as an argument: routes whose nodes change max_acceleration carry it per sample, MPG:194-196, 256-257.
 // There the two limits differ — the wheel limit y comes from max_acc, the clamp A from max_dec — and a straight
 // sample, whose limit is max_dec alone (MPG:270-272), is given amaxp = A so that the clamp decides.)
-template <bool DUP, typename R>
-__device__ __forceinline__ R fast_backward_a(R amaxp, R rho, R gq, R A, R cap, R u, R &uprev, R u_prev)
+template <bool DUP>
+__device__ __forceinline__ float fast_backward_a(float amaxp, float rho, float gq, float A, float cap, float u, float &uprev, float u_prev)
 {
-    const R t = fma(-rho, uprev, u);
-    R y;
+    const float t = fma(-rho, uprev, u);
+    float y;
     if constexpr (DUP) {
         gq = opaque(gq);   // keep the select below inside the round loop (one register per sample otherwise)
-        const R other = gq < (R)0 ? (R)0 : -t;
+        const float other = gq < 0.0f ? 0.0f : -t;
         y = fma(-vmax_(t, other), fabs(gq), amaxp);
     } else {
         y = fma(-fabs(t), gq, amaxp);
     }
     uprev = u;
-    return vmin(vmin(u + med3(y, (R)0, A), cap), u_prev);
+    return vmin(vmin(u + med3(y, 0.0f, A), cap), u_prev);
 }
-template <bool DUP, typename R>
-__device__ __forceinline__ R fast_backward(const FastConsts<R> &c, R rho, R gq, R A, R cap, R u, R &uprev, R u_prev)
+// HAS_PREV = false: the caller has folded the forward value of the sample into cap (min(cap, u_prev)) already
+template <bool DUP, bool HAS_PREV = true>
+__device__ __forceinline__ double fast_backward_a(double am, double rho, double g, double A, double cap, double u, double &uprev, double u_prev)
 {
-    return fast_backward_a<DUP>(c.amaxp, rho, gq, A, cap, u, uprev, u_prev);
+    double r;
+    if constexpr (DUP) {
+        const double t = fma(-rho, uprev, u);
+        g = opaque(g);
+        const double other = g < 0.0 ? 0.0 : -t;
+        const double c = fma_n_clamp(max_raw(t, other), g, am);
+        r = min_raw(fma(A, c, u), cap);
+    } else {
+        r = step4(am, rho, g, A, cap, u, uprev);
+    }
+    uprev = u;
+    if constexpr (HAS_PREV) return min_raw(r, u_prev);
+    else return r;
+}
+
+// The step functions as the kernels call them.  kScaledStep<R>: the arithmetic type takes the scaled form, so every
+// kernel keeps the per-sample `am` of fast_scale next to g (fp32 kernels only when nodes change max_acceleration).
+template <typename R> struct ScaledStep { static constexpr bool value = false; };
+template <> struct ScaledStep<double> { static constexpr bool value = true; };
+__device__ __forceinline__ float step_fwd(float am, float rho, float g, float A, float cap, float u, float &uprev)
+{
+    return fast_forward_a(am, rho, g, A, cap, u, uprev, Huge<float>::v);
+}
+__device__ __forceinline__ double step_fwd(double am, double rho, double g, double A, double cap, double u, double &uprev)
+{
+    return fast_forward_a<false>(am, rho, g, A, cap, u, uprev, 0.0);
 }
 
 // Cooperative copy of n doubles from HBM/L2 into LDS: up to ITER loads per thread are issued before

@@ -643,7 +643,9 @@ __global__ __launch_bounds__(64) void k_velocity_seq(int B, int S, VelConsts<R> 
             const R amaxp = acc.fwd ? twodd * cur : fc.amaxp;
             fast_derive(fc, (R)fabs(K[i]), i > 0 ? (R)fabs(K[i - 1]) : (R)0, DT[i], amaxp, rho, gq, A, cap);
             if (acc.fwd) A = fast_cap_A(fc, (R)fabs(K[i]), A);
-            u = fast_forward_a(amaxp, rho, gq, A, cap, u, wprev, un);
+            R am, g;
+            fast_scale(amaxp, gq, A, am, g);
+            u = fast_forward_a(am, rho, g, A, cap, u, wprev, un);
         } else {
             const SampleLimits<R> L = sample_limits(c, (R)fabs(K[i]), cur, acc.fwd ? cur : c.adec);
             u = forward_step(c, L, cur, twodd, u, wprev, DT[i], un);
@@ -667,8 +669,10 @@ __global__ __launch_bounds__(64) void k_velocity_seq(int B, int S, VelConsts<R> 
             // difference whose angular velocity does not rise (the wheel limit is then +inf, MPG:52-59)
             // (amaxp = A there: the clamp decides, and kHuge times any non-zero rise of the angular velocity still wins)
             const R amaxp = acc.bwd ? ((kabs < (R)1e-6 || gq < (R)0) ? A : twodd * cur_acc) : fc.amaxp;
-            up = dup ? fast_backward_a<true>(amaxp, rho, gq, A, cap, u, wprev, V[i - 1])
-                     : fast_backward_a<false>(amaxp, rho, gq, A, cap, u, wprev, V[i - 1]);
+            R am, g;
+            fast_scale(amaxp, gq, A, am, g);
+            up = dup ? fast_backward_a<true>(am, rho, g, A, cap, u, wprev, V[i - 1])
+                     : fast_backward_a<false>(am, rho, g, A, cap, u, wprev, V[i - 1]);
         } else {
             const SampleLimits<R> L = sample_limits(c, (R)fabs(K[i]), cur_acc, cur_dec);
             up = backward_step(c, L, cur_acc, twodd, u, wprev, DT[i - 1], V[i - 1]);
@@ -824,6 +828,18 @@ __device__ __forceinline__ double wave_shift_down(double x)
 // VCAP: the caller gave per-sample initial velocities (MPG:121,127,153,172: node / action-point max_velocity and
 // stops); the forward step into sample j is then also limited by vcap[j]^2 — folded into that slot's cap.
 // R = arithmetic type and type of the curvature / dtheta rows; IO = type of the caller's rows (vcap, acc, vel).
+// backward step of either form: FOLDED = the forward value of the sample is already folded into cap (commit mode)
+template <bool DUP, bool FOLDED>
+__device__ __forceinline__ float bwd_step(float am, float rho, float g, float A, float cap, float u, float &uprev, float u_prev)
+{
+    return fast_backward_a<DUP>(am, rho, g, A, cap, u, uprev, FOLDED ? Huge<float>::v : u_prev);   // (one v_min3 either way)
+}
+template <bool DUP, bool FOLDED>
+__device__ __forceinline__ double bwd_step(double am, double rho, double g, double A, double cap, double u, double &uprev, double u_prev)
+{
+    return fast_backward_a<DUP, !FOLDED>(am, rho, g, A, cap, u, uprev, u_prev);
+}
+
 template <typename R, typename IO, int L, int MAXT, int MINW, bool VCAP, bool ACC>
 __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<R> c, R start_u, R end_u,
                                                                const double *__restrict__ meta,
@@ -851,8 +867,15 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
     const int lo = tid * L;
     const int TL = T * L;
     const bool aligned = (S % (16 / (int)sizeof(R))) == 0;
-    R q[L], g[L], A[L], cp[L], u[L];
-    R am[ACC ? L : 1];   // ACC: 2dd*max_acc of the slot's step (routes whose nodes change max_acceleration)
+    // the step's `am` (fast_scale, vap_device.h) per slot: fp32 only for routes whose nodes change max_acceleration
+    // (ACC), the scaled fp64 step always
+    constexpr bool PSA = ACC || ScaledStep<R>::value;
+    // CM ("commit mode", the fp64 instantiations — registers): no array of squared velocities.  The forward rounds
+    // only move boundary states and one commit evaluation writes the forward result over cp[] (the cap is dead by
+    // then); the backward sweep folds it into its own cap, min(cap, forward value), and commits into cp[] again.
+    constexpr bool CM = ScaledStep<R>::value;
+    R q[L], g[L], A[L], cp[L], u[CM ? 1 : L];
+    R am[PSA ? L : 1];
     if (tid == 0) { s_any[0] = 0; s_any[1] = 0; s_any[2] = 0; s_dup = 0; }
 
     // ---------------- forward sweep: the step (j-1 -> j) into owned sample j uses k[j-1], dth[j-1]
@@ -912,9 +935,12 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
             const int s = s0 + i, j = lo + s;
             const bool valid = j >= 1 && j <= N - 1;
             const R gq = fast_gq(fast_gg(fc, dn[i]), g[s]);
-            g[s] = opaque(valid ? gq : (R)0);
+            R amv, gv;
+            fast_scale(ACC ? am[ACC ? s : 0] : fc.amaxp, valid ? gq : (R)0, A[s], amv, gv);
+            g[s] = opaque(gv);
+            if constexpr (PSA) am[s] = amv;
             dup |= g[s] < (R)0;
-            u[s] = start_u;
+            if constexpr (!CM) u[s] = start_u;
         }
     }
     if constexpr (VCAP) {
@@ -962,8 +988,8 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
 #pragma unroll
                 for (int s = 0; s < L; s++) {
                     if (s == 0 && tid == 0) continue;   // sample 0 is the given start velocity (MPG:189)
-                    uu = fast_forward_a(ACC ? am[ACC ? s : 0] : fc.amaxp, q[s], g[s], A[s], cp[s], uu, wp, Huge<R>::v);
-                    u[s] = uu;
+                    uu = step_fwd(PSA ? am[PSA ? s : 0] : fc.amaxp, q[s], g[s], A[s], cp[s], uu, wp);
+                    if constexpr (!CM) u[s] = uu;
                 }
                 out_u = uu;
                 out_w = wp;
@@ -995,6 +1021,16 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
         if (rounds > 2 * T + 8) {
             if (tid == 0 && flags) atomicOr(&flags[b], VAP_FLAG_NOCONVERGE_BIT);
             break;
+        }
+    }
+    if constexpr (CM) {
+        // forward commit: the converged incoming states are final; write the sweep's result over the caps
+        R uu = in_u, wp = in_w;
+#pragma unroll
+        for (int s = 0; s < L; s++) {
+            if (s == 0 && tid == 0) { cp[0] = start_u; continue; }
+            uu = step_fwd(am[PSA ? s : 0], q[s], g[s], A[s], cp[s], uu, wp);
+            cp[s] = uu;
         }
     }
     const int fwd_rounds = rounds;
@@ -1029,6 +1065,7 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
                     // from the max_acc the sweep has at j+1 (MPG:256-257); a straight sample has max_dec alone
                     base = adecp_b;
                 }
+                [[maybe_unused]] const R ufwd_s = cp[s];   // CM: the forward result sits where the new cap goes
                 fast_derive_k(fc, kc, (j + 2 <= N - 1) ? kn[i] : (R)0, base, q[s], qq, A[s], cp[s]);
                 g[s] = fast_gq(fast_gg(fc, g[s]), qq);
                 if constexpr (ACC) {
@@ -1037,7 +1074,18 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
                     // — there the clamp decides: amaxp = A (kHuge times any non-zero rise still wins against it)
                     am[s] = (valid && !(kc < (R)1e-6) && !(g[s] < (R)0)) ? twodd * (R)acc.bwd[row + j + 1] : A[s];
                 }
-                if (!valid) { idle_coef(q[s], g[s], A[s], cp[s]); u[s] = end_u; }
+                if constexpr (CM) {
+                    if (!valid) { idle_coef(q[s], g[s], A[s], cp[s]); cp[s] = end_u; }
+                    else cp[s] = vmin(cp[s], ufwd_s);
+                } else {
+                    if (!valid) { idle_coef(q[s], g[s], A[s], cp[s]); u[s] = end_u; }
+                }
+                {
+                    R amv, gv;
+                    fast_scale(ACC ? am[ACC ? s : 0] : fc.amaxp, g[s], A[s], amv, gv);
+                    g[s] = gv;
+                    if constexpr (PSA) am[s] = amv;
+                }
                 q[s] = opaque(q[s]);
                 kc = kn[i];
             }
@@ -1045,7 +1093,7 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
     }
     const int last_chunk = (N - 1) / L;     // chunk that owns the fixed end sample
     if (tid >= last_chunk) { in_u = end_u; in_w = (R)0; }
-    else { in_u = u[L - 1]; in_w = in_u; }
+    else { in_u = CM ? cp[L - 1] : u[CM ? 0 : L - 1]; in_w = in_u; }
     // The backward step reads the forward value of the sample it overwrites, so a chunk cannot be
     // re-run in place: the rounds only propagate boundary states (u[] stays the forward result) and
     // one commit evaluation with the final incoming state stores the backward velocities.
@@ -1064,10 +1112,10 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
                 R uu = in_u, wp = in_w;
                 if (any_dup) {
 #pragma unroll
-                    for (int s = L - 1; s >= 0; s--) uu = fast_backward_a<true>(ACC ? am[ACC ? s : 0] : fc.amaxp, q[s], g[s], A[s], cp[s], uu, wp, u[s]);
+                    for (int s = L - 1; s >= 0; s--) uu = bwd_step<true, CM>(PSA ? am[PSA ? s : 0] : fc.amaxp, q[s], g[s], A[s], cp[s], uu, wp, u[CM ? 0 : s]);
                 } else {
 #pragma unroll
-                    for (int s = L - 1; s >= 0; s--) uu = fast_backward_a<false>(ACC ? am[ACC ? s : 0] : fc.amaxp, q[s], g[s], A[s], cp[s], uu, wp, u[s]);
+                    for (int s = L - 1; s >= 0; s--) uu = bwd_step<false, CM>(PSA ? am[PSA ? s : 0] : fc.amaxp, q[s], g[s], A[s], cp[s], uu, wp, u[CM ? 0 : s]);
                 }
                 out_u = uu;
                 out_w = wp;
@@ -1106,10 +1154,10 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
         R uu = in_u, wp = in_w;
         if (any_dup) {
 #pragma unroll
-            for (int s = L - 1; s >= 0; s--) u[s] = uu = fast_backward_a<true>(ACC ? am[ACC ? s : 0] : fc.amaxp, q[s], g[s], A[s], cp[s], uu, wp, u[s]);
+            for (int s = L - 1; s >= 0; s--) (CM ? cp[s] : u[CM ? 0 : s]) = uu = bwd_step<true, CM>(PSA ? am[PSA ? s : 0] : fc.amaxp, q[s], g[s], A[s], cp[s], uu, wp, u[CM ? 0 : s]);
         } else {
 #pragma unroll
-            for (int s = L - 1; s >= 0; s--) u[s] = uu = fast_backward_a<false>(ACC ? am[ACC ? s : 0] : fc.amaxp, q[s], g[s], A[s], cp[s], uu, wp, u[s]);
+            for (int s = L - 1; s >= 0; s--) (CM ? cp[s] : u[CM ? 0 : s]) = uu = bwd_step<false, CM>(PSA ? am[PSA ? s : 0] : fc.amaxp, q[s], g[s], A[s], cp[s], uu, wp, u[CM ? 0 : s]);
         }
     }
     // velocities leave through the stage (as IO elements, same padded positions) so the row is written with
@@ -1119,7 +1167,7 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
 #pragma unroll
     for (int s = 0; s < L; s++) {
         const int j = lo + s;
-        ostage[cpos(s)] = j < N ? (IO)vel_sqrt(u[s]) : (IO)0;
+        ostage[cpos(s)] = j < N ? (IO)vel_sqrt(CM ? cp[s] : u[CM ? 0 : s]) : (IO)0;
     }
     __syncthreads();
     IO *V = vel + row;
@@ -1235,6 +1283,8 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_long(int S, int nsc, in
     }
     if (tid == 0) { s_any[0] = 0; s_any[1] = 0; s_any[2] = 0; }
     R q[L], g[L], A[L], cp[L], u[L];   // q[] = rho, g[] = g*k^2 (vap_device.h)
+    constexpr bool PSA = ScaledStep<R>::value;   // the scaled fp64 step keeps its `am` per slot (fast_scale)
+    R am[PSA ? L : 1];
     const R base_p = BWD ? fc.adecp : fc.amaxp;
     // element e of the stage = global sample g0 + e; a forward super-chunk needs k[base-2 ..]
     constexpr int VW = 16 / (int)sizeof(R);
@@ -1274,7 +1324,10 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_long(int S, int nsc, in
         const int src = BWD ? j : j - 1;                              // dtheta sample of the step
         const R dth = stage[stage_pos<R, L>(valid ? src - g0 : 0)];
         const R gq = fast_gq(fast_gg(fc, dth), g[s]);
-        g[s] = valid ? gq : (R)0;
+        R amv, gv;
+        fast_scale(fc.amaxp, valid ? gq : (R)0, A[s], amv, gv);
+        g[s] = gv;
+        if constexpr (PSA) am[s] = amv;
     }
     if constexpr (BWD) {
         // forward velocities of the owned samples (idle slots hold end_u)
@@ -1327,15 +1380,15 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_long(int S, int nsc, in
 #pragma unroll
                     for (int s = 0; s < L; s++) {
                         if (s == 0 && tid == 0 && base == 0) continue;   // sample 0 is the given start velocity
-                        uu = fast_forward(fc, q[s], g[s], A[s], cp[s], uu, wp, Huge<R>::v);
+                        uu = step_fwd(PSA ? am[PSA ? s : 0] : fc.amaxp, q[s], g[s], A[s], cp[s], uu, wp);
                         u[s] = uu;
                     }
                 } else if (any_dup) {
 #pragma unroll
-                    for (int s = L - 1; s >= 0; s--) uu = fast_backward<true>(fc, q[s], g[s], A[s], cp[s], uu, wp, u[s]);
+                    for (int s = L - 1; s >= 0; s--) uu = fast_backward_a<true>(PSA ? am[PSA ? s : 0] : fc.amaxp, q[s], g[s], A[s], cp[s], uu, wp, u[s]);
                 } else {
 #pragma unroll
-                    for (int s = L - 1; s >= 0; s--) uu = fast_backward<false>(fc, q[s], g[s], A[s], cp[s], uu, wp, u[s]);
+                    for (int s = L - 1; s >= 0; s--) uu = fast_backward_a<false>(PSA ? am[PSA ? s : 0] : fc.amaxp, q[s], g[s], A[s], cp[s], uu, wp, u[s]);
                 }
                 out_u = uu;
                 out_w = wp;
@@ -1375,10 +1428,10 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_long(int S, int nsc, in
             R uu = in_u, wp = in_w;
             if (any_dup) {
 #pragma unroll
-                for (int s = L - 1; s >= 0; s--) u[s] = uu = fast_backward<true>(fc, q[s], g[s], A[s], cp[s], uu, wp, u[s]);
+                for (int s = L - 1; s >= 0; s--) u[s] = uu = fast_backward_a<true>(PSA ? am[PSA ? s : 0] : fc.amaxp, q[s], g[s], A[s], cp[s], uu, wp, u[s]);
             } else {
 #pragma unroll
-                for (int s = L - 1; s >= 0; s--) u[s] = uu = fast_backward<false>(fc, q[s], g[s], A[s], cp[s], uu, wp, u[s]);
+                for (int s = L - 1; s >= 0; s--) u[s] = uu = fast_backward_a<false>(PSA ? am[PSA ? s : 0] : fc.amaxp, q[s], g[s], A[s], cp[s], uu, wp, u[s]);
             }
         }
     }
@@ -1421,6 +1474,431 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_long(int S, int nsc, in
         __syncthreads();
         R *dst = ufwd + row + base;
         for (int i = tid; i < n; i += T) dst[i] = stage[stage_pos<R, L>(i)];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5d: the same relaxation, one workgroup per path walking the row in WINDOWS of T*L samples — forward
+// through the windows in order, then backward in reverse order.  A window's incoming state is final when
+// its turn comes (it is the previous window's outgoing state), so every window is relaxed exactly once and
+// the result equals the sequential sweep bit for bit, like K5b's.  What the windows buy is residency: a
+// thread holds L samples' coefficients instead of S/T, so an fp64 row of 10 000 samples needs 256 threads
+// x 20 samples (two paths per CU, each with its own critical chain in flight) instead of 512 x 20 (one).
+// Forward squared velocities wait in an HBM scratch row (ufwd, arithmetic type) for the backward sweep.
+// ------------------------------------------------------------------------------------------------
+// what a forward window hands to the next one: the recurrence state after its last sample and the inputs of the
+// next window's first step that lie before that window (|k| of its last two samples, |dtheta| of its last one)
+template <typename R>
+struct WindowCarry {
+    R u, w, k1, k2, d1;
+};
+
+template <typename R, int T>
+struct WinShared {
+    BoundaryState<R> bs[2][T / 64 + 2];   // states crossing a wavefront boundary, by round parity
+    int any[3];                           // "some chunk's incoming state changed", rotating slots
+    int dup;
+    WindowCarry<R> carry[2];              // by window parity: a window reads one while filling the other
+};
+
+// Forward sweep of window sc (samples [base, base + T*L)): the step (j-1 -> j) into owned sample j uses k[j-1],
+// dth[j-1] (and k[j-2] for rho).  Same phases as k_velocity_relax, with the previous chunk of thread 0 coming
+// from the carry.
+template <typename R, int L, int T>
+__device__ __forceinline__ void fwd_window(R *__restrict__ stage, WinShared<R, T> &sh, int S, int N, int base, size_t row,
+                                           const FastConsts<R> &fc, R start_u, const R *__restrict__ K,
+                                           const R *__restrict__ DT, R *__restrict__ ufwd, uint32_t *__restrict__ flags,
+                                           int b, int tid_in, int &rounds_out)
+{
+    // (the thread index is hidden from loop-invariant code motion: hoisted out of the window loop, the per-thread
+    // addresses of every phase of both sweeps would be live — and spilled — throughout)
+    const int tid = opaque(tid_in);
+    constexpr int SC = T * L;
+    constexpr int VW = 16 / (int)sizeof(R);
+    constexpr int BK = (L % 8 == 0) ? 8 : ((L % 5 == 0) ? 5 : 4);
+    const int lo = tid * L, jb = base + lo;
+    const bool aligned = (S % VW) == 0;
+    const int cbase = tid * (L + 1);
+    auto cpos = [&](int k) { return k < 0 ? cbase + k - 1 : (k < L ? cbase + k : cbase + k + 1); };
+    // the carry of the previous window (published by the barrier that ended it) is read where it is needed, by
+    // thread 0 only; this window's goes into the other slot as soon as its parts are known
+    const WindowCarry<R> &cin = sh.carry[(base / SC + 1) & 1];
+    WindowCarry<R> &cout = sh.carry[(base / SC) & 1];
+    if (tid == 0) { sh.any[0] = 0; sh.any[1] = 0; sh.any[2] = 0; }
+    int n_in = N - base;
+    n_in = n_in < 0 ? 0 : (n_in > SC ? SC : n_in);
+    // commit mode, as the fp64 instantiations of k_velocity_relax: no array of squared velocities; the rounds move
+    // boundary states only and one commit evaluation writes the result over cp[]
+    R q[L], g[L], A[L], cp[L];
+    constexpr bool PSA = ScaledStep<R>::value;   // the scaled fp64 step keeps its `am` per slot (fast_scale)
+    R am[PSA ? L : 1];
+    stage_load<R, L>(stage, K + base, n_in, SC, aligned, tid, T);
+    __syncthreads();
+    {
+        R kp = tid > 0 ? (R)fabs(stage[cpos(-2)]) : (base > 0 ? cin.k2 : (R)0);
+        R kc = tid > 0 ? (R)fabs(stage[cpos(-1)]) : (base > 0 ? cin.k1 : (R)0);
+#pragma unroll
+        for (int s0 = 0; s0 < L; s0 += BK) {
+            R kn[BK];
+#pragma unroll
+            for (int i = 0; i < BK; i++) kn[i] = (R)fabs(stage[cpos(s0 + i)]);
+#pragma unroll
+            for (int i = 0; i < BK; i++) {
+                const int s = s0 + i, j = jb + s;
+                const bool valid = j >= 1 && j <= N - 1;
+                fast_derive_k(fc, kc, (j >= 2) ? kp : (R)0, fc.amaxp, q[s], g[s], A[s], cp[s]);   // g[s] = k^2 for now
+                if (!valid) idle_coef(q[s], g[s], A[s], cp[s]);
+                q[s] = opaque(q[s]);
+                kp = kc;
+                kc = kn[i];
+            }
+        }
+        if (tid == T - 1) { cout.k1 = kc; cout.k2 = kp; }   // |k| of the window's last sample and of the one before it
+    }
+    __syncthreads();
+    stage_load<R, L>(stage, DT + base, n_in, SC, aligned, tid, T);
+    __syncthreads();
+    bool dup = false;
+#pragma unroll
+    for (int s0 = 0; s0 < L; s0 += BK) {
+        R dn[BK];
+#pragma unroll
+        for (int i = 0; i < BK; i++) {
+            const int k = s0 + i - 1;
+            dn[i] = (k < 0 && tid == 0) ? (base > 0 ? cin.d1 : (R)1) : stage[cpos(k)];
+        }
+#pragma unroll
+        for (int i = 0; i < BK; i++) {
+            const int s = s0 + i, j = jb + s;
+            const bool valid = j >= 1 && j <= N - 1;
+            const R gq = fast_gq(fast_gg(fc, dn[i]), g[s]);
+            R amv, gv;
+            fast_scale(fc.amaxp, valid ? gq : (R)0, A[s], amv, gv);
+            g[s] = opaque(gv);
+            if constexpr (PSA) am[s] = amv;
+            dup |= g[s] < (R)0;
+        }
+    }
+    if (tid == T - 1) cout.d1 = stage[cpos(L - 1)];
+    if (dup) sh.dup = 1;   // (read by the backward sweep, many barriers later)
+    R in_u, in_w;
+    if (tid == 0) { in_u = base > 0 ? cin.u : start_u; in_w = base > 0 ? cin.w : (R)0; }
+    else { in_u = cp[0]; in_w = in_u; }
+    const bool active = jb <= N - 1;       // the chunk holds at least one real sample
+    bool need = active;
+    R out_u = in_u, out_w = in_w;
+    int rounds = 0;
+    __syncthreads();
+    constexpr int kInner = 8;
+    const int wv = tid >> 6, lane = tid & 63;
+    int f_cur = 0, f_nxt = 1, f_prv = 2;
+    while (true) {
+#pragma unroll 1
+        for (int k = 0; k < kInner; k++) {
+            if (need) {
+                R uu = in_u, wp = in_w;
+#pragma unroll
+                for (int s = 0; s < L; s++) {
+                    if (s == 0 && jb == 0) continue;   // sample 0 is the given start velocity (MPG:189)
+                    uu = step_fwd(PSA ? am[PSA ? s : 0] : fc.amaxp, q[s], g[s], A[s], cp[s], uu, wp);
+                }
+                out_u = uu;
+                out_w = wp;
+            }
+            const R nu = wave_shift_up(out_u), nw = wave_shift_up(out_w);
+            need = false;
+            if (lane > 0 && active) {
+                need = !(same_bits(nu, in_u) && same_bits(nw, in_w));
+                in_u = nu;
+                in_w = nw;
+            }
+            if (__ballot(need) == 0) break;
+        }
+        const int pb = rounds & 1;
+        if (lane == 63) sh.bs[pb][wv + 1] = BoundaryState<R>{out_u, out_w};
+        if (tid == 0) sh.any[f_nxt] = 0;
+        __syncthreads();
+        const int changed_last = sh.any[f_prv];
+        const BoundaryState<R> nb = sh.bs[pb][wv];
+        if (rounds > 0 && changed_last == 0) break;   // nobody had work left last round
+        if (lane == 0 && tid > 0 && active) {
+            need = !(same_bits(nb.u, in_u) && same_bits(nb.w, in_w));
+            in_u = nb.u;
+            in_w = nb.w;
+        }
+        if (need) sh.any[f_cur] = 1;
+        { const int t = f_prv; f_prv = f_cur; f_cur = f_nxt; f_nxt = t; }
+        rounds++;
+        if (rounds > 2 * T + 8) {
+            if (tid == 0 && flags) atomicOr(&flags[b], VAP_FLAG_NOCONVERGE_BIT);
+            break;
+        }
+    }
+    rounds_out += rounds;
+    if (tid == T - 1) { cout.u = out_u; cout.w = out_w; }
+    {   // commit: the converged incoming states are final
+        R uu = in_u, wp = in_w;
+#pragma unroll
+        for (int s = 0; s < L; s++) {
+            if (s == 0 && jb == 0) { cp[0] = start_u; continue; }
+            uu = step_fwd(PSA ? am[PSA ? s : 0] : fc.amaxp, q[s], g[s], A[s], cp[s], uu, wp);
+            cp[s] = uu;
+        }
+    }
+    // the squared velocities wait in the scratch row for the backward sweep
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < L; s++) stage[cpos(s)] = cp[s];
+    __syncthreads();
+    {
+        R *dst = ufwd + row + base;
+        int n = S - base;
+        n = n > SC ? SC : n;
+        if (aligned && (L % VW) == 0) {
+            using VT = typename std::conditional<sizeof(R) == 4, float4, double2>::type;
+            VT *dst4 = reinterpret_cast<VT *>(dst);
+            for (int i = tid; i < n / VW; i += T) {
+                VT v;
+                R *e = reinterpret_cast<R *>(&v);
+                const int p0 = stage_pos<R, L>(i * VW);
+#pragma unroll
+                for (int k = 0; k < VW; k++) e[k] = stage[p0 + k];
+                dst4[i] = v;
+            }
+            for (int i = (n / VW) * VW + tid; i < n; i += T) dst[i] = stage[stage_pos<R, L>(i)];
+        } else {
+            for (int i = tid; i < n; i += T) dst[i] = stage[stage_pos<R, L>(i)];
+        }
+    }
+    __syncthreads();   // the stage and the shared words belong to the next window from here on
+}
+
+// Backward sweep of window sc: the step (j+1 -> j) into owned sample j uses k[j+1], dth[j] (and k[j+2] for rho);
+// slots at or past the fixed end sample N-1 are idle slots holding end_u.
+template <typename R, typename IO, int L, int T>
+__device__ __forceinline__ void bwd_window(unsigned char *__restrict__ smem_raw, WinShared<R, T> &sh, int S, int N, int base,
+                                           bool last_window, size_t row, const FastConsts<R> &fc, R end_u,
+                                           const R *__restrict__ K, const R *__restrict__ DT, const R *__restrict__ ufwd,
+                                           IO *__restrict__ vel, bool any_dup, uint32_t *__restrict__ flags, int b, int tid_in,
+                                           int &rounds_out)
+{
+    const int tid = opaque(tid_in);
+    R *stage = reinterpret_cast<R *>(smem_raw);
+    constexpr int SC = T * L;
+    constexpr int VW = 16 / (int)sizeof(R);
+    constexpr int BK = (L % 8 == 0) ? 8 : ((L % 5 == 0) ? 5 : 4);
+    const int lo = tid * L, jb = base + lo;
+    const bool aligned = (S % VW) == 0;
+    const int cbase = tid * (L + 1);
+    auto cpos = [&](int k) { return k < 0 ? cbase + k - 1 : (k < L ? cbase + k : cbase + k + 1); };
+    const WindowCarry<R> &cin = sh.carry[(base / SC + 1) & 1];
+    WindowCarry<R> &cout = sh.carry[(base / SC) & 1];
+    if (tid == 0) { sh.any[0] = 0; sh.any[1] = 0; sh.any[2] = 0; }
+    int n_in = N - base;
+    n_in = n_in < 0 ? 0 : (n_in > SC ? SC : n_in);
+    // commit mode: no array of squared velocities; the forward values are folded into the caps
+    R q[L], g[L], A[L], cp[L];
+    constexpr bool PSA = ScaledStep<R>::value;
+    R am[PSA ? L : 1];
+    {
+        int n = N - base;
+        n = n < 0 ? 0 : (n > SC + 2 ? SC + 2 : n);
+        stage_load<R, L>(stage, K + base, n, SC + 2, aligned, tid, T);
+    }
+    __syncthreads();
+    {
+        R kc = (R)fabs(stage[cpos(1)]);
+#pragma unroll
+        for (int s0 = 0; s0 < L; s0 += BK) {
+            R kn[BK];
+#pragma unroll
+            for (int i = 0; i < BK; i++) kn[i] = (R)fabs(stage[cpos(s0 + i + 2)]);
+#pragma unroll
+            for (int i = 0; i < BK; i++) {
+                const int s = s0 + i, j = jb + s;
+                fast_derive_k(fc, kc, (j + 2 <= N - 1) ? kn[i] : (R)0, fc.adecp, q[s], g[s], A[s], cp[s]);   // g[s] = k^2 for now
+                q[s] = opaque(q[s]);
+                kc = kn[i];
+            }
+        }
+    }
+    __syncthreads();
+    stage_load<R, L>(stage, DT + base, n_in, SC, aligned, tid, T);
+    __syncthreads();
+#pragma unroll
+    for (int s0 = 0; s0 < L; s0 += BK) {
+        R dn[BK];
+#pragma unroll
+        for (int i = 0; i < BK; i++) dn[i] = stage[cpos(s0 + i)];
+#pragma unroll
+        for (int i = 0; i < BK; i++) {
+            const int s = s0 + i, j = jb + s;
+            const bool valid = j <= N - 2;
+            R gq = fast_gq(fast_gg(fc, dn[i]), g[s]);
+            if (!valid) idle_coef(q[s], gq, A[s], cp[s]);
+            R amv, gv;
+            fast_scale(fc.amaxp, gq, A[s], amv, gv);
+            g[s] = opaque(gv);
+            if constexpr (PSA) am[s] = amv;
+        }
+    }
+    __syncthreads();
+    stage_load<R, L>(stage, ufwd + row + base, n_in, SC, aligned, tid, T);
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < L; s++) {
+        const R uf = stage[cpos(s)];           // forward squared velocity of the sample
+        cp[s] = (jb + s <= N - 2) ? vmin(cp[s], uf) : end_u;
+    }
+    // chunk holding the fixed end sample (only the path's last window has it)
+    const int last_chunk = last_window ? (N - 1 - base) / L : T;
+    R in_u, in_w;
+    if (tid >= last_chunk) { in_u = end_u; in_w = (R)0; }
+    else if (tid == T - 1) { in_u = cin.u; in_w = cin.w; }     // the window above handed its first chunk's state down
+    else { in_u = cp[L - 1]; in_w = in_u; }
+    const bool active = tid <= last_chunk;
+    const bool has_nb = tid < last_chunk && tid < T - 1;       // takes its incoming state from the next chunk
+    bool need = active;
+    R out_u = in_u, out_w = in_w;
+    int rounds = 0;
+    __syncthreads();
+    constexpr int kInner = 8;
+    const int wv = tid >> 6, lane = tid & 63;
+    int f_cur = 0, f_nxt = 1, f_prv = 2;
+    while (true) {
+#pragma unroll 1
+        for (int k = 0; k < kInner; k++) {
+            if (need) {
+                R uu = in_u, wp = in_w;
+                if (any_dup) {
+#pragma unroll
+                    for (int s = L - 1; s >= 0; s--) uu = bwd_step<true, true>(PSA ? am[PSA ? s : 0] : fc.amaxp, q[s], g[s], A[s], cp[s], uu, wp, (R)0);
+                } else {
+#pragma unroll
+                    for (int s = L - 1; s >= 0; s--) uu = bwd_step<false, true>(PSA ? am[PSA ? s : 0] : fc.amaxp, q[s], g[s], A[s], cp[s], uu, wp, (R)0);
+                }
+                out_u = uu;
+                out_w = wp;
+            }
+            const R nu = wave_shift_down(out_u), nw = wave_shift_down(out_w);
+            need = false;
+            if (lane < 63 && has_nb) {
+                need = !(same_bits(nu, in_u) && same_bits(nw, in_w));
+                in_u = nu;
+                in_w = nw;
+            }
+            if (__ballot(need) == 0) break;
+        }
+        const int pb = rounds & 1;
+        if (lane == 0) sh.bs[pb][wv] = BoundaryState<R>{out_u, out_w};
+        if (tid == 0) sh.any[f_nxt] = 0;
+        __syncthreads();
+        const int changed_last = sh.any[f_prv];
+        const BoundaryState<R> nb = sh.bs[pb][wv + 1];
+        if (rounds > 0 && changed_last == 0) break;
+        if (lane == 63 && has_nb) {
+            need = !(same_bits(nb.u, in_u) && same_bits(nb.w, in_w));
+            in_u = nb.u;
+            in_w = nb.w;
+        }
+        if (need) sh.any[f_cur] = 1;
+        { const int t = f_prv; f_prv = f_cur; f_cur = f_nxt; f_nxt = t; }
+        rounds++;
+        if (rounds > 2 * T + 8) {
+            if (tid == 0 && flags) atomicOr(&flags[b], VAP_FLAG_NOCONVERGE_BIT);
+            break;
+        }
+    }
+    rounds_out += rounds;
+    // the backward step reads the forward value of the sample it overwrites: one commit evaluation with the final
+    // incoming state stores the backward velocities
+    if (active) {
+        R uu = in_u, wp = in_w;
+        if (any_dup) {
+#pragma unroll
+            for (int s = L - 1; s >= 0; s--) cp[s] = uu = bwd_step<true, true>(PSA ? am[PSA ? s : 0] : fc.amaxp, q[s], g[s], A[s], cp[s], uu, wp, (R)0);
+        } else {
+#pragma unroll
+            for (int s = L - 1; s >= 0; s--) cp[s] = uu = bwd_step<false, true>(PSA ? am[PSA ? s : 0] : fc.amaxp, q[s], g[s], A[s], cp[s], uu, wp, (R)0);
+        }
+        out_u = uu;
+        out_w = wp;
+    }
+    if (tid == 0) { cout.u = out_u; cout.w = out_w; }
+    // velocities leave through the stage (as IO elements) so the row is written with 16 bytes per lane
+    __syncthreads();
+    IO *ostage = reinterpret_cast<IO *>(smem_raw);
+    constexpr int OW = 16 / (int)sizeof(IO);
+#pragma unroll
+    for (int s = 0; s < L; s++) ostage[cpos(s)] = (jb + s) < N ? (IO)vel_sqrt(cp[s]) : (IO)0;
+    __syncthreads();
+    {
+        IO *dst = vel + row + base;
+        int n = S - base;
+        n = n > SC ? SC : n;
+        if ((S % OW) == 0 && (L % OW) == 0) {
+            using VT = typename std::conditional<sizeof(IO) == 4, float4, double2>::type;
+            VT *dst4 = reinterpret_cast<VT *>(dst);
+            for (int i = tid; i < n / OW; i += T) {
+                VT v;
+                IO *e = reinterpret_cast<IO *>(&v);
+                const int p0 = stage_pos<IO, L>(i * OW);
+#pragma unroll
+                for (int k = 0; k < OW; k++) e[k] = ostage[p0 + k];
+                dst4[i] = v;
+            }
+            for (int i = (n / OW) * OW + tid; i < n; i += T) dst[i] = ostage[stage_pos<IO, L>(i)];
+        } else {
+            for (int i = tid; i < n; i += T) dst[i] = ostage[stage_pos<IO, L>(i)];
+        }
+    }
+    __syncthreads();
+}
+
+// NW = number of windows the row capacity needs (S <= NW*T*L), unrolled: inside a run-time loop the compiler
+// hoists every per-thread address of every phase out of it and spills them.
+template <typename R, typename IO, int L, int T, int MINW, int NW>
+__global__ __launch_bounds__(T, MINW) void k_velocity_win(int S, VelConsts<R> c, R start_u, R end_u,
+                                                          const double *__restrict__ meta, const R *__restrict__ curv,
+                                                          const R *__restrict__ dtheta, R *__restrict__ ufwd,
+                                                          IO *__restrict__ vel, uint32_t *__restrict__ flags,
+                                                          long long *__restrict__ stats)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];   // (T*L + T + 16) elements of R
+    __shared__ WinShared<R, T> sh;
+    const long long t0 = stats ? __builtin_amdgcn_s_memtime() : 0;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const double *m = meta + (size_t)b * kMetaStride;
+    const R twodd = (R)2 * (R)m[2];
+    const int N = (int)m[3];
+    constexpr int SC = T * L;
+    const int last_sc = N > 0 ? (N - 1) / SC : 0;
+    const size_t row = (size_t)b * S;
+    const R *K = curv + row, *DT = dtheta + row;
+    const FastConsts<R> fc = make_fast(c, twodd);
+    if (tid == 0) sh.dup = 0;
+    __syncthreads();
+    int rounds_f = 0, rounds_b = 0;
+#pragma unroll
+    for (int sc = 0; sc < NW; sc++)
+        if (sc <= last_sc)
+            fwd_window<R, L, T>(reinterpret_cast<R *>(smem_raw), sh, S, N, sc * SC, row, fc, start_u, K, DT, ufwd, flags, b, tid, rounds_f);
+    const long long t1 = stats ? __builtin_amdgcn_s_memtime() : 0;
+    const bool any_dup = sh.dup != 0;   // (the last window ended with a barrier)
+#pragma unroll
+    for (int sc = NW - 1; sc >= 0; sc--)
+        if (sc <= last_sc)
+            bwd_window<R, IO, L, T>(smem_raw, sh, S, N, sc * SC, sc == last_sc, row, fc, end_u, K, DT, ufwd, vel, any_dup, flags, b, tid,
+                                    rounds_b);
+    for (int j = (last_sc + 1) * SC + tid; j < S; j += T) vel[row + j] = (IO)0;
+    if (stats && tid == 0) {
+        long long *st = stats + (size_t)b * 8;
+        st[0] = rounds_f;
+        st[1] = rounds_b;
+        st[2] = 0;
+        st[3] = t1 - t0;
+        st[4] = __builtin_amdgcn_s_memtime() - t1;
+        st[5] = 0;
     }
 }
 
@@ -1617,7 +2095,9 @@ hipError_t launch_velocity_seq(hipStream_t st, bool r64, bool io64, bool fast, i
 }
 
 // Largest sample capacity the register-resident relaxation kernel covers.
-int velocity_relax_max_samples(bool f64) { return f64 ? 512 * 20 : 512 * 40; }
+// (plain fp64 rows are walked in windows and could be of any length; beyond 64 windows the two-level kernel, which
+// spreads a row over many workgroups, is the better tool)
+int velocity_relax_max_samples(bool f64, bool limits) { (void)limits; return f64 ? 512 * 20 : 512 * 40; }
 // ... and with per-sample max_acceleration rows (one more register array per thread)
 int velocity_relax_acc_max_samples(bool f64) { return f64 ? 512 * 8 : 512 * 20; }
 
@@ -1664,10 +2144,58 @@ static void launch_relax_t(hipStream_t st, int B, int S, const double c[6], doub
     }
 }
 
+template <typename R, typename IO, int L, int T, int MINW, int NW>
+static void launch_win_t(hipStream_t st, int B, int S, const double c[6], double sv, double ev, const double *meta,
+                         const void *curv, const void *dth, void *ufwd, void *vel, uint32_t *flags)
+{
+    const R s = (R)sv, e = (R)ev;
+    static const bool want_stats = getenv("VAP_RELAX_STATS") != nullptr;
+    long long *stats = nullptr;
+    if (want_stats) (void)hipMalloc(&stats, (size_t)B * 8 * sizeof(long long));
+    const size_t lds = sizeof(R) * ((size_t)T * L + T + 16);
+    hipLaunchKernelGGL((k_velocity_win<R, IO, L, T, MINW, NW>), dim3(B), dim3(T), lds, st, S, make_consts<R>(c), s * s, e * e, meta,
+                       (const R *)curv, (const R *)dth, (R *)ufwd, (IO *)vel, flags, stats);
+    if (stats) {
+        std::vector<long long> h((size_t)B * 8);
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(h.data(), stats, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+        (void)hipFree(stats);
+        double sum[6] = {0, 0, 0, 0, 0, 0};
+        long long mx[6] = {0, 0, 0, 0, 0, 0};
+        for (int b = 0; b < B; b++)
+            for (int k = 0; k < 6; k++) {
+                sum[k] += (double)h[(size_t)b * 8 + k];
+                if (h[(size_t)b * 8 + k] > mx[k]) mx[k] = h[(size_t)b * 8 + k];
+            }
+        fprintf(stderr, "[win L=%d T=%d] workgroup rounds fwd mean %.1f max %lld | bwd mean %.1f max %lld | ticks mean: fwd %.0f bwd %.0f | max: %lld %lld\n",
+                L, T, sum[0] / B, mx[0], sum[1] / B, mx[1], sum[3] / B, sum[4] / B, mx[3], mx[4]);
+    }
+}
+
+// rows the windowed kernel takes instead of the whole-row one (plain rows only): the fp64 recurrence beyond 4096
+// samples, where the whole-row kernel needs 512 threads x 256 registers — one path per CU
+bool velocity_relax_uses_windows(bool r64, int S, bool limits)
+{
+    static const char *cfg = getenv("VAP_RELAX_WIN");   // developer knob: 0 = never, 1 = also the fp32 recurrence
+    const int force = cfg ? atoi(cfg) : -1;
+    if (limits || force <= 0) return false;   // (default: the whole-row kernel; windows measured no faster)
+    if (r64) return S > 512 * 8 && S <= 2 * 256 * 20;
+    return S > 256 * 16 && S <= 4 * 256 * 20;
+}
+
 hipError_t launch_velocity_relax(hipStream_t st, bool r64, bool io64, int B, int S, const double c[6], double sv, double ev,
                                  const double *meta, const void *curv, const void *dth, const void *vcap,
-                                 const AccRowsV &acc, void *vel, uint32_t *flags)
+                                 const AccRowsV &acc, void *vel, uint32_t *flags, void *ufwd)
 {
+    if (velocity_relax_uses_windows(r64, S, vcap != nullptr || acc.fwd != nullptr) && ufwd) {
+        static const char *lcfg = getenv("VAP_WIN_L");   // developer knob (tuning only): 16 or 20
+        const int wl = lcfg ? atoi(lcfg) : 20;
+        (void)wl;
+        if (r64 && io64) launch_win_t<double, double, 20, 256, 2, 2>(st, B, S, c, sv, ev, meta, curv, dth, ufwd, vel, flags);
+        else if (r64) launch_win_t<double, float, 20, 256, 2, 2>(st, B, S, c, sv, ev, meta, curv, dth, ufwd, vel, flags);
+        else launch_win_t<float, float, 20, 256, 4, 4>(st, B, S, c, sv, ev, meta, curv, dth, ufwd, vel, flags);
+        return hipGetLastError();
+    }
     if (acc.fwd) {
         // per-sample max_acceleration: one more register array per thread, so shorter chunks
         // (velocity_relax_acc_max_samples() is the limit the caller checks)
