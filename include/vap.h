@@ -125,6 +125,23 @@ int vap_fit(vap_ctx *ctx, vap_dtype dt, int B, int W, const void *d_waypoints,
             double *d_segment_lengths /* [B][G] fp64, QHS:84-85, may be NULL */, double *d_meta,
             uint32_t *d_flags);
 
+/* vap_fit with the rest of QuinticHermiteSpline.fit's own inputs (QHS:30-138), for callers that use the spline
+ * class directly as SM:57-168 does for the splines of a split route:
+ *   d_first_derivatives / d_second_derivatives  [B][W][2] fp64: used only when BOTH are given (QHS:52-68: with
+ *       one missing, _compute_derivatives overwrites both)
+ *   d_starting_tangent / d_ending_tangent       [B][2] fp64, NaN row = not set: QHS:129-132 -> set_starting_tangent /
+ *       set_ending_tangent (QHS:543-590) — both write into the LAST segment (quirk Q3) — and the 2-point special
+ *       case of _compute_derivatives (QHS:170-172, 181-182: the chord stays un-normalised).
+ *   d_first_out / d_second_out                  [B][W][2] fp64, optional: the first_derivatives / second_derivatives
+ *       attributes the reference leaves behind (estimates or the caller's arrays, with the setters' writes to
+ *       first_derivatives[0] / [-1], QHS:557, 582).
+ * Any of the six may be NULL. */
+int vap_fit_ex(vap_ctx *ctx, vap_dtype dt, int B, int W, const void *d_waypoints,
+               const double *d_tangent_in, const double *d_tangent_out, const double *d_first_derivatives,
+               const double *d_second_derivatives, const double *d_starting_tangent,
+               const double *d_ending_tangent, double *d_segments, double *d_segment_lengths,
+               double *d_first_out, double *d_second_out, double *d_meta, uint32_t *d_flags);
+
 /* SM:426-475 build_lookup_table.  Fills lut and meta[1] (= get_total_arc_length, SM:320-330). */
 int vap_build_lut(vap_ctx *ctx, int B, int W, const double *d_segments, double *d_lut,
                   double *d_meta, uint32_t *d_flags);

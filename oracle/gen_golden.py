@@ -186,6 +186,118 @@ def run_case(mods, name, wp, dd=DEFAULT_DD, samples=None, node_attrs=None, actio
           f"{os.path.getsize(path) / 1024:.0f} KiB  {time.time() - t0:.1f}s", flush=True)
 
 
+def run_api_pins(mods):
+    """Reference values for the call surface the hot path does not touch: the
+    Gauss-Legendre arc-length API of QuinticHermiteSpline, the manager's exact heading / curvature, and
+    QuinticHermiteSpline.fit / set_*_tangent used directly (supplied derivatives, split tangents, 2-point splines)."""
+    sm_mod, qh, _ = mods
+    d = {}
+    wp = np.asarray(make_waypoints(1, 8, 31)[0], dtype=np.float64)
+    mgr = build_manager(sm_mod, wp)
+    mgr.rebuild_tables()
+    sp = mgr.splines[0]
+    d["wp"] = wp
+    d["total_arc_length"] = np.float64(sp.get_total_arc_length())                      # QHS:592-644 over the whole range
+    pairs = np.array([[0.0, 7.0], [0.0, 0.5], [0.25, 0.75], [1.0, 2.0], [2.3, 6.9], [6.5, 7.0], [3.0, 3.001]])
+    d["arc_pairs"] = pairs
+    d["arc_lengths"] = np.array([sp.get_arc_length(a, b) for a, b in pairs])
+    d["arc_lengths_n5"] = np.array([sp.get_arc_length(a, b, num_points=5) for a, b in pairs])
+    s_q = np.array([0.0, 0.01, 0.5, 1.0, 2.5, 4.0, float(d["total_arc_length"]) * 0.999, float(d["total_arc_length"])])
+    d["inv_s"] = s_q
+    d["inv_t"] = np.array([sp.get_parameter_by_arc_length(float(v)) for v in s_q])     # QHS:646-717
+    d["inv_t_tol3"] = np.array([sp.get_parameter_by_arc_length(float(v), tolerance=1e-3) for v in s_q])
+    pct = np.array([0.0, 12.5, 50.0, 99.0, 100.0])
+    d["percent"] = pct
+    d["percent_parameter"] = np.array([sp.percent_to_parameter(float(v)) for v in pct])   # QHS:253-286
+    d["percent_point"] = np.array([sp.percent_to_point(float(v)) for v in pct])
+    d["end_parameter"] = np.float64(sp.get_end_parameter())
+    d["magnitudes"] = np.array([sp.get_magnitude(i) for i in range(7)])
+    ts = np.concatenate([np.linspace(0.0, 7.0, 41), [0.5, 1.0, 6.999999, 3.3333]])
+    d["exact_t"] = ts
+    d["exact_heading"] = np.array([mgr._get_heading(float(t)) for t in ts])            # SM:348-379
+    d["exact_curvature"] = np.array([mgr._get_curvature(float(t)) for t in ts])        # SM:381-418
+    d["step_heading"] = np.array([mgr.get_heading(float(t)) for t in ts])              # SM:332-346 (table step lookup)
+    d["step_curvature"] = np.array([mgr.get_curvature(float(t)) for t in ts])
+    d["mgr_percent_parameter"] = np.array([mgr.percent_to_parameter(float(v)) for v in (0.0, 0.3, 0.5, 0.99, 1.0)])  # SM:277-289
+    mags = []
+    for i in range(8):                                                                  # SM:174-202
+        try:
+            mags.append([float(v) for v in mgr.get_magnitudes_at_parameter(i)])
+        except IndexError:
+            # the last node when parameters[-1] is not exactly len(nodes)-1: local_t == end fails and the general
+            # branch indexes one past the last segment
+            mags.append([np.nan, np.nan])
+    d["mgr_magnitudes"] = np.array(mags, dtype=np.float64)
+
+    # ---- QuinticHermiteSpline used directly ----
+    k = 6
+    pts = np.asarray(make_waypoints(1, k, 32)[0], dtype=np.float64)
+    rng = np.random.default_rng(7)
+    fd = rng.normal(size=(k, 2))
+    sd = rng.normal(size=(k, 2)) * 0.5
+    d["cls_points"] = pts
+    d["cls_first"] = fd
+    d["cls_second"] = sd
+
+    def fresh():
+        q = qh.QuinticHermiteSpline()
+        q.set_all_tangents([[None, None]] * k)
+        return q
+    q = fresh()
+    assert q.fit(pts[:, 0], pts[:, 1])
+    d["cls_plain_segments"] = np.array(q.segments)
+    d["cls_plain_first"] = np.array(q.first_derivatives)
+    d["cls_plain_second"] = np.array(q.second_derivatives)
+    q = fresh()
+    assert q.fit(pts[:, 0], pts[:, 1], first_derivatives=fd.copy(), second_derivatives=sd.copy())      # QHS:52-68
+    d["cls_both_segments"] = np.array(q.segments)
+    q = fresh()
+    assert q.fit(pts[:, 0], pts[:, 1], first_derivatives=fd.copy())        # one array only: overwritten by the estimates
+    d["cls_first_only_segments"] = np.array(q.segments)
+    d["cls_first_only_first"] = np.array(q.first_derivatives)
+    st, en = np.array([0.3, -0.7]), np.array([-0.2, 0.9])
+    d["cls_start_tangent"], d["cls_end_tangent"] = st, en
+    q = fresh()
+    q.starting_tangent = st.copy()
+    q.ending_tangent = en.copy()
+    assert q.fit(pts[:, 0], pts[:, 1])                                      # QHS:129-132 (quirk Q3)
+    d["cls_tangents_segments"] = np.array(q.segments)
+    d["cls_tangents_first"] = np.array(q.first_derivatives)
+    q = fresh()
+    assert q.fit(pts[:, 0], pts[:, 1])
+    assert q.set_starting_tangent(st.copy()) and q.set_ending_tangent(en.copy())      # QHS:543-590 after the fit
+    d["cls_setters_segments"] = np.array(q.segments)
+    d["cls_setters_point"] = np.array([q.get_point(t) for t in (0.2, 4.5, 4.99)])
+    d["cls_setters_derivative"] = np.array([q.get_derivative(t) for t in (0.2, 4.5, 4.99)])
+    assert q.set_starting_tangent([0.3, -0.7]) is False                      # not an ndarray: refused
+    # second fit of the same object: the derivatives of the first one are reused (attributes, QHS:66)
+    pts2 = pts + rng.normal(size=pts.shape) * 0.05
+    q = fresh()
+    assert q.fit(pts[:, 0], pts[:, 1])
+    assert q.fit(pts2[:, 0], pts2[:, 1])
+    d["cls_refit_points"] = pts2
+    d["cls_refit_segments"] = np.array(q.segments)
+    # 2-point splines: the chord stays un-normalised where the other end has a split tangent (QHS:170-172, 181-182)
+    p2 = pts[:2]
+    for tag, s_t, e_t in (("end", None, en), ("start", st, None), ("both", st, en), ("none", None, None)):
+        q = qh.QuinticHermiteSpline()
+        q.set_all_tangents([[None, None]] * 2)
+        if s_t is not None:
+            q.starting_tangent = s_t.copy()
+        if e_t is not None:
+            q.ending_tangent = e_t.copy()
+        assert q.fit(p2[:, 0], p2[:, 1])
+        d[f"cls_two_{tag}_segments"] = np.array(q.segments)
+        d[f"cls_two_{tag}_first"] = np.array(q.first_derivatives)
+    # Q1: fit before set_all_tangents
+    d["cls_q1_fit_returns"] = np.int64(bool(qh.QuinticHermiteSpline().fit(pts[:, 0], pts[:, 1])))
+    out = os.path.join(OUT, "api")
+    os.makedirs(out, exist_ok=True)
+    path = os.path.join(out, "pin_spline_api.npz")
+    np.savez_compressed(path, **d)
+    print(f"api/pin_spline_api: {len(d)} arrays, {os.path.getsize(path) / 1024:.0f} KiB", flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--c2", action="store_true", help="also run the 1e6-sample single-path case")
@@ -278,6 +390,16 @@ def main():
         na[0] = {"wait_time": 0.3}
         na[3] = {"wait_time": 0.5}
         run_case(mods, "feat_wait", wp8, node_attrs=na, full_profile=True)
+    if want("feat_split2"):
+        # splits that leave 2-node splines at both ends: reverse at node 1 (spline of nodes 0-1 with an ending tangent),
+        # turn at node 4 (spline of nodes 4-5 with a starting tangent) — QHS:170-172, 181-182, 543-590
+        wp6 = make_waypoints(1, 6, 12)[0]
+        na = [{} for _ in range(6)]
+        na[1] = {"is_reverse_node": True}
+        na[4] = {"turn": 60}
+        run_case(mods, "feat_split2", wp6, node_attrs=na, full_profile=True)
+    if want("api_pins"):
+        run_api_pins(mods)
     if want("feat_mixed"):
         na = [{} for _ in range(8)]
         na[2] = {"is_reverse_node": True, "wait_time": 0.1}

@@ -228,3 +228,151 @@ def test_generate_motion_profile_nine_tuple(mods, name):
                      (head, "headings"), (ang, "angular_vels")):
         np.testing.assert_allclose(got, g["profile_" + key], rtol=1e-8, atol=1e-8, err_msg=key)
     np.testing.assert_allclose(np.array(coords), g["profile_coords"], rtol=1e-10, atol=1e-10)
+
+
+# ---- the call surface off the hot path, against values recorded from the real reference -----------------
+# (tests/golden/api/pin_spline_api.npz, oracle/gen_golden.py::run_api_pins): SURVEY 8(a) a2, a6, a10, a18
+@pytest.fixture(scope="module")
+def pins():
+    return np.load(os.path.join(gu.GOLDEN, "api", "pin_spline_api.npz"))
+
+
+def test_arc_length_api_matches_reference(mods, pins):
+    """QuinticHermiteSpline.get_arc_length (Gauss-Legendre, QHS:592-644), get_total_arc_length,
+    get_parameter_by_arc_length (bisection, QHS:646-717), percent_* and get_magnitude."""
+    Manager, _, Node, _ = mods
+    g = pins
+    m = Manager()
+    assert m.build_path(g["wp"], [Node() for _ in g["wp"]], [])
+    sp = m.splines[0]
+    assert sp.get_total_arc_length() == pytest.approx(float(g["total_arc_length"]), rel=1e-13)
+    for (a, b), ref, ref5 in zip(g["arc_pairs"], g["arc_lengths"], g["arc_lengths_n5"]):
+        assert sp.get_arc_length(float(a), float(b)) == pytest.approx(float(ref), rel=1e-12)
+        assert sp.get_arc_length(float(a), float(b), num_points=5) == pytest.approx(float(ref5), rel=1e-12)
+    for s, t, t3 in zip(g["inv_s"], g["inv_t"], g["inv_t_tol3"]):
+        # the bisection stops at |error| < tolerance: same sequence of midpoints, so the same parameter
+        assert sp.get_parameter_by_arc_length(float(s)) == pytest.approx(float(t), rel=1e-12, abs=1e-13)
+        assert sp.get_parameter_by_arc_length(float(s), tolerance=1e-3) == pytest.approx(float(t3), rel=1e-12, abs=1e-13)
+    with pytest.raises(ValueError):
+        sp.get_parameter_by_arc_length(float(g["total_arc_length"]) + 1.0)
+    with pytest.raises(ValueError):
+        sp.get_arc_length(2.0, 1.0)
+    for pct, tp, pp in zip(g["percent"], g["percent_parameter"], g["percent_point"]):
+        assert sp.percent_to_parameter(float(pct)) == pytest.approx(float(tp), rel=1e-15)
+        np.testing.assert_allclose(sp.percent_to_point(float(pct)), pp, rtol=1e-12, atol=1e-12)
+    assert sp.get_end_parameter() == float(g["end_parameter"])
+    np.testing.assert_allclose([sp.get_magnitude(i) for i in range(7)], g["magnitudes"], rtol=1e-15)
+
+
+def test_exact_heading_curvature_match_reference(mods, pins):
+    """The manager's exact scalar _get_heading / _get_curvature (SM:348-418) next to the table step lookup
+    get_heading / get_curvature (SM:332-346), percent_to_parameter (SM:277-289, quirk Q6) and
+    get_magnitudes_at_parameter (SM:174-202) incl. the IndexError the reference raises for the last node when
+    parameters[-1] is not exactly len(nodes) - 1."""
+    Manager, _, Node, _ = mods
+    g = pins
+    m = Manager()
+    assert m.build_path(g["wp"], [Node() for _ in g["wp"]], [])
+    m.rebuild_tables()
+    for t, h, k, sh, sk in zip(g["exact_t"], g["exact_heading"], g["exact_curvature"], g["step_heading"], g["step_curvature"]):
+        assert m._get_heading(float(t)) == pytest.approx(float(h), abs=1e-13)
+        assert m._get_curvature(float(t)) == pytest.approx(float(k), rel=1e-11, abs=1e-13)
+        assert m.get_heading(float(t)) == pytest.approx(float(sh), abs=1e-13)
+        assert m.get_curvature(float(t)) == pytest.approx(float(sk), rel=1e-11, abs=1e-13)
+    for p, ref in zip((0.0, 0.3, 0.5, 0.99, 1.0), g["mgr_percent_parameter"]):
+        assert m.percent_to_parameter(p) == pytest.approx(float(ref), rel=1e-15)
+    for i, ref in enumerate(g["mgr_magnitudes"]):
+        if np.isnan(ref[0]):
+            with pytest.raises(IndexError):
+                m.get_magnitudes_at_parameter(i)
+        else:
+            np.testing.assert_allclose(m.get_magnitudes_at_parameter(i), ref, rtol=1e-15)
+
+
+def test_spline_class_used_directly_matches_reference(mods, pins):
+    """QuinticHermiteSpline.fit with caller-supplied derivatives (both / one), with starting / ending tangents
+    (attributes before the fit: QHS:129-132; setters after it: QHS:543-590, quirk Q3), a second fit of the same
+    object (derivatives reused), and 2-point splines whose chord stays un-normalised (QHS:170-172, 181-182)."""
+    from splines.quintic_hermite_spline import QuinticHermiteSpline
+    g = pins
+    pts, fd, sd = g["cls_points"], g["cls_first"], g["cls_second"]
+    k = len(pts)
+    tol = dict(rtol=1e-14, atol=1e-15)
+
+    def fresh(n=k):
+        q = QuinticHermiteSpline()
+        q.set_all_tangents([[None, None]] * n)
+        return q
+    q = fresh()
+    assert q.fit(pts[:, 0], pts[:, 1]) is True
+    np.testing.assert_allclose(np.array(q.segments), g["cls_plain_segments"], **tol)
+    np.testing.assert_allclose(q.first_derivatives, g["cls_plain_first"], **tol)
+    np.testing.assert_allclose(q.second_derivatives, g["cls_plain_second"], **tol)
+    q = fresh()
+    assert q.fit(pts[:, 0], pts[:, 1], first_derivatives=fd.copy(), second_derivatives=sd.copy()) is True
+    np.testing.assert_allclose(np.array(q.segments), g["cls_both_segments"], **tol)
+    q = fresh()
+    assert q.fit(pts[:, 0], pts[:, 1], first_derivatives=fd.copy()) is True     # overwritten by the estimates
+    np.testing.assert_allclose(np.array(q.segments), g["cls_first_only_segments"], **tol)
+    np.testing.assert_allclose(q.first_derivatives, g["cls_first_only_first"], **tol)
+    assert fresh().fit(pts[:, 0], pts[:, 1], first_derivatives=fd[:-1]) is False
+    st, en = g["cls_start_tangent"], g["cls_end_tangent"]
+    q = fresh()
+    q.starting_tangent, q.ending_tangent = st.copy(), en.copy()
+    assert q.fit(pts[:, 0], pts[:, 1]) is True
+    np.testing.assert_allclose(np.array(q.segments), g["cls_tangents_segments"], **tol)
+    np.testing.assert_allclose(q.first_derivatives, g["cls_tangents_first"], **tol)
+    q = fresh()
+    assert q.fit(pts[:, 0], pts[:, 1]) is True
+    assert q.set_starting_tangent(st.copy()) is True and q.set_ending_tangent(en.copy()) is True
+    np.testing.assert_allclose(np.array(q.segments), g["cls_setters_segments"], **tol)
+    np.testing.assert_allclose([q.get_point(t) for t in (0.2, 4.5, 4.99)], g["cls_setters_point"], rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose([q.get_derivative(t) for t in (0.2, 4.5, 4.99)], g["cls_setters_derivative"], rtol=1e-13, atol=1e-13)
+    assert q.set_starting_tangent([0.3, -0.7]) is False and q.set_ending_tangent(np.zeros(3)) is False
+    with pytest.raises(TypeError):
+        fresh().set_starting_tangent(st.copy())            # before any fit: first_derivatives is None (QHS:557)
+    pts2 = g["cls_refit_points"]
+    q = fresh()
+    assert q.fit(pts[:, 0], pts[:, 1]) is True and q.fit(pts2[:, 0], pts2[:, 1]) is True
+    np.testing.assert_allclose(np.array(q.segments), g["cls_refit_segments"], **tol)
+    p2 = pts[:2]
+    for tag, s_t, e_t in (("end", None, en), ("start", st, None), ("both", st, en), ("none", None, None)):
+        q = fresh(2)
+        if s_t is not None:
+            q.starting_tangent = s_t.copy()
+        if e_t is not None:
+            q.ending_tangent = e_t.copy()
+        assert q.fit(p2[:, 0], p2[:, 1]) is True
+        np.testing.assert_allclose(np.array(q.segments), g[f"cls_two_{tag}_segments"], **tol, err_msg=tag)
+        np.testing.assert_allclose(q.first_derivatives, g[f"cls_two_{tag}_first"], **tol, err_msg=tag)
+    assert bool(QuinticHermiteSpline().fit(pts[:, 0], pts[:, 1])) == bool(int(g["cls_q1_fit_returns"]))
+
+
+def test_route_with_two_node_split_splines(mods):
+    """feat_split2 (real reference): a reverse at node 1 and a turn at node 4 of a 6-node route leave 2-node
+    splines at both ends; fit, tables and the whole generate_motion_profile tuple through the drop-in classes."""
+    Manager, mpg, Node, _ = mods
+    g = gu.load("feat_split2")
+    wp = g["waypoints"]
+    nodes = [Node() for _ in wp]
+    for i in range(len(wp)):
+        nodes[i].is_reverse_node = bool(g["node_is_reverse_node"][i])
+        nodes[i].turn = float(g["node_turn"][i])
+    m = Manager()
+    assert m.build_path(wp, nodes, []) is True
+    assert len(m.splines) == int(g["n_splines"]) == 3
+    assert [len(s.control_points) for s in m.splines] == [2, 4, 2]
+    for si, sp in enumerate(m.splines):
+        np.testing.assert_allclose(np.array(sp.segments), g[f"spline{si}_segments"], rtol=1e-14, atol=1e-15)
+    m.rebuild_tables()
+    np.testing.assert_allclose(m.lookup_table.distances, g["lut_distances"], rtol=1e-15, atol=1e-16)
+    c = mpg.Constraints(*g["constraints"])
+    v = mpg.forward_backward_pass(m, c, float(g["dd"]))
+    assert len(v) == int(g["n_samples"])
+    np.testing.assert_allclose(np.array(v)[g["grid_idx"]], g["grid_velocity"], rtol=1e-9)
+    res = mpg.generate_motion_profile(m, c)
+    for nm, arr in zip(("times", "positions", "linear_vels", "accelerations", "headings", "angular_vels"), res[:6]):
+        ref = g["profile_" + nm]
+        assert len(arr) == len(ref), nm
+        np.testing.assert_allclose(arr, ref, rtol=1e-8, atol=1e-8, err_msg=nm)
+    assert list(res[6]) == [int(x) for x in g["profile_nodes_map"]]

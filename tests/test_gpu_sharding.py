@@ -1,0 +1,110 @@
+"""GPU-side evidence for the multi-GPU layer on a ONE-GPU box (paths are independent, the batch is cut
+into contiguous blocks, one per rank, with no data-path collective):
+
+  * single process: the HIP path on the shard_bounds blocks of one batch (2 even halves, 8 uneven shards) gives,
+    concatenated, the unsharded run bit for bit — rows, meta and path_summaries;
+  * two processes sharing cuda:0 (gloo moves host copies; what is under test is the shard arithmetic, the
+    dataclass / sequence forms of the constraints, the uneven p2p scatter / gather and the padded all-gather of
+    vexautonomousplanner_amd.dist wrapped around the real HIP compute): gathered rows == single-process rows.
+No 1 -> 8 GPU curve exists yet (the driver's scaling run was skipped in round 1); this is what a one-GPU box can show.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIELDS = ("x", "y", "heading", "curvature", "velocity")
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("n_paths,W,S,world", [(64, 32, 10000, 2), (203, 8, 1024, 8), (9, 5, 257, 8)])
+def test_shards_concatenate_to_the_unsharded_result(torch_mod, dtype, n_paths, W, S, world):
+    torch = torch_mod
+    from vexautonomousplanner_amd import dist as vd
+    from vexautonomousplanner_amd.batch import BatchedTrajectoryGenerator
+    from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
+    gen = BatchedTrajectoryGenerator(0, dtype)
+    wp = torch.tensor(make_waypoints(n_paths, W, 17), dtype=gen.tdtype, device=gen.device)
+    full = {k: v.clone() for k, v in gen.profile(wp, DEFAULT_CONSTRAINTS, samples=S).items()}
+    full_summ = vd.path_summaries(full["meta"], full["velocity"])
+    torch.cuda.synchronize()
+    sizes = []
+    parts = {k: [] for k in FIELDS + ("meta", "flags")}
+    summ = []
+    for r in range(world):
+        lo, hi = vd.shard_bounds(n_paths, r, world)
+        sizes.append(hi - lo)
+        if hi == lo:
+            continue
+        out = gen.profile(wp[lo:hi].contiguous(), DEFAULT_CONSTRAINTS, samples=S)
+        for k in parts:
+            parts[k].append(out[k].clone())
+        summ.append(vd.path_summaries(out["meta"], out["velocity"]))
+    torch.cuda.synchronize()
+    assert sum(sizes) == n_paths and max(sizes) - min(sizes) <= 1
+    for k in parts:
+        assert torch.equal(torch.cat(parts[k]), full[k]), k
+    assert torch.equal(torch.cat(summ), full_summ)
+    assert int(full["flags"].abs().max().item()) == 0
+
+
+def _rank_worker(rank, world_size, port, n_paths, W, S, dtype, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)     # before the first GPU call
+    from vexautonomousplanner_amd import dist as vd
+    from vexautonomousplanner_amd.batch import BatchedTrajectoryGenerator
+    from vexautonomousplanner_amd.motion_profiling_v2.motion_profile_generator import Constraints
+    from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
+    dev = torch.device("cuda", 0)
+    # rank 0 owns the constraints as the drop-in dataclass, the others receive them
+    cons = vd.broadcast_constraints(Constraints(*DEFAULT_CONSTRAINTS) if rank == 0 else None, dev)
+    assert cons == [float(v) for v in DEFAULT_CONSTRAINTS]
+    gen = BatchedTrajectoryGenerator(0, dtype)
+    full = torch.tensor(make_waypoints(n_paths, W, 23), dtype=gen.tdtype, device=dev) if rank == 0 else None
+    mine = vd.scatter_waypoints(full, n_paths, W, gen.tdtype, dev)
+    lo, hi = vd.shard_bounds(n_paths, rank, world_size)
+    assert mine.shape == (hi - lo, W, 2)
+    out = gen.profile(mine, cons, samples=S)
+    summ = vd.all_gather_rows(vd.path_summaries(out["meta"], out["velocity"]), n_paths)
+    rows = vd.gather_rows_to_root(out["velocity"], n_paths)
+    torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, f"summ{rank}.npy"), summ.cpu().numpy())
+    if rank == 0:
+        np.save(os.path.join(out_dir, "vel.npy"), rows.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_two_ranks_on_one_gpu_equal_the_single_process_run(torch_mod, tmp_path, dtype):
+    torch = torch_mod
+    import torch.multiprocessing as mp
+    from vexautonomousplanner_amd import dist as vd
+    from vexautonomousplanner_amd.batch import BatchedTrajectoryGenerator
+    from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
+    n_paths, W, S = 37, 8, 2000          # odd: the shards differ by one path
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_rank_worker, args=(2, port, n_paths, W, S, dtype, str(tmp_path)), nprocs=2, join=True)
+    gen = BatchedTrajectoryGenerator(0, dtype)
+    wp = torch.tensor(make_waypoints(n_paths, W, 23), dtype=gen.tdtype, device=gen.device)
+    ref = gen.profile(wp, DEFAULT_CONSTRAINTS, samples=S)
+    ref_summ = vd.path_summaries(ref["meta"], ref["velocity"]).cpu().numpy()
+    vel = np.load(tmp_path / "vel.npy")
+    assert np.array_equal(vel, ref["velocity"].cpu().numpy())
+    s0, s1 = np.load(tmp_path / "summ0.npy"), np.load(tmp_path / "summ1.npy")
+    assert np.array_equal(s0, s1) and np.array_equal(s0, ref_summ)

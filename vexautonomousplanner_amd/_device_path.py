@@ -31,7 +31,9 @@ class DevicePath:
         self._d = {}
 
     # -- K1 -------------------------------------------------------------------------------------
-    def fit(self, points, tan_in=None, tan_out=None):
+    def fit(self, points, tan_in=None, tan_out=None, first=None, second=None, start_tangent=None, end_tangent=None):
+        """vap_fit_ex: QuinticHermiteSpline.fit with everything the class can carry into it (QHS:30-138).  Leaves
+        the first / second derivatives the segments were built from in self.first / self.second."""
         pts = np.ascontiguousarray(points, dtype=np.float64)
         W = len(pts)
         dev = self.device
@@ -46,13 +48,21 @@ class DevicePath:
         if tan_in is not None:
             d["tin"] = torch.tensor(np.asarray(tan_in, dtype=np.float64)[None], device=dev)
             d["tout"] = torch.tensor(np.asarray(tan_out, dtype=np.float64)[None], device=dev)
+        def opt(a, shape):
+            return None if a is None else torch.tensor(np.asarray(a, dtype=np.float64).reshape(shape), device=dev)
+        d["first"], d["second"] = opt(first, (1, W, 2)), opt(second, (1, W, 2))
+        d["stan"], d["etan"] = opt(start_tangent, (1, 2)), opt(end_tangent, (1, 2))
+        d["fd"] = torch.empty((1, W, 2), dtype=torch.float64, device=dev)
+        d["sd"] = torch.empty((1, W, 2), dtype=torch.float64, device=dev)
         self.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-        st = self._L.vap_fit(self.ctx.handle, _lib.VAP_F64, 1, W, _ptr(d["wp"]), _ptr(d["tin"]),
-                             _ptr(d["tout"]), _ptr(d["seg"]), _ptr(d["seglen"]), _ptr(d["meta"]),
-                             _ptr(d["flags"]))
+        st = self._L.vap_fit_ex(self.ctx.handle, _lib.VAP_F64, 1, W, _ptr(d["wp"]), _ptr(d["tin"]), _ptr(d["tout"]),
+                                _ptr(d["first"]), _ptr(d["second"]), _ptr(d["stan"]), _ptr(d["etan"]), _ptr(d["seg"]),
+                                _ptr(d["seglen"]), _ptr(d["fd"]), _ptr(d["sd"]), _ptr(d["meta"]), _ptr(d["flags"]))
         if st == _lib.VAP_ERR_INVALID:
             return False
-        _lib.check(st, "vap_fit")
+        _lib.check(st, "vap_fit_ex")
+        self.first = d["fd"][0].cpu().numpy()
+        self.second = d["sd"][0].cpu().numpy()
         self.W = W
         self.segments = d["seg"][0].cpu().numpy()
         self.segment_lengths = d["seglen"][0].cpu().numpy()

@@ -40,7 +40,7 @@ EXPORTS = (
     "vap_time_profile", "vap_profile_batch", "vap_profile_batch_host", "vap_eval_host", "vap_lookup_host",
     "vap_route_create", "vap_route_destroy", "vap_route_info", "vap_route_get_splines", "vap_route_eval",
     "vap_route_lookup", "vap_route_sample_count", "vap_route_forward_backward", "vap_route_motion_profile",
-    "vap_grid_distances", "vap_route_limits", "vap_velocity_pass_limits", "vap_time_insert_waits",
+    "vap_grid_distances", "vap_route_limits", "vap_velocity_pass_limits", "vap_time_insert_waits", "vap_fit_ex",
 )
 
 
@@ -103,6 +103,7 @@ def lib():
     L.vap_ctx_set_option.argtypes = [vp, C.c_int, C.c_int]
     L.vap_last_timing.argtypes = [vp, C.POINTER(C.c_float)]
     L.vap_fit.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]
+    L.vap_fit_ex.argtypes = [vp, C.c_int, C.c_int, C.c_int] + [vp] * 13
     L.vap_build_lut.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp]
     L.vap_sample.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, vp, vp, vp,
                              vp, vp, vp, vp, vp, vp]

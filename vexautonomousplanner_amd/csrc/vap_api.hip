@@ -254,6 +254,20 @@ int vap_fit(vap_ctx *ctx, vap_dtype dt, int B, int W, const void *d_waypoints, c
     return VAP_OK;
 }
 
+int vap_fit_ex(vap_ctx *ctx, vap_dtype dt, int B, int W, const void *d_waypoints, const double *d_tangent_in,
+               const double *d_tangent_out, const double *d_first_derivatives, const double *d_second_derivatives,
+               const double *d_starting_tangent, const double *d_ending_tangent, double *d_segments,
+               double *d_segment_lengths, double *d_first_out, double *d_second_out, double *d_meta, uint32_t *d_flags)
+{
+    VAP_TRY(vap_set_device(ctx));
+    VAP_TRY(check_shape(B, W, 2));
+    if (!d_waypoints || !d_segments || !d_meta) return vap_fail(VAP_ERR_INVALID, "null buffer");
+    HIP_TRY(vap::launch_fit(ctx->stream, dt == VAP_F64, B, W, d_waypoints, d_tangent_in, d_tangent_out,
+                            d_segments, nullptr, d_segment_lengths, d_meta, d_flags, d_first_derivatives,
+                            d_second_derivatives, d_starting_tangent, d_ending_tangent, d_first_out, d_second_out));
+    return VAP_OK;
+}
+
 int vap_build_lut(vap_ctx *ctx, int B, int W, const double *d_segments, double *d_lut, double *d_meta,
                   uint32_t *d_flags)
 {

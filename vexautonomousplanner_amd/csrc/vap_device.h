@@ -295,6 +295,10 @@ __device__ __forceinline__ float dtheta_f32(double ax, double ay, double bx, dou
 // the angle between the two fp64 derivative vectors from atan's series in z = cross/dot (|z| < 0.06 for any
 // pair of neighbouring table entries of a smooth path: truncation < 1e-17), plus the 2*pi multiple of the raw
 // headings.  Relative error ~1e-16, i.e. tighter than the reference's own difference of two rounded atan2 values.
+// (the general atan2 is the rare branch of dtheta_f64: kept out of line so that its register needs do not weigh on
+// the sampling kernel's straight path)
+__device__ __attribute__((noinline)) double atan2_out_of_line(double y, double x) { return atan2(y, x); }
+
 __device__ __forceinline__ double dtheta_f64(double ax, double ay, double bx, double by, float tha, float thb)
 {
     const double cr = fma(ax, by, -(ay * bx));
@@ -310,7 +314,7 @@ __device__ __forceinline__ double dtheta_f64(double ax, double ay, double bx, do
         const double p = fma(fma(fma(fma(fma(-1.0 / 11.0, z2, 1.0 / 9.0), z2, -1.0 / 7.0), z2, 1.0 / 5.0), z2, -1.0 / 3.0), z2, 1.0);
         dl = z * p;
     } else {
-        dl = atan2(cr, dt);
+        dl = atan2_out_of_line(cr, dt);
     }
     const double n = rint(((double)(thb - tha) - dl) * 0.15915494309189535);
     return fabs(fma(n, 6.283185307179586, dl));

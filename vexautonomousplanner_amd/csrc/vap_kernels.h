@@ -19,7 +19,9 @@ constexpr int kLdsCoefSegments = 112;                     // segments whose coef
 constexpr int kMaxWaypoints = 2048;              // k_fit LDS: 7*W doubles
 
 hipError_t launch_fit(hipStream_t st, bool f64, int B, int W, const void *wp, const double *tin,
-                      const double *tout, double *seg, double *pw, double *seglen, double *meta, uint32_t *flags);
+                      const double *tout, double *seg, double *pw, double *seglen, double *meta, uint32_t *flags,
+                      const double *first = nullptr, const double *second = nullptr, const double *start_tan = nullptr,
+                      const double *end_tan = nullptr, double *out_first = nullptr, double *out_second = nullptr);
 // When aux is set, k_lut also defines each path's distance grid (what launch_grid does) — the fused call, where
 // the spacing is known before the table exists.
 struct GridArgs {

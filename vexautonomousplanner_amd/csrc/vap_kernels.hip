@@ -25,10 +25,19 @@ static_assert(kGridRunBlockDoubles == kGridRunDoubles, "scratch sizing and run-t
 // K1: fit.  One workgroup per path.  QHS:30-138, 149-219, 719-736; SM:65-77 tangent overrides.
 // LDS (dynamic): pts[W][2], dist[G], fd[W][2], sd[W][2]  (fp64)
 // ------------------------------------------------------------------------------------------------
+// ex (optional, QuinticHermiteSpline's own call surface): caller-supplied derivatives — used only when BOTH arrays are
+// given (QHS:52-68: with one of them missing _compute_derivatives overwrites both) — and the starting / ending
+// tangent of a split spline (QHS:129-132, 543-590; quirk Q3: both patch the LAST segment).
+struct FitExtras {
+    const double *first = nullptr, *second = nullptr;    // [B][W][2]
+    const double *start_tan = nullptr, *end_tan = nullptr;   // [B][2], NaN = not set
+    double *out_first = nullptr, *out_second = nullptr;      // [B][W][2]: the derivatives the segments were built from
+};
+
 template <typename IT>
 __global__ __launch_bounds__(256) void k_fit(int W, const IT *__restrict__ waypoints,
                                              const double *__restrict__ tan_in,
-                                             const double *__restrict__ tan_out,
+                                             const double *__restrict__ tan_out, FitExtras ex,
                                              double *__restrict__ segments, double *__restrict__ power,
                                              double *__restrict__ seglen, double *__restrict__ meta,
                                              uint32_t *__restrict__ flags)
@@ -59,15 +68,24 @@ __global__ __launch_bounds__(256) void k_fit(int W, const IT *__restrict__ waypo
         const double t_max = (cum == 0.0) ? (double)G : cum * (double)G / cum;
         meta[(size_t)b * kMetaStride + 0] = t_max;
     }
+    const bool have_d = ex.first && ex.second;
+    const bool has_st = ex.start_tan && !isnan(ex.start_tan[(size_t)b * 2]);
+    const bool has_en = ex.end_tan && !isnan(ex.end_tan[(size_t)b * 2]);
     // QHS:163-195 first derivatives
     for (int i = tid; i < W; i += nt) {
         double fx, fy;
-        if (i == 0) {
-            fx = (pts[2] - pts[0]) / dist[0];
-            fy = (pts[3] - pts[1]) / dist[0];
+        if (have_d) {
+            fx = ex.first[((size_t)b * W + i) * 2];
+            fy = ex.first[((size_t)b * W + i) * 2 + 1];
+        } else if (i == 0) {
+            // QHS:170-172: a 2-point spline with an ending tangent keeps the chord un-normalised
+            const double d = (W == 2 && has_en) ? 1.0 : dist[0];
+            fx = (pts[2] - pts[0]) / d;
+            fy = (pts[3] - pts[1]) / d;
         } else if (i == W - 1) {
-            fx = (pts[2 * i] - pts[2 * (i - 1)]) / dist[G - 1];
-            fy = (pts[2 * i + 1] - pts[2 * (i - 1) + 1]) / dist[G - 1];
+            const double d = (W == 2 && has_st) ? 1.0 : dist[G - 1];   // QHS:181-182
+            fx = (pts[2 * i] - pts[2 * (i - 1)]) / d;
+            fy = (pts[2 * i + 1] - pts[2 * (i - 1) + 1]) / d;
         } else {
             const double px = (pts[2 * i] - pts[2 * (i - 1)]) / dist[i - 1];
             const double py = (pts[2 * i + 1] - pts[2 * (i - 1) + 1]) / dist[i - 1];
@@ -83,7 +101,10 @@ __global__ __launch_bounds__(256) void k_fit(int W, const IT *__restrict__ waypo
     // QHS:197-219 second derivatives (zero at both ends)
     for (int i = tid; i < W; i += nt) {
         double sx = 0.0, sy = 0.0;
-        if (i > 0 && i < W - 1) {
+        if (have_d) {
+            sx = ex.second[((size_t)b * W + i) * 2];
+            sy = ex.second[((size_t)b * W + i) * 2 + 1];
+        } else if (i > 0 && i < W - 1) {
             const double avg = (dist[i - 1] + dist[i]) / 2;
             sx = (fd[2 * (i + 1)] - fd[2 * (i - 1)]) / (avg * 0.5);
             sy = (fd[2 * (i + 1) + 1] - fd[2 * (i - 1) + 1]) / (avg * 0.5);
@@ -92,6 +113,17 @@ __global__ __launch_bounds__(256) void k_fit(int W, const IT *__restrict__ waypo
         sd[2 * i + 1] = sy;
     }
     __syncthreads();
+    if (ex.out_first && ex.out_second) {
+        // the attributes the reference leaves behind: estimates (or the caller's arrays), with the tangent setters'
+        // writes to first_derivatives[0] / [-1] (QHS:557, 582)
+        for (int i = tid; i < 2 * W; i += nt) {
+            double f = fd[i];
+            if (has_st && i < 2) f = ex.start_tan[(size_t)b * 2 + i];
+            if (has_en && i >= 2 * (W - 1)) f = ex.end_tan[(size_t)b * 2 + i - 2 * (W - 1)];   // (applied second, as QHS:131-132)
+            ex.out_first[(size_t)b * W * 2 + i] = f;
+            ex.out_second[(size_t)b * W * 2 + i] = sd[i];
+        }
+    }
     // QHS:76-127 segment assembly
     for (int i = tid; i < G; i += nt) {
         const double L = dist[i];  // == np.linalg.norm(p1 - p0)
@@ -117,6 +149,10 @@ __global__ __launch_bounds__(256) void k_fit(int W, const IT *__restrict__ waypo
             r[6] = fd[2 * (i + 1)];    r[7] = fd[2 * (i + 1) + 1];
             r[8] = sd[2 * i];          r[9] = sd[2 * i + 1];
             r[10] = sd[2 * (i + 1)];   r[11] = sd[2 * (i + 1) + 1];
+        }
+        if (i == G - 1) {   // QHS:129-132 -> 543-590: both setters write into segments[-1] (quirk Q3)
+            if (has_st) { r[4] = ex.start_tan[(size_t)b * 2]; r[5] = ex.start_tan[(size_t)b * 2 + 1]; }
+            if (has_en) { r[6] = ex.end_tan[(size_t)b * 2]; r[7] = ex.end_tan[(size_t)b * 2 + 1]; }
         }
         double *sg = segments + ((size_t)b * G + i) * 12;
 #pragma unroll
@@ -470,7 +506,8 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int 
             continue;
         }
         OT vx[kSPT], vy[kSPT], vh[kSPT], vk[kSPT], vd[kSPT];
-        double vk64[HI ? kSPT : 1], vd64[HI ? kSPT : 1];
+        double vd64[HI ? kSPT : 1];
+        [[maybe_unused]] double kap_even = 0.0;   // HI: the fp64 curvature row leaves in pairs as soon as a pair exists
         // MPG:112-122 distance grid: the reference accumulates current_dist += dd.  The thread's first
         // sample comes from the path's run table (that sum in closed form), the following ones by the
         // reference's own addition.  The wave's kSPT*64 consecutive samples almost always lie in one run,
@@ -515,7 +552,21 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int 
             const double num = fma(ex, fy, -(ey * fx));                           // SM:523
             const double kap = (ss >= 1e-10) ? curvature_of(num, ss) : 0.0;       // SM:526-527
             vk[i] = (OT)kap;
-            if constexpr (HI) { vk64[i] = kap; vd64[i] = 0.0; }
+            if constexpr (HI) {
+                vd64[i] = 0.0;
+                if ((i & 1) == 0) {
+                    kap_even = kap;
+                } else if (writer) {
+                    const int ke = kbase + i - 1;
+                    const double v0 = ke < N ? kap_even : 0.0, v1 = ke + 1 < N ? kap : 0.0;
+                    if ((S & 1) == 0 && ke + 2 <= S) {
+                        *reinterpret_cast<double2 *>(ok64 + row + ke) = make_double2(v0, v1);
+                    } else {
+                        if (ke < S) ok64[row + ke] = v0;
+                        if (ke + 1 < S) ok64[row + ke + 1] = v1;
+                    }
+                }
+            }
             vh[i] = heading_of<OT>(ey, ex);                                       // SM:536
             d1x[i] = ex;
             d1y[i] = ey;
@@ -565,11 +616,11 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int 
                 for (int i = 0; i < kSPT; i++)
                     if (kbase + i >= N) {
                         vx[i] = vy[i] = vh[i] = vk[i] = vd[i] = (OT)0;
-                        if constexpr (HI) { vk64[i] = 0.0; vd64[i] = 0.0; }
+                        if constexpr (HI) vd64[i] = 0.0;
                     }
             }
             store_vec(ox, vx); store_vec(oy, vy); store_vec(oh, vh); store_vec(ok, vk);
-            if constexpr (HI) { store_hi(ok64, vk64); store_hi(odth64, vd64); }
+            if constexpr (HI) store_hi(odth64, vd64);
             store_vec(odth, vd);
         }
     }
@@ -1962,20 +2013,29 @@ __global__ void k_lookup(int W, const double *__restrict__ seg, double t_max, co
 // ------------------------------------------------------------------------------------------------
 template <typename IT>
 static hipError_t launch_fit_t(hipStream_t st, int B, int W, const void *wp, const double *tin,
-                               const double *tout, double *seg, double *pw, double *seglen, double *meta,
+                               const double *tout, const FitExtras &ex, double *seg, double *pw, double *seglen, double *meta,
                                uint32_t *flags)
 {
     const size_t lds = sizeof(double) * (size_t)(7 * W);
-    hipLaunchKernelGGL(k_fit<IT>, dim3(B), dim3(W <= 64 ? 64 : 256), lds, st, W, (const IT *)wp, tin, tout,
+    hipLaunchKernelGGL(k_fit<IT>, dim3(B), dim3(W <= 64 ? 64 : 256), lds, st, W, (const IT *)wp, tin, tout, ex,
                        seg, pw, seglen, meta, flags);
     return hipGetLastError();
 }
 
 hipError_t launch_fit(hipStream_t st, bool f64, int B, int W, const void *wp, const double *tin,
-                      const double *tout, double *seg, double *pw, double *seglen, double *meta, uint32_t *flags)
+                      const double *tout, double *seg, double *pw, double *seglen, double *meta, uint32_t *flags,
+                      const double *first, const double *second, const double *start_tan, const double *end_tan,
+                      double *out_first, double *out_second)
 {
-    return f64 ? launch_fit_t<double>(st, B, W, wp, tin, tout, seg, pw, seglen, meta, flags)
-               : launch_fit_t<float>(st, B, W, wp, tin, tout, seg, pw, seglen, meta, flags);
+    FitExtras ex;
+    ex.first = first;
+    ex.second = second;
+    ex.start_tan = start_tan;
+    ex.end_tan = end_tan;
+    ex.out_first = out_first;
+    ex.out_second = out_second;
+    return f64 ? launch_fit_t<double>(st, B, W, wp, tin, tout, ex, seg, pw, seglen, meta, flags)
+               : launch_fit_t<float>(st, B, W, wp, tin, tout, ex, seg, pw, seglen, meta, flags);
 }
 
 hipError_t launch_lut(hipStream_t st, int B, int W, const double *seg, double *lut, double *slopes, double *meta,

@@ -31,10 +31,22 @@ def shard_bounds(n_paths: int, rank: int, world_size: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def _six(constraints):
+    """A Constraints-like object (the drop-in dataclass, MPG:14-21 field order) or a 6-sequence -> 6 floats."""
+    if hasattr(constraints, "max_vel"):
+        c = constraints
+        return [float(c.max_vel), float(c.max_acc), float(c.max_dec), float(c.friction_coef), float(c.max_jerk),
+                float(c.track_width)]
+    vals = [float(v) for v in constraints]
+    if len(vals) != 6:
+        raise ValueError("constraints need 6 values: max_vel, max_acc, max_dec, friction_coef, max_jerk, track_width")
+    return vals
+
+
 def broadcast_constraints(constraints, device, src: int = 0):
     """Rank `src` owns the constraints; every rank returns the same 6 floats."""
     rank, ws = world()
-    vals = [float(v) for v in constraints] if (rank == src and constraints is not None) else [0.0] * 6
+    vals = _six(constraints) if (rank == src and constraints is not None) else [0.0] * 6
     t = torch.tensor(vals, dtype=torch.float64, device=device)
     if ws > 1:
         tc = t.to(_comm_device(t))

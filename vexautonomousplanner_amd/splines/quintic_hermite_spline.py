@@ -55,27 +55,47 @@ class QuinticHermiteSpline(Spline):
         return tin, tout
 
     def fit(self, x, y, first_derivatives=None, second_derivatives=None) -> bool:
+        """QHS:30-138.  Caller-supplied derivatives are used only when both are present — with one missing the
+        reference's _compute_derivatives overwrites both (QHS:66-68, 149-219) — and, as there, derivatives left by
+        an earlier fit of this object are reused by the next one (they are attributes, QHS:56, 62, 66)."""
         if len(x) != len(y) or len(x) < 2:
             return False
-        if first_derivatives is not None or second_derivatives is not None:
-            raise NotImplementedError("caller-supplied derivatives are not used anywhere in the "
-                                      "reference's call graph and are not on the device path")
+        k = len(x)
+        if first_derivatives is not None:
+            if len(first_derivatives) != k:
+                return False
+            self.first_derivatives = first_derivatives
+        if second_derivatives is not None:
+            if len(second_derivatives) != k:
+                return False
+            self.second_derivatives = second_derivatives
+        estimate = self.first_derivatives is None or self.second_derivatives is None
         if self.set_tangents is None:
-            return False  # Q1
+            return False  # Q1: the reference dereferences set_tangents[i] and its blanket except returns False
         pts = np.column_stack((np.asarray(x, dtype=float), np.asarray(y, dtype=float)))
-        if self.starting_tangent is not None or self.ending_tangent is not None:
-            raise NotImplementedError("split-point tangents (reverse / turn nodes) are SURVEY §8(f) "
-                                      "rank 2 and not on the device path yet")
         try:
-            tin, tout = self._tangent_rows(len(pts))
-        except (TypeError, IndexError):
+            tin, tout = self._tangent_rows(k)
+            first = second = None
+            if not estimate:
+                first = np.asarray(self.first_derivatives, dtype=float).reshape(k, 2)
+                second = np.asarray(self.second_derivatives, dtype=float).reshape(k, 2)
+            stan = etan = None
+            if self.starting_tangent is not None:
+                # QHS:129-130 -> set_starting_tangent: anything but a (2,) ndarray is refused there, silently
+                if isinstance(self.starting_tangent, np.ndarray) and self.starting_tangent.shape == (2,):
+                    stan = self.starting_tangent
+            if self.ending_tangent is not None:
+                if isinstance(self.ending_tangent, np.ndarray) and self.ending_tangent.shape == (2,):
+                    etan = self.ending_tangent
+        except (TypeError, IndexError, ValueError):
             return False  # the reference's blanket `except Exception: return False` (QHS:136-138)
         dev = DevicePath()
-        if not dev.fit(pts, tin, tout):
+        if not dev.fit(pts, tin, tout, first, second, stan, etan):
             return False
         self._dev = dev
         self.control_points = pts
-        k = len(pts)
+        self.first_derivatives = dev.first
+        self.second_derivatives = dev.second
         # QHS:719-736 chord-length parameters (only [0] and [-1] are ever read); the cumulative
         # chord and parameters[-1] itself come from the device fit
         cum = np.concatenate(([0.0], np.cumsum(dev.segment_lengths)))
@@ -155,10 +175,25 @@ class QuinticHermiteSpline(Spline):
 
     # -- tangent setters (QHS:543-590) --------------------------------------------------------------
     def set_starting_tangent(self, tangent: np.ndarray) -> bool:
-        raise NotImplementedError("split-point tangents: SURVEY §8(f) rank 2")
+        """QHS:543-564.  Quirk Q3 kept: the row that changes is the LAST segment's start tangent.  (The evaluators
+        take the segment rows from this host mirror on every call, so the patch is all there is to do.)"""
+        if not isinstance(tangent, np.ndarray) or tangent.shape != (2,):
+            return False
+        self.first_derivatives[0] = tangent      # TypeError before the first fit, as in the reference
+        if len(self.segments) > 0:
+            self.segments[-1][2] = tangent
+        self.starting_tangent = tangent
+        return True
 
     def set_ending_tangent(self, tangent: np.ndarray) -> bool:
-        raise NotImplementedError("split-point tangents: SURVEY §8(f) rank 2")
+        """QHS:566-590."""
+        if not isinstance(tangent, np.ndarray) or tangent.shape != (2,):
+            return False
+        self.first_derivatives[-1] = tangent
+        if len(self.segments) > 0:
+            self.segments[-1][3] = tangent
+        self.ending_tangent = tangent
+        return True
 
     # -- exact-ish arc length API (QHS:592-717; unused by the manager) -------------------------------
     def get_arc_length(self, t_start: float, t_end: float, num_points: int = 20) -> float:
