@@ -55,7 +55,11 @@ def test_shards_concatenate_to_the_unsharded_result(torch_mod, dtype, n_paths, W
     assert sum(sizes) == n_paths and max(sizes) - min(sizes) <= 1
     for k in parts:
         assert torch.equal(torch.cat(parts[k]), full[k]), k
-    assert torch.equal(torch.cat(summ), full_summ)
+    # (length and sample count are copies; the traversal time is a per-path fp64 sum whose association torch picks
+    # by tensor shape, so shards agree with the unsharded batch to rounding, not to the bit)
+    got = torch.cat(summ)
+    assert torch.equal(got[:, :2], full_summ[:, :2])
+    assert float(((got[:, 2] - full_summ[:, 2]).abs() / full_summ[:, 2]).max()) <= 1e-14
     assert int(full["flags"].abs().max().item()) == 0
 
 
@@ -107,4 +111,5 @@ def test_two_ranks_on_one_gpu_equal_the_single_process_run(torch_mod, tmp_path, 
     vel = np.load(tmp_path / "vel.npy")
     assert np.array_equal(vel, ref["velocity"].cpu().numpy())
     s0, s1 = np.load(tmp_path / "summ0.npy"), np.load(tmp_path / "summ1.npy")
-    assert np.array_equal(s0, s1) and np.array_equal(s0, ref_summ)
+    assert np.array_equal(s0, s1) and np.array_equal(s0[:, :2], ref_summ[:, :2])
+    np.testing.assert_allclose(s0[:, 2], ref_summ[:, 2], rtol=1e-14)
