@@ -93,20 +93,57 @@ def parity_check(out, wp, S, constraints, n_paths, dtype):
     return res
 
 
-def profiled_traffic(stage, workload, dtype, paths):
+def tolerance_sweep(device_index, wp32, constraints, S):
+    """Per-path worst relative velocity difference of the fp32-row modes against the fp64 run of the same batch
+    (fp32-representable waypoints, so all modes see identical inputs).  Quantiles over the paths of this rank."""
+    import torch
+    from vexautonomousplanner_amd.batch import BatchedTrajectoryGenerator
+    ref = BatchedTrajectoryGenerator(device_index, "f64").profile(wp32.double(), constraints, samples=S, want=("velocity",))["velocity"]
+    out = {"reference": "this library's fp64 mode on the same batch", "measure": "max over a path's samples of |v - v64| / v64",
+           "modes": {}}
+    for name, rec in (("f32 rows, f64 recurrence (default)", "f64"), ("f32 rows, f32 recurrence", "f32")):
+        v = BatchedTrajectoryGenerator(device_index, "f32", recurrence=rec).profile(wp32.float(), constraints, samples=S,
+                                                                                     want=("velocity",))["velocity"]
+        e = ((v.double() - ref).abs() / ref).amax(dim=1)
+        q = torch.quantile(e, torch.tensor([0.5, 0.9, 0.99, 0.999], dtype=torch.float64, device=e.device))
+        out["modes"][name] = {"paths": int(e.numel()), "median": float(q[0]), "p90": float(q[1]), "p99": float(q[2]),
+                              "p999": float(q[3]), "worst": float(e.max()), "paths_above_1e-5": int((e > 1e-5).sum())}
+        del v, e
+    return out
+
+
+def kernel_source_sha():
+    """sha256 over the kernel sources the library is built from: a PMC profile is only quoted while it matches."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "vexautonomousplanner_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def profiled_traffic(stage, workload, dtype, paths, recurrence):
     """HBM bytes per launch of the stage's kernel from the committed PMC profile of this round
-    (profiles/r*_traffic.json, made by tools/profile_round.sh: separate FETCH_SIZE / WRITE_SIZE passes,
-    gfx950 corrections applied).  Only meaningful for the default workload the profile was taken on."""
+    (profiles/r*_traffic.json, made by tools/profile_round.sh: separate FETCH_SIZE / WRITE_SIZE passes, gfx950
+    corrections applied) — only while that profile was taken on this workload and mode AND on these kernel sources
+    (it records their hash); otherwise (None, reason): a stale figure is not quoted."""
     import glob
-    if workload != "c3" or dtype != "f32" or paths != WORKLOADS["c3"]["paths"]:
-        return None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
     if not files:
-        return None
+        return None, "no PMC profile committed"
+    prof = json.load(open(files[-1]))
+    name = os.path.basename(files[-1])
+    want = {"workload": workload, "dtype": dtype, "paths": paths, "recurrence": recurrence if dtype == "f32" else "f64"}
+    have = prof.get("bench", {})
+    if any(have.get(k) != v for k, v in want.items()):
+        return None, f"{name} was taken on another workload / mode"
+    if prof.get("kernel_source_sha") != kernel_source_sha():
+        return None, f"{name} is stale: the kernel sources changed since it was taken"
     kern = {"sample": "k_sample", "velocity": "k_velocity", "fit": "k_fit", "lut": "k_lut"}[stage]
-    data = json.load(open(files[-1]))["kernels"]
-    vals = [v["hbm_bytes"] for k, v in data.items() if kern in k]
-    return sum(vals) if vals else None
+    vals = [v["hbm_bytes"] for k, v in prof["kernels"].items() if kern in k]
+    return (sum(vals), name) if vals else (None, f"{name} has no {kern} entry")
 
 
 def main():
@@ -125,6 +162,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--time-domain", action="store_true",
                     help="also time the batched time-domain resample (vap_time_profile) after the timed region")
+    ap.add_argument("--tolerance-sweep", action="store_true",
+                    help="BASELINE config 5: after the timed region run the same batch in the other precision modes and "
+                         "report the per-path distribution of |fp32 - fp64| (relative, velocity) on the device")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="process-group backend; gloo + --share-device rehearses the multi-rank path on a 1-GPU box")
     ap.add_argument("--share-device", action="store_true", help="(rehearsal) every rank uses cuda:0")
@@ -236,6 +276,20 @@ def main():
     if rank == 0 and args.parity_paths > 0:
         parity = parity_check(out, wp, S, constraints, min(args.parity_paths, B), args.dtype)
 
+    # BASELINE config 5, "fp64 vs fp32 tolerance sweep": this rank's whole batch in every mode, compared on the device
+    sweep = None
+    if args.tolerance_sweep:
+        sweep = tolerance_sweep(local_rank, wp, constraints, S)
+        if world > 1:
+            # worst over ranks, counts summed: three small all-reduces after the timed region
+            for mode in sweep["modes"].values():
+                t = torch.tensor([mode["worst"]], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                mode["worst"] = float(t.item())
+                c = torch.tensor([mode["paths_above_1e-5"], mode["paths"]], dtype=torch.float64, device=dev)
+                dist.all_reduce(c)
+                mode["paths_above_1e-5"], mode["paths"] = int(c[0].item()), int(c[1].item())
+
     if rank == 0:
         points = B * S * world
         esz = 4 if args.dtype == "f32" else 8
@@ -245,7 +299,7 @@ def main():
         dom = max(("fit", "lut", "sample", "velocity"), key=lambda k: acc.get(k, 0.0))
         dom_ms = acc[dom]
         achieved = stage_bytes[dom] * B * S / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        traffic = profiled_traffic(dom, args.workload, args.dtype, B)
+        traffic, traffic_note = profiled_traffic(dom, args.workload, args.dtype, B, args.recurrence)
         line = {
             "metric": "trajectory sample-points/sec (batched paths)",
             "value": points / elapsed * args.steps,
@@ -261,7 +315,7 @@ def main():
                        "flags_or": flags, "sum_path_length_ft": total_len,
                        "fastest_traversal_s": best_time},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "kernel_ms": dom_ms, "algorithmic_bytes_per_point": stage_bytes[dom]},
             "pipeline": {"bytes_per_point": bytes_per_point,
                          "achieved_GBs": bytes_per_point * B * S / (acc["total"] * 1e-3) / 1e9,
@@ -270,10 +324,15 @@ def main():
         }
         if parity is not None:
             line["parity"] = parity
+        if sweep is not None:
+            line["tolerance_sweep"] = sweep
         if time_domain is not None:
             line["time_domain"] = time_domain
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(wl)
+            # context, not measured here: the reference's own Python cannot travel to this box
+            line["cpu_baseline"]["reference_python"] = {"value": 5.3e3, "unit": "sample-points/s", "cores": 1,
+                                                        "measured": "build container, 1 Xeon 2.1 GHz core, config 1 (BASELINE.md)"}
         print(json.dumps(line))
     if world > 1:
         dist.barrier()
