@@ -334,6 +334,122 @@ __global__ __launch_bounds__(256) void k_lut(int W, const double *__restrict__ s
     }
 }
 
+// K2 for very many short paths (config 5: 131 072 paths x 8 waypoints): one workgroup builds the tables of 64 paths.
+// The 1000-entry sequential sum — np.cumsum's order, kept for bit-identity — costs a one-lane chain of 1000
+// dependent fp64 adds per path in k_lut; here the 64 lanes of one wavefront each walk their own path's chain, so
+// the chain is paid once per 64 paths.  Entries go through LDS in tiles of 32 per path: all threads evaluate
+// magnitudes and trapezoid increments (lanes = consecutive entries of a path, so segment rows are read as
+// broadcasts), the scanner wave adds, all threads store distances and slopes (256-byte rows).
+// Same expressions in the same order as k_lut: the tables are bit-identical.
+constexpr int kLutManyPaths = 64, kLutManyTile = 32, kLutManyThreads = 256;
+__global__ __launch_bounds__(kLutManyThreads) void k_lut_many(int B, int W, const double *__restrict__ segments,
+                                                               double *__restrict__ lut, double *__restrict__ slopes,
+                                                               double *__restrict__ meta, uint32_t *__restrict__ flags,
+                                                               GridArgs grid)
+{
+    constexpr int P = kLutManyPaths, TE = kLutManyTile, ST = TE + 1;   // row stride 33: lane = path reads hit 64 banks
+    extern __shared__ __attribute__((aligned(16))) double s_seg[];     // the 64 paths' segment rows: P * G * 12
+    __shared__ double s_mag[P * ST], s_inc[P * ST];
+    __shared__ double s_prev_mag[P], s_carry[P], s_prev_cum[P], s_tmax[P];
+    const int tid = threadIdx.x, b0 = blockIdx.x * P;
+    const int G = W - 1;
+    const int n_paths = B - b0 < P ? B - b0 : P;
+    lds_fill<4>(s_seg, segments + (size_t)b0 * G * 12, n_paths * G * 12, tid, kLutManyThreads);
+    if (tid < P) {
+        s_prev_mag[tid] = 0.0; s_carry[tid] = 0.0; s_prev_cum[tid] = 0.0;
+        s_tmax[tid] = tid < n_paths ? meta[(size_t)(b0 + tid) * kMetaStride + 0] : 1.0;
+    }
+    __syncthreads();
+    constexpr int kTiles = (kLutN + TE - 1) / TE;
+#pragma unroll 1
+    for (int tl = 0; tl < kTiles; tl++) {
+        const int j0 = tl * TE;
+        // magnitudes |P'(t_j)| (SM:447-448): item = (path, entry), a wavefront covers two paths' 32 entries
+#pragma unroll 2
+        for (int r = 0; r < P * TE / kLutManyThreads; r++) {
+            const int it = tid + r * kLutManyThreads, p = it / TE, e = it % TE, j = j0 + e, b = b0 + p;
+            double m = 0.0;
+            if (b < B && j < kLutN) {
+                const double t_max = s_tmax[p];
+                const double t = linspace_at(t_max, kLutN, j);
+                double lt;
+                int idx;
+                normalize_parameter(t, t_max, G, lt, idx);
+                double dx, dy;
+                hermite_d1_ref(s_seg + ((size_t)p * G + idx) * 12, lt, dx, dy);
+                m = sqrt(dx * dx + dy * dy);
+            }
+            s_mag[p * ST + e] = m;
+        }
+        __syncthreads();
+        // trapezoid increments (SM:452-454: (m[j-1] + m[j]) * 0.5 * dt, that association)
+#pragma unroll
+        for (int r = 0; r < P * TE / kLutManyThreads; r++) {
+            const int it = tid + r * kLutManyThreads, p = it / TE, e = it % TE, j = j0 + e, b = b0 + p;
+            double inc = 0.0;
+            if (b < B && j > 0 && j < kLutN) {
+                const double t_max = s_tmax[p];
+                const double dt = linspace_at(t_max, kLutN, 1) - linspace_at(t_max, kLutN, 0);   // SM:444
+                const double mp = e > 0 ? s_mag[p * ST + e - 1] : s_prev_mag[p];
+                inc = (mp + s_mag[p * ST + e]) * 0.5 * dt;
+            }
+            s_inc[p * ST + e] = inc;
+        }
+        __syncthreads();
+        // np.cumsum's strictly left-to-right sum, one lane per path
+        if (tid < P) {
+            double acc = s_carry[tid];
+            const double last_mag = s_mag[tid * ST + TE - 1];
+#pragma unroll
+            for (int h = 0; h < TE; h += 8) {      // eight reads in flight, eight dependent adds, eight writes
+                double v[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[e] = s_inc[tid * ST + h + e];
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    acc += v[e];
+                    v[e] = acc;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; e++) s_mag[tid * ST + h + e] = v[e];   // the tile's distances
+            }
+            s_prev_mag[tid] = last_mag;
+            s_carry[tid] = acc;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < P * TE / kLutManyThreads; r++) {
+            const int it = tid + r * kLutManyThreads, p = it / TE, e = it % TE, j = j0 + e, b = b0 + p;
+            if (b < B && j < kLutN) {
+                const double c = s_mag[p * ST + e];
+                lut[(size_t)b * kLutN + j] = c;
+                if (slopes) {
+                    // (t1 - t0)/(d1 - d0) of SM:311-317 for the interval ending at entry j
+                    double w = 0.0;
+                    if (j > 0) {
+                        const double t_max = s_tmax[p];
+                        const double lstep = t_max / (double)(kLutN - 1);
+                        const double t0 = (double)(j - 1) * lstep, t1 = (j == kLutN - 1) ? t_max : (double)j * lstep;
+                        const double cp = e > 0 ? s_mag[p * ST + e - 1] : s_prev_cum[p];
+                        w = (t1 - t0) / (c - cp);
+                    }
+                    slopes[(size_t)b * kLutN + j] = w;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < P) s_prev_cum[tid] = s_mag[tid * ST + TE - 1];
+        // (the next tile's first barrier orders this write before its readers)
+    }
+    if (tid < P && b0 + tid < B) {
+        const int b = b0 + tid;
+        const double acc = s_carry[tid];
+        meta[(size_t)b * kMetaStride + 1] = acc;
+        if (flags && !(acc > 0.0 && isfinite(acc))) atomicOr(&flags[b], VAP_FLAG_DEGENERATE_BIT);
+        if (grid.aux) grid_define(b, W, grid.S, grid.dd, acc, meta[(size_t)b * kMetaStride + 0], meta, grid.aux, grid.runs, flags);
+    }
+}
+
 // Slopes for a distance table that came in through the staged API.
 __global__ void k_lut_slopes(int B, const double *__restrict__ lut, const double *__restrict__ meta,
                              double *__restrict__ slopes)
@@ -2044,6 +2160,15 @@ hipError_t launch_lut(hipStream_t st, int B, int W, const double *seg, double *l
     static const bool want_stats = getenv("VAP_LUT_STATS") != nullptr;
     long long *stats = nullptr;
     if (want_stats) (void)hipMalloc(&stats, (size_t)B * 4 * sizeof(long long));
+    static const char *many_cfg = getenv("VAP_LUT_MANY");   // developer knob: 0 = never, 1 = always
+    const int many = many_cfg ? atoi(many_cfg) : -1;
+    // (the 64 paths' segment rows are staged in LDS: 6 KB per segment column, so short paths only)
+    if (!want_stats && W <= 9 && (many == 1 || (many != 0 && B >= 32768))) {
+        // very many paths: 64 per workgroup, the sequential sums of 64 paths in the lanes of one wavefront
+        hipLaunchKernelGGL(k_lut_many, dim3((B + kLutManyPaths - 1) / kLutManyPaths), dim3(kLutManyThreads),
+                           sizeof(double) * kLutManyPaths * (W - 1) * 12, st, B, W, seg, lut, slopes, meta, flags, grid);
+        return hipGetLastError();
+    }
     // 128 threads: the sequential sum keeps one lane busy, so residency (16 workgroups per CU) is what hides it
     if (W - 1 <= 512) hipLaunchKernelGGL(k_lut<true>, dim3(B), dim3(128), sizeof(double) * 12 * (W - 1), st, W, seg, lut, slopes, meta, flags, grid, stats);
     else hipLaunchKernelGGL(k_lut<false>, dim3(B), dim3(128), 0, st, W, seg, lut, slopes, meta, flags, grid, stats);
