@@ -266,6 +266,27 @@ int vap_profile_batch(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd
                       double end_vel, void *d_x, void *d_y, void *d_heading, void *d_curvature,
                       void *d_velocity, double *d_meta, uint32_t *d_flags);
 
+/* The same for B routes whose reverse / turn nodes cut them into several splines (SM:42-172 build_path for a whole
+ * batch): fit with split tangents (SM:84-158) and the tangent setters' quirk (QHS:543-590), one 1000-entry table per
+ * spline concatenated with running offsets (SM:436-464), distance -> parameter over that table and parameter ->
+ * (spline, local parameter) with a split node belonging to the earlier spline (SM:243-275), then the plain velocity
+ * pass — forward_backward_pass treats reverse / turn nodes like any other node (MPG:112-176).
+ *   max_splines            upper bound of the splines of any route of the batch (1 + its reverse / turn nodes among
+ *                          nodes 1..W-2); table scratch is sized by it
+ *   d_node_reverse [B][W]  int32 is_reverse_node, d_node_turn [B][W] degrees (NULL arrays: none)
+ *   d_node_tangent [B][W][2] fp64 (NaN row = None) with d_node_magnitudes [B][W][2] {incoming, outgoing} (SM:65-77)
+ *   d_spline_counts [B]    int32 out, optional: splines per route
+ * A route with a reverse / turn attribute on its LAST node (IndexError in the reference, SM:97) or with more
+ * splines than max_splines is flagged VAP_FLAG_BAD_ROUTE; its rows are undefined.  Afterwards the context holds the
+ * batch's tables: vap_route_limits + vap_velocity_pass_limits apply node / action-point limits as for plain paths.
+ * The time domain of split routes (in-place turns, reversed rows) is vap_route_motion_profile's. */
+#define VAP_FLAG_BAD_ROUTE 8u
+int vap_profile_routes(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd, int max_splines,
+                       const void *d_waypoints, const int *d_node_reverse, const double *d_node_turn,
+                       const double *d_node_tangent, const double *d_node_magnitudes, const vap_constraints *c,
+                       double start_vel, double end_vel, void *d_x, void *d_y, void *d_heading, void *d_curvature,
+                       void *d_velocity, double *d_meta, uint32_t *d_flags, int *d_spline_counts);
+
 /* Same with host buffers (allocates device scratch in the context arena, copies in and out,
  * synchronises).  This is what a single-path GUI call uses. */
 int vap_profile_batch_host(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd,

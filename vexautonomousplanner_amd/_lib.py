@@ -22,6 +22,7 @@ VAP_F64 = 1
 FLAG_DEGENERATE = 1
 FLAG_TRUNCATED = 2
 FLAG_NOCONVERGE = 4
+FLAG_BAD_ROUTE = 8
 T_FIT, T_LUT, T_SAMPLE, T_VELOCITY, T_TOTAL, T_COUNT = 0, 1, 2, 3, 4, 8
 OPT_VELOCITY_KERNEL = 0
 OPT_F32_RECURRENCE = 1
@@ -41,6 +42,7 @@ EXPORTS = (
     "vap_route_create", "vap_route_destroy", "vap_route_info", "vap_route_get_splines", "vap_route_eval",
     "vap_route_lookup", "vap_route_sample_count", "vap_route_forward_backward", "vap_route_motion_profile",
     "vap_grid_distances", "vap_route_limits", "vap_velocity_pass_limits", "vap_time_insert_waits", "vap_fit_ex",
+    "vap_profile_routes",
 )
 
 
@@ -113,6 +115,8 @@ def lib():
                                     C.POINTER(Constraints), C.c_double, C.c_double,
                                     vp, vp, vp, vp, vp, vp, vp]
     L.vap_profile_batch_host.argtypes = L.vap_profile_batch.argtypes
+    L.vap_profile_routes.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp, vp, vp, vp, vp,
+                                     C.POINTER(Constraints), C.c_double, C.c_double, vp, vp, vp, vp, vp, vp, vp, vp]
     L.vap_time_profile.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp,
                                    C.POINTER(Constraints), C.c_double, C.c_int, vp, vp, vp, vp]
     L.vap_route_limits.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int] + [vp] * 9 + [C.POINTER(Constraints), C.c_double] + [vp] * 6

@@ -106,6 +106,62 @@ class BatchedTrajectoryGenerator:
         self._last_shape = (B, W, S)
         return res
 
+    def profile_routes(self, waypoints, node_reverse=None, node_turn=None, node_tangent=None, node_magnitudes=None,
+                       constraints=DEFAULT_CONSTRAINTS, samples=None, dd=None, start_vel=START_VEL, end_vel=END_VEL,
+                       want=FIELDS, out=None, capacity=None):
+        """``profile`` for B routes whose reverse / turn nodes cut them into several splines (SM:42-172 for a whole
+        batch; vap_profile_routes).  Per-node attributes are (B, W) array-likes:
+          node_reverse (bool), node_turn (degrees), node_tangent (B, W, 2) with NaN rows for None and
+          node_magnitudes (B, W, 2) = [incoming, outgoing] for the nodes that have a tangent.
+        Returns the dict of ``profile`` plus "spline_counts" (B,) int32.  ``apply_node_limits`` works on the result
+        as for plain paths; the time domain of split routes goes through the drop-in classes."""
+        if (samples is None) == (dd is None):
+            raise ValueError("give exactly one of samples= or dd=")
+        wp = waypoints
+        if wp.device != self.device or wp.dtype != self.tdtype or wp.dim() != 3 or wp.shape[2] != 2:
+            raise ValueError(f"waypoints must be a (B,W,2) {self.tdtype} tensor on {self.device}")
+        wp = wp.contiguous()
+        B, W, _ = wp.shape
+        rev = np.zeros((B, W), dtype=np.int32) if node_reverse is None else np.asarray(node_reverse).astype(bool).astype(np.int32).reshape(B, W)
+        turn = np.zeros((B, W)) if node_turn is None else np.asarray(node_turn, dtype=np.float64).reshape(B, W)
+        split = ((rev != 0) | (turn != 0))[:, 1:W - 1] if W > 2 else np.zeros((B, 0), dtype=bool)
+        max_splines = int(1 + (split.sum(axis=1).max() if split.size else 0))
+        dev = self.device
+        d_rev = torch.tensor(rev, device=dev)
+        d_turn = torch.tensor(turn, device=dev)
+        d_tan = d_mag = None
+        if node_tangent is not None:
+            d_tan = torch.tensor(np.asarray(node_tangent, dtype=np.float64).reshape(B, W, 2), device=dev)
+            d_mag = torch.tensor(np.nan_to_num(np.asarray(node_magnitudes, dtype=np.float64)).reshape(B, W, 2), device=dev)
+        if samples is not None:
+            S, ddv = int(samples), 0.0
+        else:
+            ddv = float(dd)
+            S = int(capacity) if capacity is not None else int(np.ceil(64.0 / ddv)) + 2
+        c = _lib.make_constraints(constraints)
+        res = {} if out is None else out
+        for f in FIELDS:
+            if f in want or f == "velocity":
+                t = res.get(f)
+                if t is None or t.shape != (B, S) or t.dtype != self.tdtype:
+                    res[f] = torch.empty((B, S), dtype=self.tdtype, device=dev)
+        res["meta"] = torch.empty((B, 4), dtype=torch.float64, device=dev)
+        res["flags"] = torch.empty((B,), dtype=torch.int32, device=dev)
+        res["spline_counts"] = torch.empty((B,), dtype=torch.int32, device=dev)
+
+        def p(name):
+            t = res.get(name) if (name in want or name == "velocity") else None
+            return C.c_void_p(t.data_ptr()) if t is not None else None
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        self.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        st = self._L.vap_profile_routes(self.ctx.handle, self.vdtype, B, W, S, ddv, max_splines, ptr(wp), ptr(d_rev), ptr(d_turn),
+                                        ptr(d_tan), ptr(d_mag), C.byref(c), float(start_vel), float(end_vel), p("x"), p("y"),
+                                        p("heading"), p("curvature"), p("velocity"), ptr(res["meta"]), ptr(res["flags"]),
+                                        ptr(res["spline_counts"]))
+        _lib.check(st, "vap_profile_routes")
+        self._last_shape = (B, W, S)
+        return res
+
     def time_profile(self, result, constraints=DEFAULT_CONSTRAINTS, dt=0.01, capacity_rows=None, out=None):
         """Time-domain resample (the loop of generate_motion_profile, MPG:413-628) of the batch that
         ``profile`` has just produced with this generator: ``result`` is its return value (the

@@ -175,7 +175,7 @@ int vap_ctx_destroy(vap_ctx *ctx)
     if (!ctx) return VAP_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    VapBuffer *bufs[] = {&ctx->k64, &ctx->dth64, &ctx->ufwd, &ctx->lstate, &ctx->lcount, &ctx->seg, &ctx->power, &ctx->lut, &ctx->slopes, &ctx->aux, &ctx->runs, &ctx->meta, &ctx->dth, &ctx->flags, &ctx->small_in,
+    VapBuffer *bufs[] = {&ctx->sptab, &ctx->nspl, &ctx->k64, &ctx->dth64, &ctx->ufwd, &ctx->lstate, &ctx->lcount, &ctx->seg, &ctx->power, &ctx->lut, &ctx->slopes, &ctx->aux, &ctx->runs, &ctx->meta, &ctx->dth, &ctx->flags, &ctx->small_in,
                       &ctx->small_out, &ctx->small_seg, &ctx->small_lut};
     for (VapBuffer *b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
@@ -308,6 +308,7 @@ int vap_sample(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd, const
     ctx->rows_valid = hi;
     ctx->rows_hi = hi;
     ctx->rows_dt = dt;
+    ctx->route_NS = 0;
     return VAP_OK;
 }
 
@@ -435,6 +436,96 @@ int vap_profile_batch(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd
     ctx->rows_valid = true;
     ctx->rows_hi = hi;
     ctx->rows_dt = dt;
+    ctx->route_NS = 0;
+    return VAP_OK;
+}
+
+int vap_profile_routes(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd, int max_splines, const void *d_waypoints,
+                       const int *d_node_reverse, const double *d_node_turn, const double *d_node_tangent,
+                       const double *d_node_magnitudes, const vap_constraints *c, double start_vel, double end_vel,
+                       void *d_x, void *d_y, void *d_heading, void *d_curvature, void *d_velocity, double *d_meta,
+                       uint32_t *d_flags, int *d_spline_counts)
+{
+    VAP_TRY(vap_set_device(ctx));
+    VAP_TRY(check_shape(B, W, S));
+    if (!d_waypoints || !c || !d_velocity) return vap_fail(VAP_ERR_INVALID, "null buffer");
+    if (max_splines < 1 || max_splines > W - 1) return vap_fail(VAP_ERR_INVALID, "max_splines must be in [1, W-1] (got %d)", max_splines);
+    if (d_node_tangent && !d_node_magnitudes) return vap_fail(VAP_ERR_INVALID, "node tangents come with their magnitudes");
+    const bool f64 = dt == VAP_F64;
+    const int NS = max_splines;
+    const size_t n_seg = (size_t)B * (W - 1), n_pts = (size_t)B * S;
+    VAP_TRY(ctx->ensure(ctx->seg, n_seg * 12 * sizeof(double)));
+    VAP_TRY(ctx->ensure(ctx->power, n_seg * vap::kCoefBlockDoubles * sizeof(double)));
+    VAP_TRY(ctx->ensure(ctx->lut, (size_t)B * NS * VAP_LUT_SAMPLES * sizeof(double)));
+    VAP_TRY(ctx->ensure(ctx->sptab, (size_t)B * NS * 4 * sizeof(double)));
+    VAP_TRY(ctx->ensure(ctx->nspl, (size_t)B * sizeof(int)));
+    VAP_TRY(ctx->ensure(ctx->aux, (size_t)B * 4 * sizeof(double)));
+    VAP_TRY(ctx->ensure(ctx->runs, (size_t)B * vap::kGridRunBlockDoubles * sizeof(double)));
+    const bool hi = !f64 && ctx->f32_recurrence == VAP_RECURRENCE_F64;
+    if (hi) {
+        VAP_TRY(ctx->ensure(ctx->k64, n_pts * sizeof(double)));
+        VAP_TRY(ctx->ensure(ctx->dth64, n_pts * sizeof(double)));
+    } else {
+        VAP_TRY(ctx->ensure(ctx->dth, n_pts * esz(dt)));
+    }
+    double *meta = d_meta;
+    if (!meta) {
+        VAP_TRY(ctx->ensure(ctx->meta, (size_t)B * 4 * sizeof(double)));
+        meta = (double *)ctx->meta.ptr;
+    }
+    uint32_t *flags = d_flags;
+    if (!flags) {
+        VAP_TRY(ctx->ensure(ctx->flags, (size_t)B * sizeof(uint32_t)));
+        flags = (uint32_t *)ctx->flags.ptr;
+    }
+    void *curv = d_curvature;
+    if (!curv && !hi) {
+        VAP_TRY(ctx->ensure(ctx->io[7], n_pts * esz(dt)));
+        curv = ctx->io[7].ptr;
+    }
+    const double cc[6] = {c->max_vel, c->max_acc, c->max_acc, c->friction_coef, c->max_jerk, c->track_width};   // quirk Q9
+    vap::RouteSplitInputs in;
+    in.rev = d_node_reverse;
+    in.turn = d_node_turn;
+    in.tangent = d_node_tangent;
+    in.mag = d_node_magnitudes;
+    double *sptab = (double *)ctx->sptab.ptr;
+    int *nspl = (int *)ctx->nspl.ptr;
+    StageTimer tm(ctx);
+    HIP_TRY(vap::launch_fit_routes(ctx->stream, f64, B, W, NS, d_waypoints, in, (double *)ctx->seg.ptr, (double *)ctx->power.ptr,
+                                   nullptr, sptab, nspl, meta, flags));
+    tm.mark(VAP_T_FIT);
+    vap::RouteTables rt;
+    rt.sptab = sptab;
+    rt.nspl = nspl;
+    rt.NS = NS;
+    HIP_TRY(vap::launch_lut(ctx->stream, B, W, (const double *)ctx->seg.ptr, (double *)ctx->lut.ptr, nullptr, meta, flags,
+                            vap::GridArgs(), rt));
+    HIP_TRY(vap::launch_route_offsets(ctx->stream, B, W, NS, S, dd, (const double *)ctx->lut.ptr, sptab, nspl, meta,
+                                      (double *)ctx->aux.ptr, (double *)ctx->runs.ptr, flags));
+    tm.mark(VAP_T_LUT);
+    HIP_TRY(vap::launch_sample_routes(ctx->stream, f64, B, W, NS, S, (const double *)ctx->power.ptr, (const double *)ctx->lut.ptr,
+                                      sptab, nspl, meta, (const double *)ctx->aux.ptr, (const double *)ctx->runs.ptr, d_x, d_y,
+                                      d_heading, curv, hi ? nullptr : ctx->dth.ptr, hi ? (double *)ctx->k64.ptr : nullptr,
+                                      hi ? (double *)ctx->dth64.ptr : nullptr));
+    tm.mark(VAP_T_SAMPLE);
+    if (hi)
+        VAP_TRY(run_velocity(ctx, true, false, B, S, cc, start_vel, end_vel, meta, ctx->k64.ptr, ctx->dth64.ptr, nullptr,
+                             vap::AccRowsV(), d_velocity, flags));
+    else
+        VAP_TRY(run_velocity(ctx, f64, f64, B, S, cc, start_vel, end_vel, meta, curv, ctx->dth.ptr, nullptr, vap::AccRowsV(),
+                             d_velocity, flags));
+    tm.mark(VAP_T_VELOCITY);
+    if (d_spline_counts) HIP_TRY(hipMemcpyAsync(d_spline_counts, nspl, sizeof(int) * (size_t)B, hipMemcpyDeviceToDevice, ctx->stream));
+    ctx->last_B = B;
+    ctx->last_W = W;
+    ctx->grid_B = B;
+    ctx->grid_W = W;
+    ctx->grid_S = S;
+    ctx->rows_valid = true;
+    ctx->rows_hi = hi;
+    ctx->rows_dt = dt;
+    ctx->route_NS = NS;
     return VAP_OK;
 }
 
@@ -480,9 +571,16 @@ int vap_route_limits(vap_ctx *ctx, vap_dtype dt, int B, int W, int M, int S, con
     in.max_vel = c->max_vel;
     in.max_acc = c->max_acc;
     in.end_vel = end_vel;
+    vap::RouteTables rt;
+    if (ctx->route_NS > 0) {   // the batch on the context is one of routes cut into splines: its own tables only
+        if (d_lut) return vap_fail(VAP_ERR_INVALID, "a batch of routes (vap_profile_routes) is on the context: d_lut must be NULL");
+        rt.sptab = (const double *)ctx->sptab.ptr;
+        rt.nspl = (const int *)ctx->nspl.ptr;
+        rt.NS = ctx->route_NS;
+    }
     HIP_TRY(vap::launch_route_limits(ctx->stream, dt == VAP_F64, B, W, M, S, lut, d_meta, (const double *)ctx->aux.ptr,
                                      (const double *)ctx->runs.ptr, in, node_k, ap_k, ev_k, ev_mv, ev_ma, ev_stop, d_vcap,
-                                     d_acc_forward, d_acc_backward, d_dec_backward));
+                                     d_acc_forward, d_acc_backward, d_dec_backward, rt));
     if (d_node_sample) HIP_TRY(hipMemcpyAsync(d_node_sample, node_k, sizeof(int) * (size_t)B * W, hipMemcpyDeviceToDevice, ctx->stream));
     if (d_action_sample && M > 0)
         HIP_TRY(hipMemcpyAsync(d_action_sample, ap_k, sizeof(int) * (size_t)B * M, hipMemcpyDeviceToDevice, ctx->stream));
@@ -502,6 +600,9 @@ int vap_time_profile(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, const doub
         if (ctx->last_B != B || ctx->last_W != W || !ctx->seg.ptr || !ctx->lut.ptr)
             return vap_fail(VAP_ERR_UNFITTED, "no tables of a %d x %d batch in this context (last vap_profile_batch: %d x %d)", B,
                             W, ctx->last_B, ctx->last_W);
+        if (ctx->route_NS > 0)
+            return vap_fail(VAP_ERR_UNSUPPORTED, "the batch on the context is one of split routes (vap_profile_routes): their "
+                                                 "time domain goes through vap_route_motion_profile");
         d_segments = (const double *)ctx->seg.ptr;
         d_lut = (const double *)ctx->lut.ptr;
     }
@@ -528,6 +629,9 @@ int vap_time_insert_waits(vap_ctx *ctx, int B, int W, int M, int capacity_in, in
         if (ctx->last_B != B || ctx->last_W != W || !ctx->seg.ptr || !ctx->lut.ptr)
             return vap_fail(VAP_ERR_UNFITTED, "no tables of a %d x %d batch in this context (last vap_profile_batch: %d x %d)", B,
                             W, ctx->last_B, ctx->last_W);
+        if (ctx->route_NS > 0)
+            return vap_fail(VAP_ERR_UNSUPPORTED, "the batch on the context is one of split routes (vap_profile_routes): their "
+                                                 "time domain goes through vap_route_motion_profile");
         d_segments = (const double *)ctx->seg.ptr;
         d_lut = (const double *)ctx->lut.ptr;
     }

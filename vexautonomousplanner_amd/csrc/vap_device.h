@@ -203,6 +203,66 @@ __device__ __forceinline__ double distance_to_time(const double *__restrict__ D,
     return t0 + (t1 - t0) * (s - d0) / (d1 - d0);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Routes that reverse / turn nodes cut into several splines (SM:57-168): the lookup table is the concatenation of
+// the splines' 1000-entry tables with running offsets (SM:436-464), and a global parameter maps to the spline that
+// holds it, a split node belonging to the EARLIER spline (SM:243-275: t <= segment_end).  Segment i always joins
+// nodes i and i+1 (splines share their split node), so a spline is {first node, point count, parameters[-1]}.
+//   sp[s][4] = {parameters[-1] of spline s, distance offset, parameter offset, first node}      (kSplineStride)
+// A plain path is the case of one spline with zero offsets: adding 0.0 changes no bit, so the functions below give
+// the single-spline numbers (distance_to_time above) exactly.
+// ------------------------------------------------------------------------------------------------
+constexpr int kSplineStride = 4;
+struct LutView {
+    const double *D;     // [n_spl][1000] partial distances of each spline (SM:448-454)
+    const double *sp;    // [n_spl][kSplineStride]
+    int n_spl;
+    double total;        // lookup_table.total_length
+    double end_param;    // len(nodes) - 1
+};
+__device__ __forceinline__ double lutv_d(const LutView &v, int e)      // lookup_table.distances[e] (SM:457)
+{
+    const int s = e / kLutN, j = e - s * kLutN;
+    return v.D[(size_t)s * kLutN + j] + v.sp[s * kSplineStride + 1];
+}
+__device__ __forceinline__ double lutv_p(const LutView &v, int e)      // lookup_table.parameters[e] (SM:461)
+{
+    const int s = e / kLutN, j = e - s * kLutN;
+    return linspace_at(v.sp[s * kSplineStride + 0], kLutN, j) + v.sp[s * kSplineStride + 2];
+}
+// SM:291-318 distance_to_time on the concatenated table
+__device__ __forceinline__ double lutv_distance_to_time(const LutView &v, double s)
+{
+    if (s <= 0) return 0.0;
+    if (s >= v.total) return v.end_param;
+    int lo = 0, hi = v.n_spl * kLutN;
+#pragma unroll 1
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (lutv_d(v, mid) < s) lo = mid + 1;
+        else hi = mid;
+    }
+    if (lo == 0) return lutv_p(v, 0);
+    const double d0 = lutv_d(v, lo - 1), d1 = lutv_d(v, lo);
+    const double t0 = lutv_p(v, lo - 1), t1 = lutv_p(v, lo);
+    return t0 + (t1 - t0) * (s - d0) / (d1 - d0);
+}
+// SM:243-275 _map_parameter_to_spline + QHS:506-541 _normalize_parameter: global parameter -> (segment, local t)
+__device__ __forceinline__ void lutv_map_parameter(const LutView &v, int W, double t, int &seg, double &lt)
+{
+    int si = v.n_spl - 1;
+#pragma unroll 1
+    for (int i = 0; i < v.n_spl - 1; i++) {
+        const double end = v.sp[(i + 1) * kSplineStride + 3];     // this spline's last node = the next one's first
+        if (t <= end) { si = i; break; }
+    }
+    const int first = (int)v.sp[si * kSplineStride + 3];
+    const int last = si + 1 < v.n_spl ? (int)v.sp[(si + 1) * kSplineStride + 3] : W - 1;
+    int idx;
+    normalize_parameter(t - (double)first, v.sp[si * kSplineStride + 0], last - first, lt, idx);
+    seg = first + idx;
+}
+
 // SM:550-580 _interpolate_property reduced to what it always does (a step lookup):
 // returns the index into the linspace(0, W-1, 1000*W) property table that the reference reads for
 // parameter t.  tab_n = 1000*W, end_param = W-1.
@@ -920,5 +980,78 @@ __device__ __forceinline__ double clip(double x, double lo, double hi)
     const double m = x < lo ? lo : x;
     return m > hi ? hi : m;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Grid definition of one path (MPG:112-122 sample count, or this build's fixed-S grid) and the evaluations the
+// sampling kernels share.
+// ------------------------------------------------------------------------------------------------
+__device__ inline void grid_define(int b, int W, int S, double dd_in, double total, double t_max, double *__restrict__ meta,
+                            double *__restrict__ aux, double *__restrict__ runs, uint32_t *__restrict__ flags)
+{
+    double *tab = runs + (size_t)b * kGridRunDoubles;
+    double dd, n;
+    int n_runs = 1;
+    const bool usable = total > 0.0 && isfinite(total);
+    if (dd_in > 0) {
+        dd = dd_in;
+    } else {
+        dd = total / ((double)S - 1.5);
+    }
+    long n_loop = 1;
+    if (usable && dd > 0.0) {
+        // the reference's accumulated grid (current_dist += dd, MPG:112-122), exactly: vap_device.h
+        n_loop = build_grid_runs(dd, total, (long)S, tab, n_runs);
+    } else {
+        for (int j = 0; j < 5; j++) {     // one run that never moves, and the end markers
+            grid_run_set_k0(tab, j, j == 0 ? 0 : (long)S + 2);
+            tab[3 * j + 1] = 0.0;
+            tab[3 * j + 2] = 0.0;
+        }
+    }
+    if (dd_in > 0) {
+        long N = n_loop + 1;  // + appended end sample, MPG:172-175
+        if (N > S) {
+            N = S;
+            if (flags) atomicOr(&flags[b], 2u /* VAP_FLAG_TRUNCATED */);
+        }
+        n = (double)N;
+    } else {
+        n = (double)S;      // dd = total/(S-1.5): s_(S-2) < total <= s_(S-1) with half a step of margin
+    }
+    meta[(size_t)b * kMetaStride + 2] = dd;
+    meta[(size_t)b * kMetaStride + 3] = n;
+    const double tstep = (double)(W - 1) / (double)(W * kSamplesPerNode - 1);  // np.linspace step, SM:487
+    aux[(size_t)b * kAuxStride + 0] = t_max / (double)(kLutN - 1);             // SM:443
+    aux[(size_t)b * kAuxStride + 1] = tstep;
+    aux[(size_t)b * kAuxStride + 2] = 1.0 / tstep;
+    aux[(size_t)b * kAuxStride + 3] = (double)n_runs;
+}
+
+
+// the same for a route of several splines (the per-spline table steps live in its spline table)
+__device__ inline void grid_define_route(int b, int W, int S, double dd_in, double total, double *__restrict__ meta,
+                                         double *__restrict__ aux, double *__restrict__ runs, uint32_t *__restrict__ flags)
+{
+    grid_define(b, W, S, dd_in, total, meta[(size_t)b * kMetaStride + 0], meta, aux, runs, flags);
+}
+
+template <typename OT>
+__device__ __forceinline__ OT heading_of(double dy, double dx);
+template <>
+__device__ __forceinline__ float heading_of<float>(double dy, double dx) { return atan2_f32((float)dy, (float)dx); }
+template <>
+__device__ __forceinline__ double heading_of<double>(double dy, double dx) { return atan2(dy, dx); }
+
+// 1/sqrt(x)^3 * num without fp64 sqrt/div: hardware estimate + two Newton steps (~1e-16 relative)
+__device__ __forceinline__ double curvature_of(double num, double ss)
+{
+    double r = __builtin_amdgcn_rsq(ss);
+    r = r * fma(-0.5 * ss * r, r, 1.5);
+    r = r * fma(-0.5 * ss * r, r, 1.5);
+    return num * r * r * r;
+}
+template <typename OT>
+__device__ __forceinline__ OT heading_of_r(double dy, double dx) { return heading_of<OT>(dy, dx); }
+__device__ __forceinline__ double curvature_of_r(double num, double ss) { return curvature_of(num, ss); }
 
 }  // namespace vap

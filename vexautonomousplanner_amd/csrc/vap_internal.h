@@ -41,6 +41,8 @@ struct vap_ctx {
     VapBuffer seg, power, lut, slopes, aux, runs, meta, dth, flags, io[8], small_in, small_out, small_seg, small_lut;
     VapBuffer ufwd, lstate, lcount;   // long-row velocity pass
     VapBuffer k64, dth64;             // fp64 curvature / |dtheta| rows behind fp32 outputs (VAP_RECURRENCE_F64)
+    VapBuffer sptab, nspl;            // spline tables of the last vap_profile_routes batch
+    int route_NS = 0;                 // > 0: seg / lut hold a batch of routes with up to route_NS splines each
     int last_B = 0, last_W = 0;       // shape of the tables the last vap_profile_batch left in seg / lut
     int grid_B = 0, grid_W = 0, grid_S = 0;   // shape of the distance grids (aux, runs) the last sampling call left
     // rows the last sampling call left for a velocity pass with d_dtheta == NULL:

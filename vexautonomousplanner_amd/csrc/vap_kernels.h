@@ -18,6 +18,19 @@ constexpr int kGridRunBlockDoubles = 3 * 100;            // distance-grid runs p
 constexpr int kLdsCoefSegments = 112;                     // segments whose coefficient blocks are staged in LDS
 constexpr int kMaxWaypoints = 2048;              // k_fit LDS: 7*W doubles
 
+// Routes cut into several splines by reverse / turn nodes (vap_routes_batch.hip): the per-route spline table
+//   sptab [B][NS][4] = {parameters[-1], distance offset, parameter offset, first node}, nspl [B] = splines per route
+struct RouteTables {
+    const double *sptab = nullptr;
+    const int *nspl = nullptr;
+    int NS = 1;
+};
+struct RouteSplitInputs {
+    const int *rev = nullptr;         // [B][W] is_reverse_node
+    const double *turn = nullptr;     // [B][W] degrees
+    const double *tangent = nullptr;  // [B][W][2], NaN row = None
+    const double *mag = nullptr;      // [B][W][2] incoming, outgoing magnitude
+};
 hipError_t launch_fit(hipStream_t st, bool f64, int B, int W, const void *wp, const double *tin,
                       const double *tout, double *seg, double *pw, double *seglen, double *meta, uint32_t *flags,
                       const double *first = nullptr, const double *second = nullptr, const double *start_tan = nullptr,
@@ -31,7 +44,14 @@ struct GridArgs {
     double *runs = nullptr;
 };
 hipError_t launch_lut(hipStream_t st, int B, int W, const double *seg, double *lut, double *slopes, double *meta,
-                      uint32_t *flags, GridArgs grid = GridArgs());
+                      uint32_t *flags, GridArgs grid = GridArgs(), RouteTables rt = RouteTables());
+hipError_t launch_fit_routes(hipStream_t st, bool f64, int B, int W, int NS, const void *wp, const RouteSplitInputs &in, double *seg,
+                             double *pw, double *seglen, double *sptab, int *nspl, double *meta, uint32_t *flags);
+hipError_t launch_route_offsets(hipStream_t st, int B, int W, int NS, int S, double dd, const double *lut, double *sptab,
+                                const int *nspl, double *meta, double *aux, double *runs, uint32_t *flags);
+hipError_t launch_sample_routes(hipStream_t st, bool f64, int B, int W, int NS, int S, const double *pw, const double *lut,
+                                const double *sptab, const int *nspl, const double *meta, const double *aux, const double *runs,
+                                void *x, void *y, void *h, void *k, void *dth, double *k64, double *dth64);
 hipError_t launch_lut_slopes(hipStream_t st, int B, const double *lut, const double *meta, double *slopes);
 hipError_t launch_grid(hipStream_t st, int B, int W, int S, double dd, double *meta, double *aux, double *runs,
                        uint32_t *flags);
@@ -85,7 +105,7 @@ struct LimitInputs {
 hipError_t launch_route_limits(hipStream_t st, bool f64, int B, int W, int M, int S, const double *lut, const double *meta,
                                const double *aux, const double *runs, const LimitInputs &in, int *node_k, int *ap_k,
                                int *ev_k, double *ev_mv, double *ev_ma, int *ev_stop, void *vcap, void *acc_fwd,
-                               void *acc_bwd, void *dec_bwd);
+                               void *acc_bwd, void *dec_bwd, RouteTables rt = RouteTables());
 // waits of nodes / action points and actions_map on top of the rows of launch_time_profile (vap_time.hip)
 hipError_t launch_time_waits(hipStream_t st, int B, int W, int M, int cap_in, int cap_out, double dt, const double *segments,
                              const double *lut, const double *meta, const double *rows_in, const int *counts_in,

@@ -164,48 +164,6 @@ __global__ __launch_bounds__(256) void k_fit(int W, const IT *__restrict__ waypo
     if (tid == 0 && flags) flags[b] = s_flag;
 }
 
-__device__ void grid_define(int b, int W, int S, double dd_in, double total, double t_max, double *__restrict__ meta,
-                            double *__restrict__ aux, double *__restrict__ runs, uint32_t *__restrict__ flags)
-{
-    double *tab = runs + (size_t)b * kGridRunDoubles;
-    double dd, n;
-    int n_runs = 1;
-    const bool usable = total > 0.0 && isfinite(total);
-    if (dd_in > 0) {
-        dd = dd_in;
-    } else {
-        dd = total / ((double)S - 1.5);
-    }
-    long n_loop = 1;
-    if (usable && dd > 0.0) {
-        // the reference's accumulated grid (current_dist += dd, MPG:112-122), exactly: vap_device.h
-        n_loop = build_grid_runs(dd, total, (long)S, tab, n_runs);
-    } else {
-        for (int j = 0; j < 5; j++) {     // one run that never moves, and the end markers
-            grid_run_set_k0(tab, j, j == 0 ? 0 : (long)S + 2);
-            tab[3 * j + 1] = 0.0;
-            tab[3 * j + 2] = 0.0;
-        }
-    }
-    if (dd_in > 0) {
-        long N = n_loop + 1;  // + appended end sample, MPG:172-175
-        if (N > S) {
-            N = S;
-            if (flags) atomicOr(&flags[b], VAP_FLAG_TRUNCATED_BIT);
-        }
-        n = (double)N;
-    } else {
-        n = (double)S;      // dd = total/(S-1.5): s_(S-2) < total <= s_(S-1) with half a step of margin
-    }
-    meta[(size_t)b * kMetaStride + 2] = dd;
-    meta[(size_t)b * kMetaStride + 3] = n;
-    const double tstep = (double)(W - 1) / (double)(W * kSamplesPerNode - 1);  // np.linspace step, SM:487
-    aux[(size_t)b * kAuxStride + 0] = t_max / (double)(kLutN - 1);             // SM:443
-    aux[(size_t)b * kAuxStride + 1] = tstep;
-    aux[(size_t)b * kAuxStride + 2] = 1.0 / tstep;
-    aux[(size_t)b * kAuxStride + 3] = (double)n_runs;
-}
-
 __global__ void k_grid(int B, int W, int S, double dd_in, double *__restrict__ meta, double *__restrict__ aux,
                        double *__restrict__ runs, uint32_t *__restrict__ flags)
 {
@@ -219,11 +177,13 @@ __global__ void k_grid(int B, int W, int S, double dd_in, double *__restrict__ m
 // 1000 uniform-parameter samples of |P'(t)| (reference basis, reference order), trapezoid, and a
 // SEQUENTIAL cumulative sum (np.cumsum order) so the table is bit-identical to the reference's.
 // ------------------------------------------------------------------------------------------------
+// Routes cut into several splines (rt.sptab set): grid = (routes, spline slots); the workgroup builds the partial
+// (un-offset) table of one spline, SM:436-454, and k_route_offsets (vap_routes_batch.hip) does the rest.
 template <bool SEG_LDS>
 __global__ __launch_bounds__(256) void k_lut(int W, const double *__restrict__ segments,
                                              double *__restrict__ lut, double *__restrict__ slopes,
                                              double *__restrict__ meta, uint32_t *__restrict__ flags,
-                                             GridArgs grid, long long *__restrict__ stats)
+                                             GridArgs grid, RouteTables rt, long long *__restrict__ stats)
 {
     const long long tl0 = stats ? __builtin_amdgcn_s_memtime() : 0;
     extern __shared__ __attribute__((aligned(16))) double s_seg[];   // G * 12 when SEG_LDS
@@ -232,9 +192,22 @@ __global__ __launch_bounds__(256) void k_lut(int W, const double *__restrict__ s
     __shared__ __attribute__((aligned(16))) double cum[kPad];
     double *mag = cum;
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-    const int G = W - 1;
-    const double t_max = meta[(size_t)b * kMetaStride + 0];
-    const double *seg = segments + (size_t)b * G * 12;
+    int G = W - 1;
+    double t_max;
+    const double *seg = segments + (size_t)b * (W - 1) * 12;
+    size_t row = (size_t)b;                 // table row: the path, or (route, spline slot)
+    if (rt.sptab) {
+        const int sl = blockIdx.y, n = rt.nspl[b];
+        if (sl >= n) return;
+        const double *sp = rt.sptab + ((size_t)b * rt.NS + sl) * kSplineStride;
+        const int first = (int)sp[3], last = sl + 1 < n ? (int)sp[kSplineStride + 3] : W - 1;
+        G = last - first;
+        t_max = sp[0];
+        seg += (size_t)first * 12;
+        row = (size_t)b * rt.NS + sl;
+    } else {
+        t_max = meta[(size_t)b * kMetaStride + 0];
+    }
     if constexpr (SEG_LDS) {
         lds_fill<4>(s_seg, seg, G * 12, tid, nt);
         __syncthreads();
@@ -288,14 +261,14 @@ __global__ __launch_bounds__(256) void k_lut(int W, const double *__restrict__ s
 #pragma unroll
             for (int k = 0; k < 16; k++) { acc += v[k].x; acc += v[k].y; }
         }
-        meta[(size_t)b * kMetaStride + 1] = acc;   // elements past kLutN-1 are zero increments
+        if (!rt.sptab) meta[(size_t)b * kMetaStride + 1] = acc;   // elements past kLutN-1 are zero increments
         s_total = acc;
         if (flags && !(acc > 0.0 && isfinite(acc))) atomicOr(&flags[b], VAP_FLAG_DEGENERATE_BIT);
     }
     __syncthreads();
     // the fused call knows the grid spacing already: the last thread (a wave with nothing to do during the
     // replay below) defines the path's distance grid, which would otherwise be a launch of its own
-    if (grid.aux && tid == nt - 1) grid_define(b, W, grid.S, grid.dd, s_total, t_max, meta, grid.aux, grid.runs, flags);
+    if (grid.aux && !rt.sptab && tid == nt - 1) grid_define(b, W, grid.S, grid.dd, s_total, t_max, meta, grid.aux, grid.runs, flags);
     if (tid < kPad / 32) {
         double acc = s_start[tid];
         double2 *cum2 = reinterpret_cast<double2 *>(cum) + tid * 16;
@@ -316,7 +289,7 @@ __global__ __launch_bounds__(256) void k_lut(int W, const double *__restrict__ s
     const long long tl2 = stats ? __builtin_amdgcn_s_memtime() : 0;
     const double lstep = t_max / (double)(kLutN - 1);
     for (int j = tid; j < kLutN; j += nt) {
-        lut[(size_t)b * kLutN + j] = cum[j];
+        lut[row * kLutN + j] = cum[j];
         if (slopes) {
             // (t1 - t0)/(d1 - d0) of SM:311-317 for the interval ending at entry j
             double w = 0.0;
@@ -324,7 +297,7 @@ __global__ __launch_bounds__(256) void k_lut(int W, const double *__restrict__ s
                 const double t0 = (double)(j - 1) * lstep, t1 = (j == kLutN - 1) ? t_max : (double)j * lstep;
                 w = (t1 - t0) / (cum[j] - cum[j - 1]);
             }
-            slopes[(size_t)b * kLutN + j] = w;
+            slopes[row * kLutN + j] = w;
         }
     }
     if (stats && tid == 0) {
@@ -482,22 +455,6 @@ __global__ void k_lut_slopes(int B, const double *__restrict__ lut, const double
 // Arithmetic: parameter/index path, derivative evaluation and curvature in fp64 (DESIGN.md
 // §Numerics); no fp64 division on the per-sample path.
 // ------------------------------------------------------------------------------------------------
-template <typename OT>
-__device__ __forceinline__ OT heading_of(double dy, double dx);
-template <>
-__device__ __forceinline__ float heading_of<float>(double dy, double dx) { return atan2_f32((float)dy, (float)dx); }
-template <>
-__device__ __forceinline__ double heading_of<double>(double dy, double dx) { return atan2(dy, dx); }
-
-// 1/sqrt(x)^3 * num without fp64 sqrt/div: hardware estimate + two Newton steps (~1e-16 relative)
-__device__ __forceinline__ double curvature_of(double num, double ss)
-{
-    double r = __builtin_amdgcn_rsq(ss);
-    r = r * fma(-0.5 * ss * r, r, 1.5);
-    r = r * fma(-0.5 * ss * r, r, 1.5);
-    return num * r * r * r;
-}
-
 // HI (fp32 outputs only): also write the curvature and |dtheta| rows in fp64 (ok64, odth64) for the fp64
 // velocity recurrence behind fp32 outputs; the fp32 |dtheta| row is then optional (odth may be NULL).
 template <typename OT, bool COEF_LDS, bool HI>
@@ -2155,7 +2112,7 @@ hipError_t launch_fit(hipStream_t st, bool f64, int B, int W, const void *wp, co
 }
 
 hipError_t launch_lut(hipStream_t st, int B, int W, const double *seg, double *lut, double *slopes, double *meta,
-                      uint32_t *flags, GridArgs grid)
+                      uint32_t *flags, GridArgs grid, RouteTables rt)
 {
     static const bool want_stats = getenv("VAP_LUT_STATS") != nullptr;
     long long *stats = nullptr;
@@ -2163,15 +2120,16 @@ hipError_t launch_lut(hipStream_t st, int B, int W, const double *seg, double *l
     static const char *many_cfg = getenv("VAP_LUT_MANY");   // developer knob: 0 = never, 1 = always
     const int many = many_cfg ? atoi(many_cfg) : -1;
     // (the 64 paths' segment rows are staged in LDS: 6 KB per segment column, so short paths only)
-    if (!want_stats && W <= 9 && (many == 1 || (many != 0 && B >= 32768))) {
+    if (!want_stats && !rt.sptab && W <= 9 && (many == 1 || (many != 0 && B >= 32768))) {
         // very many paths: 64 per workgroup, the sequential sums of 64 paths in the lanes of one wavefront
         hipLaunchKernelGGL(k_lut_many, dim3((B + kLutManyPaths - 1) / kLutManyPaths), dim3(kLutManyThreads),
                            sizeof(double) * kLutManyPaths * (W - 1) * 12, st, B, W, seg, lut, slopes, meta, flags, grid);
         return hipGetLastError();
     }
     // 128 threads: the sequential sum keeps one lane busy, so residency (16 workgroups per CU) is what hides it
-    if (W - 1 <= 512) hipLaunchKernelGGL(k_lut<true>, dim3(B), dim3(128), sizeof(double) * 12 * (W - 1), st, W, seg, lut, slopes, meta, flags, grid, stats);
-    else hipLaunchKernelGGL(k_lut<false>, dim3(B), dim3(128), 0, st, W, seg, lut, slopes, meta, flags, grid, stats);
+    const dim3 lgrid(B, rt.sptab ? rt.NS : 1);
+    if (W - 1 <= 512) hipLaunchKernelGGL(k_lut<true>, lgrid, dim3(128), sizeof(double) * 12 * (W - 1), st, W, seg, lut, slopes, meta, flags, grid, rt, stats);
+    else hipLaunchKernelGGL(k_lut<false>, lgrid, dim3(128), 0, st, W, seg, lut, slopes, meta, flags, grid, rt, stats);
     if (stats) {
         std::vector<long long> h((size_t)B * 4);
         (void)hipStreamSynchronize(st);

@@ -16,7 +16,9 @@
 //                     an event with stop falls on the sample, end_vel at the end sample;
 //   k_limit_fill      also the per-sample max_acceleration rows the two sweeps see (boundary_map / max_accels,
 //                     MPG:194-196, 256-257) when the route changes max_acceleration.
-// Not covered here (single-route path only, vap_route_*): reverse / turn nodes, waits.
+// Routes cut into several splines by reverse / turn nodes go through the same kernels: forward_backward_pass treats
+// their nodes like any other (MPG:112-176), only distance_to_time runs over the concatenated table (LutView).
+// Waits and turns act in the time domain (vap_time.hip).
 #include "vap_device.h"
 #include "vap_kernels.h"
 
@@ -25,25 +27,31 @@ namespace vap {
 constexpr int kNever = 0x7fffffff;
 
 // first loop sample k (1 <= k <= N-2) whose parameter has reached T, or kNever
-__device__ int first_sample_reaching(double T, int W, const double *__restrict__ D, const double *__restrict__ m,
+__device__ int first_sample_reaching(double T, int W, const LutView &v, const double *__restrict__ m,
                                      const double *__restrict__ tab, int n_runs)
 {
-    const double t_max = m[0], total = m[1], dd = m[2];
+    const double total = m[1], dd = m[2];
     const int N = (int)m[3];
     const double end_param = (double)(W - 1);
     if (!(T > 0.0 && T < end_param && N >= 3 && total > 0.0 && dd > 0.0)) return kNever;
-    // where the table's parameter reaches T (its parameters are linspace(0, t_max, 1000), SM:443)
+    // where the table's parameter reaches T: the spline whose parameter range holds it (its parameters are
+    // linspace(0, parameters[-1], 1000) + offset, SM:443, 461) — a guess only, settled below
+    int si = v.n_spl - 1;
+    for (int i = 0; i < v.n_spl - 1; i++)
+        if (T <= v.sp[(i + 1) * kSplineStride + 2]) { si = i; break; }
+    const double t_max = v.sp[si * kSplineStride + 0], lt = T - v.sp[si * kSplineStride + 2];
+    const double *D = v.D + (size_t)si * kLutN;
     const double lstep = t_max / (double)(kLutN - 1);
-    int j = (int)floor(T / lstep);
+    int j = (int)floor(lt / lstep);
     j = j < 0 ? 0 : (j > kLutN - 2 ? kLutN - 2 : j);
     const double t0 = linspace_at(t_max, kLutN, j), t1 = linspace_at(t_max, kLutN, j + 1);
-    const double s_star = D[j] + (T - t0) / (t1 - t0) * (D[j + 1] - D[j]);
+    const double s_star = v.sp[si * kSplineStride + 1] + D[j] + (lt - t0) / (t1 - t0) * (D[j + 1] - D[j]);
     long k = (long)floor(s_star / dd);
     k = k < 1 ? 1 : (k > N - 2 ? N - 2 : k);
     // settle it with the reference's own parameter of the neighbouring samples
     auto t_of = [&](long kk) {
         int r = grid_run_hint(dd, kk, n_runs);
-        return distance_to_time(D, total, t_max, end_param, grid_s(tab, n_runs, kk, r));
+        return lutv_distance_to_time(v, grid_s(tab, n_runs, kk, r));
     };
     while (k > 1 && t_of(k - 1) >= T) k--;
     while (k <= N - 2 && t_of(k) < T) k++;
@@ -52,7 +60,7 @@ __device__ int first_sample_reaching(double T, int W, const double *__restrict__
 
 // One thread per (path, node 1..W-2 or action point): the sample at which it would take effect on its own.
 __global__ void k_event_samples(int B, int W, int M, const double *__restrict__ lut, const double *__restrict__ meta,
-                                const double *__restrict__ aux, const double *__restrict__ runs,
+                                const double *__restrict__ aux, const double *__restrict__ runs, RouteTables rt,
                                 const double *__restrict__ ap_t, int *__restrict__ node_k, int *__restrict__ ap_k)
 {
     const int per = W + M;
@@ -60,15 +68,22 @@ __global__ void k_event_samples(int B, int W, int M, const double *__restrict__ 
     if (i >= B * per) return;
     const int b = i / per, e = i - b * per;
     const double *m = meta + (size_t)b * kMetaStride;
-    const double *D = lut + (size_t)b * kLutN;
     const double *tab = runs + (size_t)b * kGridRunDoubles;
     const int n_runs = (int)aux[(size_t)b * kAuxStride + 3];
+    // the table: one spline with zero offsets for a plain path (bit for bit distance_to_time of SM:291-318 on it)
+    const double plain_sp[kSplineStride] = {m[0], 0.0, 0.0, 0.0};
+    LutView v;
+    v.D = lut + (size_t)b * rt.NS * kLutN;
+    v.sp = rt.sptab ? rt.sptab + (size_t)b * rt.NS * kSplineStride : plain_sp;
+    v.n_spl = rt.sptab ? rt.nspl[b] : 1;
+    v.total = m[1];
+    v.end_param = (double)(W - 1);
     if (e < W) {
         // node e: index 0 is the start (sample 0), the last node is never passed inside the loop (MPG:125)
-        node_k[(size_t)b * W + e] = e == 0 ? 0 : (e == W - 1 ? kNever : first_sample_reaching((double)e, W, D, m, tab, n_runs));
+        node_k[(size_t)b * W + e] = e == 0 ? 0 : (e == W - 1 ? kNever : first_sample_reaching((double)e, W, v, m, tab, n_runs));
     } else {
         const double T = ap_t[(size_t)b * M + (e - W)];
-        ap_k[(size_t)b * M + (e - W)] = (T == T && T != INFINITY) ? first_sample_reaching(T, W, D, m, tab, n_runs) : kNever;
+        ap_k[(size_t)b * M + (e - W)] = (T == T && T != INFINITY) ? first_sample_reaching(T, W, v, m, tab, n_runs) : kNever;
     }
 }
 
@@ -183,11 +198,11 @@ __global__ void k_limit_fill(int B, int W, int S, int E, const double *__restric
 hipError_t launch_route_limits(hipStream_t st, bool f64, int B, int W, int M, int S, const double *lut, const double *meta,
                                const double *aux, const double *runs, const LimitInputs &in, int *node_k, int *ap_k,
                                int *ev_k, double *ev_mv, double *ev_ma, int *ev_stop, void *vcap, void *acc_fwd,
-                               void *acc_bwd, void *dec_bwd)
+                               void *acc_bwd, void *dec_bwd, RouteTables rt)
 {
     const int E = (W > 2 ? W - 2 : 0) + M;
     const int per = W + M;
-    hipLaunchKernelGGL(k_event_samples, dim3((B * per + 127) / 128), dim3(128), 0, st, B, W, M, lut, meta, aux, runs, in.ap_t, node_k, ap_k);
+    hipLaunchKernelGGL(k_event_samples, dim3((B * per + 127) / 128), dim3(128), 0, st, B, W, M, lut, meta, aux, runs, rt, in.ap_t, node_k, ap_k);
     if (E > 0) hipLaunchKernelGGL(k_event_merge, dim3((B + 63) / 64), dim3(64), 0, st, B, W, M, in, node_k, ap_k, ev_k, ev_mv, ev_ma, ev_stop);
     const dim3 grid((unsigned)((S + 255) / 256 < 64 ? (S + 255) / 256 : 64), (unsigned)B);
     if (f64)
