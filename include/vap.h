@@ -256,6 +256,28 @@ int vap_time_insert_waits(vap_ctx *ctx, int B, int W, int M, int capacity_in, in
                           double *d_rows_out, int *d_counts_out, int *d_nodes_map_out, int *d_actions_map_out,
                           uint32_t *d_flags);
 
+/* vap_time_profile on the tables this context holds from its last vap_profile_batch / vap_profile_routes call, with
+ * the reversed state of routes (MPG:431-433, 540-541): d_node_reverse [B][W] int32 (NULL: none); rows made while an
+ * odd number of reverse nodes (node 0's flag included) has been passed carry heading - pi (before the wrap and the
+ * sign, MPG:555-563) and negated velocity and acceleration (MPG:587-589).  Rows as vap_time_profile. */
+int vap_time_profile_routes(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, const double *d_meta,
+                            const void *d_velocity, const vap_constraints *c, double time_step, int capacity_rows,
+                            const int *d_node_reverse, double *d_rows, int *d_counts, int *d_nodes_map,
+                            uint32_t *d_flags);
+
+/* vap_time_insert_waits plus in-place turns (MPG:487-507 handle_turn over MPG:319-346 motion_profile_angle and
+ * one_dim_mp_generator.py:4-69): a node with turn != 0 inserts, where it is passed and before its wait, the rows of a
+ * trapezoidal heading profile of max_vel / max_acc on an arc of |turn| * track_width / 2 (zero velocity, the last
+ * position and point, headings continuing from the last row, wrapped).  On the context's own tables (plain batch or
+ * routes).  d_node_turn [B][W] degrees, d_node_reverse [B][W] (only node 0's wait heading reads it, MPG:463-464);
+ * either may be NULL.  A turn at node 0 raises in the reference (quirk Q4): VAP_FLAG_BAD_ROUTE. */
+int vap_time_insert_events(vap_ctx *ctx, int B, int W, int M, int capacity_in, int capacity_out, double time_step,
+                           const vap_constraints *c, const double *d_meta, const double *d_rows_in,
+                           const int *d_counts_in, const int *d_nodes_map_in, const double *d_node_wait,
+                           const double *d_node_turn, const int *d_node_reverse, const double *d_action_t,
+                           const double *d_action_wait, double *d_rows_out, int *d_counts_out, int *d_nodes_map_out,
+                           int *d_actions_map_out, uint32_t *d_flags);
+
 /* ---- fused hot path ------------------------------------------------------------------------ */
 
 /* rebuild_tables (SM:582-594) + forward_backward_pass (MPG:70-316) for B plain-node paths, inputs
@@ -279,7 +301,7 @@ int vap_profile_batch(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd
  * A route with a reverse / turn attribute on its LAST node (IndexError in the reference, SM:97) or with more
  * splines than max_splines is flagged VAP_FLAG_BAD_ROUTE; its rows are undefined.  Afterwards the context holds the
  * batch's tables: vap_route_limits + vap_velocity_pass_limits apply node / action-point limits as for plain paths.
- * The time domain of split routes (in-place turns, reversed rows) is vap_route_motion_profile's. */
+ * The time domain of such a batch: vap_time_profile_routes, vap_time_insert_events. */
 #define VAP_FLAG_BAD_ROUTE 8u
 int vap_profile_routes(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd, int max_splines,
                        const void *d_waypoints, const int *d_node_reverse, const double *d_node_turn,

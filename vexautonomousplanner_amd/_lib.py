@@ -42,7 +42,7 @@ EXPORTS = (
     "vap_route_create", "vap_route_destroy", "vap_route_info", "vap_route_get_splines", "vap_route_eval",
     "vap_route_lookup", "vap_route_sample_count", "vap_route_forward_backward", "vap_route_motion_profile",
     "vap_grid_distances", "vap_route_limits", "vap_velocity_pass_limits", "vap_time_insert_waits", "vap_fit_ex",
-    "vap_profile_routes",
+    "vap_profile_routes", "vap_time_profile_routes", "vap_time_insert_events",
 )
 
 
@@ -123,6 +123,9 @@ def lib():
     L.vap_velocity_pass_limits.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(Constraints), C.c_double, C.c_double,
                                            vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.vap_time_insert_waits.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double] + [vp] * 14
+    L.vap_time_profile_routes.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.POINTER(Constraints), C.c_double,
+                                          C.c_int, vp, vp, vp, vp, vp]
+    L.vap_time_insert_events.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(Constraints)] + [vp] * 14
     L.vap_eval_host.argtypes = [vp, C.c_int, dp, C.c_double, C.c_int, C.c_int, dp, dp]
     L.vap_lookup_host.argtypes = [vp, C.c_int, dp, C.c_double, dp, C.c_int, C.c_int, dp, dp]
     lp = C.POINTER(C.c_long)

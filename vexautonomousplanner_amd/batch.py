@@ -162,7 +162,7 @@ class BatchedTrajectoryGenerator:
         self._last_shape = (B, W, S)
         return res
 
-    def time_profile(self, result, constraints=DEFAULT_CONSTRAINTS, dt=0.01, capacity_rows=None, out=None):
+    def time_profile(self, result, constraints=DEFAULT_CONSTRAINTS, dt=0.01, capacity_rows=None, out=None, node_reverse=None):
         """Time-domain resample (the loop of generate_motion_profile, MPG:413-628) of the batch that
         ``profile`` has just produced with this generator: ``result`` is its return value (the
         velocity rows and meta are read from it, the spline tables from the context).
@@ -173,6 +173,8 @@ class BatchedTrajectoryGenerator:
           counts    (B, 2) int32: rows written, entries of nodes_map
           nodes_map (B, W) int32: row index at which each node is passed (MPG:420, 527-529)
         Paths that need more than capacity_rows rows are cut there and flagged (result["flags"]).
+        ``node_reverse`` (B, W): the is_reverse_node flags of routes (``profile_routes``): rows behind an odd number of
+        them are reversed (heading - pi, negated velocity / acceleration; MPG:431-433, 540-541, 555, 587-589).
         """
         vel, meta = result["velocity"], result["meta"]
         B, S = vel.shape
@@ -191,12 +193,15 @@ class BatchedTrajectoryGenerator:
             res["nodes_map"] = torch.empty((B, W), dtype=torch.int32, device=self.device)
         c = _lib.make_constraints(constraints)
         self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
-        st = self._L.vap_time_profile(self.ctx.handle, self.vdtype, B, W, S, None, None,
-                                      C.c_void_p(meta.data_ptr()), C.c_void_p(vel.data_ptr()), C.byref(c),
-                                      float(dt), int(capacity_rows), C.c_void_p(res["rows"].data_ptr()),
-                                      C.c_void_p(res["counts"].data_ptr()), C.c_void_p(res["nodes_map"].data_ptr()),
-                                      C.c_void_p(result["flags"].data_ptr()))
-        _lib.check(st, "vap_time_profile")
+        d_rev = None
+        if node_reverse is not None:
+            d_rev = torch.tensor(np.asarray(node_reverse).astype(bool).astype(np.int32).reshape(B, W), device=self.device)
+        st = self._L.vap_time_profile_routes(self.ctx.handle, self.vdtype, B, W, S, C.c_void_p(meta.data_ptr()),
+                                             C.c_void_p(vel.data_ptr()), C.byref(c), float(dt), int(capacity_rows),
+                                             C.c_void_p(d_rev.data_ptr()) if d_rev is not None else None,
+                                             C.c_void_p(res["rows"].data_ptr()), C.c_void_p(res["counts"].data_ptr()),
+                                             C.c_void_p(res["nodes_map"].data_ptr()), C.c_void_p(result["flags"].data_ptr()))
+        _lib.check(st, "vap_time_profile_routes")
         return res
 
     def apply_node_limits(self, result, constraints=DEFAULT_CONSTRAINTS, node_max_velocity=None, node_stop=None,
@@ -264,12 +269,15 @@ class BatchedTrajectoryGenerator:
         result["action_sample"] = ap_k[:, :M]
         return result
 
-    def insert_waits(self, result, tp, node_wait_time=None, action_points=None, dt=0.01, capacity_rows=None):
+    def insert_waits(self, result, tp, node_wait_time=None, action_points=None, dt=0.01, capacity_rows=None,
+                     node_turn=None, node_reverse=None, constraints=DEFAULT_CONSTRAINTS):
         """Waits of nodes / action points and ``actions_map`` on top of ``tp = time_profile(result, ...)``
         (MPG:457-476, 509-518, 543-553): returns a new dict with
           rows (B, capacity_rows, 8), counts (B, 3) int32 [rows, nodes_map entries, actions_map entries],
           nodes_map (B, W), actions_map (B, M) int32.
-        ``action_points``: list (per path) of lists of dicts {"t", "wait_time"} in route order."""
+        ``action_points``: list (per path) of lists of dicts {"t", "wait_time"} in route order.
+        ``node_turn`` (B, W) degrees: in-place turns (MPG:487-507) inserted where the node is passed, before its wait, with
+        the trapezoid of ``constraints``; ``node_reverse`` (B, W): only the heading of a wait at node 0 reads it."""
         rows_in, counts_in, nodes_in = tp["rows"], tp["counts"], tp["nodes_map"]
         B, cap_in, _ = rows_in.shape
         W = nodes_in.shape[1]
@@ -284,6 +292,17 @@ class BatchedTrajectoryGenerator:
                 ap_t[b, i] = float(a["t"])
                 ap_w[b, i] = float(a.get("wait_time", 0.0))
         extra = int(np.max(np.floor(wait / dt).sum(axis=1) + np.floor(ap_w / dt).sum(axis=1))) + 1
+        c = _lib.make_constraints(constraints)
+        d_turn = d_rev = None
+        if node_turn is not None:
+            turn = np.asarray(node_turn, dtype=np.float64).reshape(B, W)
+            d_turn = torch.tensor(turn, device=dev)
+            # rows of a turn: the trapezoid's duration / dt + 1 (one_dim_mp_generator.py:4-69), bounded generously
+            arc = np.abs(np.radians(turn)) * c.track_width / 2
+            dur = 2 * c.max_vel / c.max_acc + arc / c.max_vel
+            extra += int(np.max(np.where(turn != 0, np.ceil(dur / dt) + 3, 0).sum(axis=1)))
+        if node_reverse is not None:
+            d_rev = torch.tensor(np.asarray(node_reverse).astype(bool).astype(np.int32).reshape(B, W), device=dev)
         cap_out = int(capacity_rows) if capacity_rows is not None else cap_in + extra
         out = {"rows": torch.empty((B, cap_out, 8), dtype=torch.float64, device=dev),
                "counts": torch.zeros((B, 3), dtype=torch.int32, device=dev),
@@ -292,12 +311,13 @@ class BatchedTrajectoryGenerator:
         d_wait = torch.tensor(wait, device=dev)
         d_apt = torch.tensor(ap_t, device=dev)
         d_apw = torch.tensor(ap_w, device=dev)
-        ptr = lambda t: C.c_void_p(t.data_ptr())
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         self.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-        _lib.check(self._L.vap_time_insert_waits(self.ctx.handle, B, W, M, cap_in, cap_out, float(dt), None, None,
-                                                 ptr(result["meta"]), ptr(rows_in), ptr(counts_in), ptr(nodes_in), ptr(d_wait),
-                                                 ptr(d_apt), ptr(d_apw), ptr(out["rows"]), ptr(out["counts"]), ptr(out["nodes_map"]),
-                                                 ptr(out["actions_map"]), ptr(result["flags"])), "vap_time_insert_waits")
+        _lib.check(self._L.vap_time_insert_events(self.ctx.handle, B, W, M, cap_in, cap_out, float(dt), C.byref(c),
+                                                  ptr(result["meta"]), ptr(rows_in), ptr(counts_in), ptr(nodes_in), ptr(d_wait),
+                                                  ptr(d_turn), ptr(d_rev), ptr(d_apt), ptr(d_apw), ptr(out["rows"]), ptr(out["counts"]),
+                                                  ptr(out["nodes_map"]), ptr(out["actions_map"]), ptr(result["flags"])),
+                   "vap_time_insert_events")
         out["actions_map"] = out["actions_map"][:, :M]
         return out
 

@@ -602,7 +602,7 @@ int vap_time_profile(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, const doub
                             W, ctx->last_B, ctx->last_W);
         if (ctx->route_NS > 0)
             return vap_fail(VAP_ERR_UNSUPPORTED, "the batch on the context is one of split routes (vap_profile_routes): their "
-                                                 "time domain goes through vap_route_motion_profile");
+                                                 "time domain goes through vap_time_profile_routes / vap_time_insert_events");
         d_segments = (const double *)ctx->seg.ptr;
         d_lut = (const double *)ctx->lut.ptr;
     }
@@ -631,13 +631,67 @@ int vap_time_insert_waits(vap_ctx *ctx, int B, int W, int M, int capacity_in, in
                             W, ctx->last_B, ctx->last_W);
         if (ctx->route_NS > 0)
             return vap_fail(VAP_ERR_UNSUPPORTED, "the batch on the context is one of split routes (vap_profile_routes): their "
-                                                 "time domain goes through vap_route_motion_profile");
+                                                 "time domain goes through vap_time_profile_routes / vap_time_insert_events");
         d_segments = (const double *)ctx->seg.ptr;
         d_lut = (const double *)ctx->lut.ptr;
     }
     HIP_TRY(vap::launch_time_waits(ctx->stream, B, W, M, capacity_in, capacity_out, time_step, d_segments, d_lut, d_meta,
                                    d_rows_in, d_counts_in, d_nodes_map_in, d_node_wait, d_action_t, d_action_wait, d_rows_out,
                                    d_counts_out, d_nodes_map_out, d_actions_map_out, d_flags));
+    return VAP_OK;
+}
+
+int vap_time_profile_routes(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, const double *d_meta, const void *d_velocity,
+                            const vap_constraints *c, double time_step, int capacity_rows, const int *d_node_reverse,
+                            double *d_rows, int *d_counts, int *d_nodes_map, uint32_t *d_flags)
+{
+    VAP_TRY(vap_set_device(ctx));
+    VAP_TRY(check_shape(B, W, S));
+    if (!d_meta || !d_velocity || !c || !d_rows || !d_counts || !d_nodes_map) return vap_fail(VAP_ERR_INVALID, "null buffer");
+    if (!(time_step > 0) || capacity_rows < 1) return vap_fail(VAP_ERR_INVALID, "time_step and capacity_rows must be positive");
+    if (ctx->last_B != B || ctx->last_W != W || !ctx->seg.ptr || !ctx->lut.ptr)
+        return vap_fail(VAP_ERR_UNFITTED, "no tables of a %d x %d batch in this context (last profile call: %d x %d)", B, W,
+                        ctx->last_B, ctx->last_W);
+    vap::RouteTables rt;
+    if (ctx->route_NS > 0) {
+        rt.sptab = (const double *)ctx->sptab.ptr;
+        rt.nspl = (const int *)ctx->nspl.ptr;
+        rt.NS = ctx->route_NS;
+    }
+    HIP_TRY(vap::launch_time_profile(ctx->stream, dt == VAP_F64, B, W, S, (const double *)ctx->seg.ptr, (const double *)ctx->lut.ptr,
+                                     d_meta, d_velocity, c->max_acc, c->max_dec, time_step, capacity_rows, d_rows, d_counts,
+                                     d_nodes_map, d_flags, rt, d_node_reverse));
+    return VAP_OK;
+}
+
+int vap_time_insert_events(vap_ctx *ctx, int B, int W, int M, int capacity_in, int capacity_out, double time_step,
+                           const vap_constraints *c, const double *d_meta, const double *d_rows_in, const int *d_counts_in,
+                           const int *d_nodes_map_in, const double *d_node_wait, const double *d_node_turn,
+                           const int *d_node_reverse, const double *d_action_t, const double *d_action_wait, double *d_rows_out,
+                           int *d_counts_out, int *d_nodes_map_out, int *d_actions_map_out, uint32_t *d_flags)
+{
+    VAP_TRY(vap_set_device(ctx));
+    VAP_TRY(check_shape(B, W, 2));
+    if (M < 0 || capacity_in < 1 || capacity_out < 1 || !(time_step > 0) || !c) return vap_fail(VAP_ERR_INVALID, "bad argument");
+    if (!d_meta || !d_rows_in || !d_counts_in || !d_nodes_map_in || !d_rows_out || !d_counts_out || !d_nodes_map_out)
+        return vap_fail(VAP_ERR_INVALID, "null buffer");
+    if (M > 0 && (!d_action_t || !d_actions_map_out)) return vap_fail(VAP_ERR_INVALID, "null action-point array");
+    if (d_rows_out == d_rows_in) return vap_fail(VAP_ERR_INVALID, "the rows move: d_rows_out must not be d_rows_in");
+    if (d_node_turn && !(c->max_vel > 0 && c->max_acc > 0 && c->track_width > 0))
+        return vap_fail(VAP_ERR_INVALID, "in-place turns need max_vel, max_acc and track_width");
+    if (ctx->last_B != B || ctx->last_W != W || !ctx->seg.ptr || !ctx->lut.ptr)
+        return vap_fail(VAP_ERR_UNFITTED, "no tables of a %d x %d batch in this context (last profile call: %d x %d)", B, W,
+                        ctx->last_B, ctx->last_W);
+    vap::RouteTables rt;
+    if (ctx->route_NS > 0) {
+        rt.sptab = (const double *)ctx->sptab.ptr;
+        rt.nspl = (const int *)ctx->nspl.ptr;
+        rt.NS = ctx->route_NS;
+    }
+    HIP_TRY(vap::launch_time_waits(ctx->stream, B, W, M, capacity_in, capacity_out, time_step, (const double *)ctx->seg.ptr,
+                                   (const double *)ctx->lut.ptr, d_meta, d_rows_in, d_counts_in, d_nodes_map_in, d_node_wait,
+                                   d_action_t, d_action_wait, d_rows_out, d_counts_out, d_nodes_map_out, d_actions_map_out, d_flags, rt,
+                                   d_node_turn, d_node_reverse, c->max_vel, c->max_acc, c->track_width));
     return VAP_OK;
 }
 

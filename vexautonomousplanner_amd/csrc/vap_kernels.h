@@ -92,7 +92,8 @@ hipError_t launch_velocity_windows(hipStream_t st, int B, int S, const double c[
 hipError_t launch_power(hipStream_t st, int n_seg, const double *seg, double *pw);
 hipError_t launch_time_profile(hipStream_t st, bool f64, int B, int W, int S, const double *segments, const double *lut,
                                const double *meta, const void *vel, double max_acc, double max_dec, double dt, int cap,
-                               double *rows, int *counts, int *nodes_map, uint32_t *flags);
+                               double *rows, int *counts, int *nodes_map, uint32_t *flags, RouteTables rt = RouteTables(),
+                               const int *node_reverse = nullptr);
 // vap_limits.hip: sample of every event (node / action point), then the per-sample limit rows
 struct LimitInputs {
     const double *node_mv = nullptr, *node_ma = nullptr;   // [B][W] per-node max_velocity / max_acceleration (<= 0: none)
@@ -110,7 +111,9 @@ hipError_t launch_route_limits(hipStream_t st, bool f64, int B, int W, int M, in
 hipError_t launch_time_waits(hipStream_t st, int B, int W, int M, int cap_in, int cap_out, double dt, const double *segments,
                              const double *lut, const double *meta, const double *rows_in, const int *counts_in,
                              const int *nodes_in, const double *node_wait, const double *ap_t, const double *ap_wait,
-                             double *rows_out, int *counts_out, int *nodes_out, int *actions_out, uint32_t *flags);
+                             double *rows_out, int *counts_out, int *nodes_out, int *actions_out, uint32_t *flags,
+                             RouteTables rt = RouteTables(), const double *node_turn = nullptr, const int *node_reverse = nullptr,
+                             double max_vel = 0, double max_acc = 0, double track_width = 0);
 hipError_t launch_eval(hipStream_t st, int W, const double *seg, double t_max, int order, int n, const double *t,
                        double *out);
 hipError_t launch_lookup(hipStream_t st, int W, const double *seg, double t_max, const double *lut, int what,

@@ -1,6 +1,6 @@
 // vap_time.hip — batched time-domain resample: the loop of generate_motion_profile that follows
-// forward_backward_pass (MPG:413-628), for B plain-node paths (no turn / wait / reverse nodes, no
-// action points — those insert rows and are served by the single-route kernel in vap_route.hip).
+// forward_backward_pass (MPG:413-628), for B paths or routes at once.  Rows that nodes and action points insert
+// (waits, in-place turns) and the reversed state are applied on top of the kinematic rows (k_time_waits).
 //
 // The reference's loop is sequential in current_pos, but only its kinematic half is: the position
 // and velocity of a time step depend on the previous step and on the distance-domain velocity row
@@ -75,15 +75,34 @@ __global__ __launch_bounds__(64) void k_time_integrate(int B, int S, const doubl
     if (full && flags) atomicOr(&flags[b], VAP_FLAG_TRUNCATED_BIT);
 }
 
+// point / derivative / second derivative on ONE segment at its local parameter (the sum of QHS:221-251 / 473-504)
+__device__ __forceinline__ void hermite_eval_seg(const double *__restrict__ sg, int order, double lt, double &ox, double &oy)
+{
+    double H[6];
+    hermite_basis_ref(order, lt, H);
+    double ax = 0.0, ay = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        ax += H[i] * sg[2 * i];
+        ay += H[i] * sg[2 * i + 1];
+    }
+    ox = ax;
+    oy = ay;
+}
+
 // One workgroup per path.  LDS: the path's distance table (8 KB) and, when they fit, its segment rows.
-template <bool SEG_LDS>
+// ROUTES: the batch is one of routes cut into several splines (vap_profile_routes): the concatenated table and the
+// parameter -> spline mapping come from the route tables (LutView), and rows behind an odd number of reverse nodes
+// are "reversed" — heading - pi before the wrap, velocity and acceleration negated (MPG:431-433, 540-541, 555, 587-589).
+template <bool SEG_LDS, bool ROUTES>
 __global__ __launch_bounds__(256) void k_time_geometry(int W, int cap, const double *__restrict__ segments,
                                                        const double *__restrict__ lut,
-                                                       const double *__restrict__ meta, double *__restrict__ rows,
+                                                       const double *__restrict__ meta, RouteTables rt,
+                                                       const int *__restrict__ node_reverse, double *__restrict__ rows,
                                                        int *__restrict__ counts, int *__restrict__ nodes_map)
 {
     extern __shared__ __attribute__((aligned(16))) double s_seg[];   // G * 12 when SEG_LDS
-    __shared__ double sD[kLutN];
+    __shared__ double sD[ROUTES ? 1 : kLutN];
     __shared__ int s_wave[4], s_base;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int G = W - 1;
@@ -91,42 +110,49 @@ __global__ __launch_bounds__(256) void k_time_geometry(int W, int cap, const dou
     const double t_max = m[0], total = m[1];
     const int T = counts[2 * b];
     const double *seg = segments + (size_t)b * G * 12;
-    lds_fill<4>(sD, lut + (size_t)b * kLutN, kLutN, tid, 256);
+    if constexpr (!ROUTES) lds_fill<4>(sD, lut + (size_t)b * kLutN, kLutN, tid, 256);
     if constexpr (SEG_LDS) lds_fill<4>(s_seg, seg, G * 12, tid, 256);
     if (tid == 0) { s_base = 1; nodes_map[(size_t)b * W] = 0; }   // MPG:420: the first node maps to row 0
     __syncthreads();
     if constexpr (SEG_LDS) seg = s_seg;
     const double end_param = (double)(W - 1);
     const int tab_n = W * kSamplesPerNode;
+    LutView v;
+    if constexpr (ROUTES) {
+        v.D = lut + (size_t)b * rt.NS * kLutN;
+        v.sp = rt.sptab + (size_t)b * rt.NS * kSplineStride;
+        v.n_spl = rt.nspl[b];
+        v.total = total;
+        v.end_param = end_param;
+    }
+    auto d2t = [&](double pos) {
+        if constexpr (ROUTES) return lutv_distance_to_time(v, pos);
+        else return distance_to_time(sD, total, t_max, end_param, pos);
+    };
+    auto eval = [&](int order, double t, double &ox, double &oy) {
+        if constexpr (ROUTES) {
+            int sg;
+            double lt;
+            lutv_map_parameter(v, W, t, sg, lt);
+            hermite_eval_seg(seg + (size_t)sg * 12, order, lt, ox, oy);
+        } else {
+            hermite_eval_ref(seg, t_max, G, order, t, ox, oy);
+        }
+    };
+    const int *rev = node_reverse ? node_reverse + (size_t)b * W : nullptr;
     double *out = rows + (size_t)b * cap * kRowWidth;
     for (int r0 = 0; r0 < T; r0 += 256) {
         const int i = r0 + tid;
         bool crossing = false;
+        double t = 0.0;
         if (i < T) {
-            double *q = out + (size_t)i * kRowWidth;
+            const double *q = out + (size_t)i * kRowWidth;
             // the row was produced from the position BEFORE its own update: the previous row's
             const double pos = i == 0 ? 0.0 : q[1 - kRowWidth];
-            const double t = distance_to_time(sD, total, t_max, end_param, pos);              // MPG:525
+            t = d2t(pos);                                                                     // MPG:525
             double prev_t = 0.0;                                                              // MPG:521
-            if (i > 0) prev_t = distance_to_time(sD, total, t_max, end_param, i == 1 ? 0.0 : q[1 - 2 * kRowWidth]);
+            if (i > 0) prev_t = d2t(i == 1 ? 0.0 : q[1 - 2 * kRowWidth]);
             crossing = mod1(t) < mod1(prev_t) && t < end_param;                               // MPG:527
-            // SM:332-346, 550-580: step lookup into the (never materialised) property table
-            const int jj = table_index(t, tab_n, end_param);
-            const double tp = linspace_at(end_param, tab_n, jj);
-            double d1x, d1y, d2x, d2y, px, py;
-            hermite_eval_ref(seg, t_max, G, 1, tp, d1x, d1y);
-            hermite_eval_ref(seg, t_max, G, 2, tp, d2x, d2y);
-            const double ss = d1x * d1x + d1y * d1y;
-            const double num = d1x * d2y - d1y * d2x;
-            const double curvature = (ss >= 1e-10) ? num / (ss * sqrt(ss)) : 0.0;             // SM:517-527
-            double heading = atan2(d1y, d1x);                                                 // SM:536
-            heading = py_mod(heading + M_PI, 2 * M_PI) - M_PI;                                // MPG:559-563
-            heading *= -1;
-            hermite_eval_ref(seg, t_max, G, 0, t, px, py);                                    // MPG:565
-            q[4] = heading;
-            q[5] = q[5] * curvature * -1;                                                     // MPG:575
-            q[6] = px;
-            q[7] = py;
         }
         // ordered compaction of the crossings of these 256 rows into nodes_map (MPG:528-529)
         const unsigned long long bal = __ballot(crossing);
@@ -134,9 +160,36 @@ __global__ __launch_bounds__(256) void k_time_geometry(int W, int cap, const dou
         __syncthreads();
         int before = s_base;
         for (int w = 0; w < (tid >> 6); w++) before += s_wave[w];
-        if (crossing) {
-            const int k = before + __popcll(bal & ((1ull << (tid & 63)) - 1ull));
-            if (k < W) nodes_map[(size_t)b * W + k] = i;
+        const int k_self = before + __popcll(bal & ((1ull << (tid & 63)) - 1ull));   // nodes_map slot if this row crosses
+        if (crossing && k_self < W) nodes_map[(size_t)b * W + k_self] = i;
+        if (i < T) {
+            double *q = out + (size_t)i * kRowWidth;
+            // the node the robot has passed when this row is made (the crossing is handled first, MPG:527-541), and
+            // with it the reversed state: node 0's flag and every passed node's toggle it
+            bool reversed = false;
+            if (rev) {
+                int node_idx = k_self - 1 + (crossing ? 1 : 0);
+                node_idx = node_idx > W - 1 ? W - 1 : node_idx;
+                for (int n = 0; n <= node_idx; n++) reversed ^= rev[n] != 0;
+            }
+            // SM:332-346, 550-580: step lookup into the (never materialised) property table
+            const int jj = table_index(t, tab_n, end_param);
+            const double tp = linspace_at(end_param, tab_n, jj);
+            double d1x, d1y, d2x, d2y, px, py;
+            eval(1, tp, d1x, d1y);
+            eval(2, tp, d2x, d2y);
+            const double ss = d1x * d1x + d1y * d1y;
+            const double num = d1x * d2y - d1y * d2x;
+            const double curvature = (ss >= 1e-10) ? num / (ss * sqrt(ss)) : 0.0;             // SM:517-527
+            double heading = atan2(d1y, d1x) - (reversed ? M_PI : 0);                         // SM:536, MPG:555
+            heading = py_mod(heading + M_PI, 2 * M_PI) - M_PI;                                // MPG:559-563
+            heading *= -1;
+            eval(0, t, px, py);                                                               // MPG:565
+            if (reversed) { q[2] = q[2] * -1; q[3] = q[3] * -1; }                             // MPG:587, 589
+            q[4] = heading;
+            q[5] = q[5] * curvature * -1;                                                     // MPG:575
+            q[6] = px;
+            q[7] = py;
         }
         __syncthreads();
         if (tid == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
@@ -147,7 +200,7 @@ __global__ __launch_bounds__(256) void k_time_geometry(int W, int cap, const dou
 
 hipError_t launch_time_profile(hipStream_t st, bool f64, int B, int W, int S, const double *segments, const double *lut,
                                const double *meta, const void *vel, double max_acc, double max_dec, double dt, int cap,
-                               double *rows, int *counts, int *nodes_map, uint32_t *flags)
+                               double *rows, int *counts, int *nodes_map, uint32_t *flags, RouteTables rt, const int *node_reverse)
 {
     const int nblk = (B + 63) / 64;
     if (f64)
@@ -157,12 +210,13 @@ hipError_t launch_time_profile(hipStream_t st, bool f64, int B, int W, int S, co
         hipLaunchKernelGGL(k_time_integrate<float>, dim3(nblk), dim3(64), 0, st, B, S, meta, (const float *)vel, max_acc,
                            max_dec, dt, cap, rows, counts, flags);
     const size_t seg_bytes = sizeof(double) * 12 * (size_t)(W - 1);
-    if (seg_bytes <= 40 * 1024)
-        hipLaunchKernelGGL(k_time_geometry<true>, dim3(B), dim3(256), seg_bytes, st, W, cap, segments, lut, meta, rows, counts,
-                           nodes_map);
-    else
-        hipLaunchKernelGGL(k_time_geometry<false>, dim3(B), dim3(256), 0, st, W, cap, segments, lut, meta, rows, counts,
-                           nodes_map);
+    const bool in_lds = seg_bytes <= 40 * 1024;
+#define VAP_TG(LDS_, RT_)                                                                                              \
+    hipLaunchKernelGGL((k_time_geometry<LDS_, RT_>), dim3(B), dim3(256), LDS_ ? seg_bytes : 0, st, W, cap, segments, lut, meta, rt, \
+                       node_reverse, rows, counts, nodes_map)
+    if (rt.sptab) { if (in_lds) VAP_TG(true, true); else VAP_TG(false, true); }
+    else { if (in_lds) VAP_TG(true, false); else VAP_TG(false, false); }
+#undef VAP_TG
     return hipGetLastError();
 }
 
@@ -179,17 +233,58 @@ hipError_t launch_time_profile(hipStream_t st, bool f64, int B, int W, int S, co
 //              two maps (row counts at the moment of the event, MPG:528, 549);
 //   all        copy row i to i + (rows inserted before it) and write the inserted rows.
 // ------------------------------------------------------------------------------------------------
+// MPG:319-346 motion_profile_angle over ODM:4-69 generate_trapezoidal_profile: the rows an in-place turn inserts
+struct TurnProfile {
+    double t_acc, vpeak, total_time, amax, half_tw, sign;
+    int n;
+};
+__device__ inline TurnProfile turn_profile(double angle, double vmax, double amax, double tw, double dt)
+{
+    TurnProfile p;
+    const double arc = fabs(angle) * tw / 2;
+    p.t_acc = vmax / amax;
+    const double d_acc = 0.5 * amax * (p.t_acc * p.t_acc);
+    p.vpeak = vmax;
+    if (2 * d_acc > arc) {
+        p.t_acc = sqrt(arc / amax);
+        p.vpeak = amax * p.t_acc;
+        p.total_time = 2 * p.t_acc;
+    } else {
+        p.total_time = 2 * p.t_acc + (arc - 2 * d_acc) / p.vpeak;
+    }
+    p.amax = amax;
+    p.half_tw = tw / 2;
+    p.sign = angle > 0 ? -1.0 : 1.0;
+    p.n = (int)ceil((p.total_time + dt) / dt);   // np.arange(0, total_time + dt, dt)
+    return p;
+}
+__device__ inline double turn_velocity(const TurnProfile &p, double tt)
+{
+    if (tt <= p.t_acc) return p.amax * tt;
+    if (tt <= p.total_time - p.t_acc) return p.vpeak;
+    return p.vpeak - p.amax * (tt - (p.total_time - p.t_acc));
+}
+
+struct TimeEventInputs {
+    const double *node_wait = nullptr;   // [B][W] seconds
+    const double *node_turn = nullptr;   // [B][W] degrees
+    const int *node_reverse = nullptr;   // [B][W] (only the heading of a wait at node 0 looks at it, MPG:463-464)
+    const double *ap_t = nullptr, *ap_wait = nullptr;   // [B][M]
+    double max_vel = 0, max_acc = 0, track_width = 0;   // the in-place turn's trapezoid (MPG:326-329)
+};
+
 __global__ __launch_bounds__(256) void k_time_waits(int W, int M, int cap_in, int cap_out, double dt,
                                                     const double *__restrict__ segments, const double *__restrict__ lut,
-                                                    const double *__restrict__ meta, const double *__restrict__ rows_in,
+                                                    const double *__restrict__ meta, RouteTables rt,
+                                                    const double *__restrict__ rows_in,
                                                     const int *__restrict__ counts_in, const int *__restrict__ nodes_in,
-                                                    const double *__restrict__ node_wait, const double *__restrict__ ap_t,
-                                                    const double *__restrict__ ap_wait, double *__restrict__ rows_out,
+                                                    TimeEventInputs ev, double *__restrict__ rows_out,
                                                     int *__restrict__ counts_out, int *__restrict__ nodes_out,
                                                     int *__restrict__ actions_out, uint32_t *__restrict__ flags)
 {
-    extern __shared__ int s_ev[];            // [E][2]: row, steps — E = W + M events at most
+    extern __shared__ int s_ev[];            // [E][3]: row, steps, node (>= 0: an in-place turn at that node; -1: a wait)
     __shared__ int s_n_ev;
+    const int E = 2 * W + M;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int G = W - 1;
     const double *m = meta + (size_t)b * kMetaStride;
@@ -198,27 +293,36 @@ __global__ __launch_bounds__(256) void k_time_waits(int W, int M, int cap_in, in
     const int T = counts_in[2 * b], n_nodes = counts_in[2 * b + 1];
     const double *in = rows_in + (size_t)b * cap_in * kRowWidth;
     double *out = rows_out + (size_t)b * cap_out * kRowWidth;
-    const double *D = lut + (size_t)b * kLutN;
     const double *seg = segments + (size_t)b * G * 12;
-    int *ev_row = s_ev, *ev_steps = s_ev + (W + M);
+    int *ev_row = s_ev, *ev_steps = s_ev + E, *ev_node = s_ev + 2 * E;
+    const double *ntu = ev.node_turn ? ev.node_turn + (size_t)b * W : nullptr;
     if (tid == 0) {
-        auto t_of_row = [&](int i) { return distance_to_time(D, total, t_max, end_param, i == 0 ? 0.0 : in[(size_t)(i - 1) * kRowWidth + 1]); };
-        const double *nw = node_wait ? node_wait + (size_t)b * W : nullptr;
+        const double plain_sp[kSplineStride] = {t_max, 0.0, 0.0, 0.0};
+        LutView v;
+        v.D = lut + (size_t)b * rt.NS * kLutN;
+        v.sp = rt.sptab ? rt.sptab + (size_t)b * rt.NS * kSplineStride : plain_sp;
+        v.n_spl = rt.sptab ? rt.nspl[b] : 1;
+        v.total = total;
+        v.end_param = end_param;
+        auto t_of_row = [&](int i) { return lutv_distance_to_time(v, i == 0 ? 0.0 : in[(size_t)(i - 1) * kRowWidth + 1]); };
+        const double *nw = ev.node_wait ? ev.node_wait + (size_t)b * W : nullptr;
         int n_ev = 0, shift = 0, n_act = 0;
-        // the wait at node 0 comes before everything (MPG:457-476)
         auto steps_of = [&](double w) { return w > 0.0 ? (int)(w / dt) : 0; };   // int(wait_time / dt)
+        auto push = [&](int row, int steps, int node) {
+            if (steps > 0 && n_ev < E) { ev_row[n_ev] = row; ev_steps[n_ev] = steps; ev_node[n_ev] = node; n_ev++; shift += steps; }
+        };
         nodes_out[(size_t)b * W] = 0;
-        {
-            const int s0 = nw ? steps_of(nw[0]) : 0;
-            if (s0 > 0) { ev_row[n_ev] = -1; ev_steps[n_ev] = s0; n_ev++; shift += s0; }   // row -1: before row 0
-        }
+        // node 0: a turn there reads headings[-1] of an empty list in the reference (IndexError, quirk Q4); its wait
+        // comes before everything (MPG:457-476)
+        if (ntu && ntu[0] != 0.0 && flags) atomicOr(&flags[b], 8u /* VAP_FLAG_BAD_ROUTE */);
+        push(-1, nw ? steps_of(nw[0]) : 0, -1);   // row -1: before row 0
         int node = 1, act = 0, last_act_row = -1;
         bool act_blocked = false;
         int next_act_row = -1;
         auto find_action = [&]() {      // row at which the pending action point fires, or -1
             next_act_row = -1;
             if (act_blocked || act >= M) return;
-            const double Tk = ap_t[(size_t)b * M + act];
+            const double Tk = ev.ap_t[(size_t)b * M + act];
             if (!(Tk == Tk) || Tk == INFINITY) { act_blocked = true; return; }   // padding
             int lo = 0, hi = T;         // first row with t > Tk
             while (lo < hi) {
@@ -235,14 +339,15 @@ __global__ __launch_bounds__(256) void k_time_waits(int W, int M, int cap_in, in
             const int ra = next_act_row >= 0 ? next_act_row : 0x7fffffff;
             if (rn <= ra) {             // node first on the same row (MPG:527 then 546)
                 nodes_out[(size_t)b * W + node] = rn + shift;
-                const int st = nw ? steps_of(nw[node]) : 0;
-                if (st > 0 && n_ev < W + M) { ev_row[n_ev] = rn; ev_steps[n_ev] = st; n_ev++; shift += st; }
+                // the in-place turn first (MPG:533-537), then the wait (MPG:543-544)
+                if (ntu && ntu[node] != 0.0)
+                    push(rn, turn_profile(ntu[node] * (M_PI / 180.0), ev.max_vel, ev.max_acc, ev.track_width, dt).n, node);
+                push(rn, nw ? steps_of(nw[node]) : 0, -1);
                 node++;
             } else {
                 actions_out[(size_t)b * M + n_act] = ra + shift;
                 n_act++;
-                const int st = ap_wait ? steps_of(ap_wait[(size_t)b * M + act]) : 0;
-                if (st > 0 && n_ev < W + M) { ev_row[n_ev] = ra; ev_steps[n_ev] = st; n_ev++; shift += st; }
+                push(ra, ev.ap_wait ? steps_of(ev.ap_wait[(size_t)b * M + act]) : 0, -1);
                 last_act_row = ra;
                 act++;
                 find_action();
@@ -272,44 +377,78 @@ __global__ __launch_bounds__(256) void k_time_waits(int W, int M, int cap_in, in
 #pragma unroll
         for (int c = 1; c < kRowWidth; c++) w[c] = q[c];
     }
-    // inserted rows
+    __syncthreads();
+    // inserted rows, event after event: each continues from the output row in front of it (headings[-1],
+    // positions[-1], coords[-1] — a kinematic row, or the last row of the event before it on the same row)
     int before = 0;
     for (int e = 0; e < n_ev; e++) {
-        const int r = ev_row[e], st = ev_steps[e];
-        double h, px, py, t0;
-        if (r < 0) {                    // node 0: heading and point of the path's start (MPG:461-473)
+        const int r = ev_row[e], st = ev_steps[e], nd = ev_node[e];
+        const int base = (r < 0 ? 0 : r) + before;
+        double h, px, py, lastpos = 0.0, t0;
+        if (base == 0) {                // node 0's wait: heading and point of the route's start (MPG:461-473)
             double dx, dy;
-            hermite_eval_ref(seg, t_max, G, 1, 0.0, dx, dy);
+            hermite_eval_seg(seg, 1, 0.0, dx, dy);
             h = -1.0 * atan2(dy, dx);
+            if (ev.node_reverse && ev.node_reverse[(size_t)b * W] != 0) h -= M_PI;
             if (h > M_PI) h -= 2 * M_PI;
             if (h < -M_PI) h += 2 * M_PI;
-            hermite_eval_ref(seg, t_max, G, 0, 0.0, px, py);
+            hermite_eval_seg(seg, 0, 0.0, px, py);
             t0 = 0.0;
-        } else {                        // headings[-1], coords[-1]: the row before; current_time: this row's
-            const double *prev = in + (size_t)(r > 0 ? r - 1 : 0) * kRowWidth;
-            h = prev[4]; px = prev[6]; py = prev[7];
-            t0 = (r < T ? in[(size_t)r * kRowWidth] : in[(size_t)(T - 1) * kRowWidth] + dt) + (double)before * dt;
+        } else {
+            const double *prev = out + (size_t)(base - 1 < cap_out ? base - 1 : cap_out - 1) * kRowWidth;
+            h = prev[4]; px = prev[6]; py = prev[7]; lastpos = prev[1];
+            // current_time: the time the next kinematic row would have had
+            t0 = (r < T ? in[(size_t)(r < 0 ? 0 : r) * kRowWidth] : in[(size_t)(T - 1) * kRowWidth] + dt) + (double)before * dt;
         }
-        const int base = (r < 0 ? 0 : r) + before;
-        for (int j = tid; j < st; j += 256) {
-            const int o = base + j;
-            if (o >= cap_out) continue;
-            double *w = out + (size_t)o * kRowWidth;
-            w[0] = t0 + (double)j * dt;
-            w[1] = 0.0; w[2] = 0.0; w[3] = 0.0; w[4] = h; w[5] = 0.0; w[6] = px; w[7] = py;
+        if (nd < 0) {                   // handle_wait, MPG:509-518 (position 0: quirk Q7)
+            for (int j = tid; j < st; j += 256) {
+                const int o = base + j;
+                if (o >= cap_out) continue;
+                double *w = out + (size_t)o * kRowWidth;
+                w[0] = t0 + (double)j * dt;
+                w[1] = 0.0; w[2] = 0.0; w[3] = 0.0; w[4] = h; w[5] = 0.0; w[6] = px; w[7] = py;
+            }
+        } else if (tid == 0) {          // handle_turn, MPG:487-507: the heading profile is a running sum
+            const TurnProfile p = turn_profile(ntu[nd] * (M_PI / 180.0), ev.max_vel, ev.max_acc, ev.track_width, dt);
+            double accum = 0, prev_h = 0;
+            for (int j = 0; j < st; j++) {
+                const double vel = turn_velocity(p, (double)j * dt);
+                double hh = accum / p.half_tw * p.sign;
+                const double raw = hh;
+                accum += vel * dt;
+                const double wv = j == 0 ? 0.0 : (raw - prev_h) / dt;   // differences of the UN-wrapped headings
+                prev_h = raw;
+                while (hh + h > M_PI) hh -= 2 * M_PI;
+                while (hh + h < -M_PI) hh += 2 * M_PI;
+                const int o = base + j;
+                if (o >= cap_out) break;
+                double *w = out + (size_t)o * kRowWidth;
+                w[0] = t0 + j * dt; w[1] = lastpos; w[2] = 0; w[3] = 0; w[4] = h + hh; w[5] = wv; w[6] = px; w[7] = py;
+            }
         }
         before += st;
+        __syncthreads();
     }
 }
 
 hipError_t launch_time_waits(hipStream_t st, int B, int W, int M, int cap_in, int cap_out, double dt, const double *segments,
                              const double *lut, const double *meta, const double *rows_in, const int *counts_in,
                              const int *nodes_in, const double *node_wait, const double *ap_t, const double *ap_wait,
-                             double *rows_out, int *counts_out, int *nodes_out, int *actions_out, uint32_t *flags)
+                             double *rows_out, int *counts_out, int *nodes_out, int *actions_out, uint32_t *flags, RouteTables rt,
+                             const double *node_turn, const int *node_reverse, double max_vel, double max_acc, double track_width)
 {
-    const size_t lds = sizeof(int) * 2 * (size_t)(W + M);
-    hipLaunchKernelGGL(k_time_waits, dim3(B), dim3(256), lds, st, W, M, cap_in, cap_out, dt, segments, lut, meta, rows_in, counts_in,
-                       nodes_in, node_wait, ap_t, ap_wait, rows_out, counts_out, nodes_out, actions_out, flags);
+    const size_t lds = sizeof(int) * 3 * (size_t)(2 * W + M);
+    TimeEventInputs ev;
+    ev.node_wait = node_wait;
+    ev.node_turn = node_turn;
+    ev.node_reverse = node_reverse;
+    ev.ap_t = ap_t;
+    ev.ap_wait = ap_wait;
+    ev.max_vel = max_vel;
+    ev.max_acc = max_acc;
+    ev.track_width = track_width;
+    hipLaunchKernelGGL(k_time_waits, dim3(B), dim3(256), lds, st, W, M, cap_in, cap_out, dt, segments, lut, meta, rt, rows_in,
+                       counts_in, nodes_in, ev, rows_out, counts_out, nodes_out, actions_out, flags);
     return hipGetLastError();
 }
 
