@@ -1,0 +1,195 @@
+"""Experiment (CPU, numpy): how many parallel iterations does the forward velocity sweep of a config-3 path need
+under (a) the kernel's chunk relaxation (one chunk per iteration along a chain), (b) a quasi-Newton iteration whose
+chunk maps are modelled as affine u_out = out + J (u_in - in) with a secant J and solved by a scan, (c) Newton with
+the exact 2x2 chunk Jacobians (the recurrence is piecewise linear)?  Rows come from the oracle.  Developer tool.
+"""
+import sys, os
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import oracle
+from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
+
+HUGE = 1e300
+
+
+def coefficients(kappa, heading, L_total, S, cons):
+    vmax, amax, adec, _, _, tw = cons
+    N = S
+    dd = L_total / (S - 1.5)
+    twodd = 2 * dd
+    k = np.abs(kappa)
+    dth = np.abs((np.diff(heading) + np.pi) % (2 * np.pi) - np.pi)
+    # forward step into j (1..N-1) uses k[j-1], dth[j-1], k[j-2]
+    rho = np.zeros(N); g = np.zeros(N); A = np.full(N, HUGE); cap = np.full(N, HUGE)
+    for j in range(1, N):
+        kc = k[j - 1]; kp = k[j - 2] if j >= 2 else 0.0
+        q = kc * kc
+        straight = kc < 1e-6
+        r = 1.0 / (1.0 + tw / 2 * kc)
+        cap[j] = (vmax * r) ** 2
+        A[j] = twodd * amax * (1.0 if straight else r)
+        qp = kp * kp
+        rho[j] = 0.0 if straight else (1.0 if qp == q else qp / q)
+        gg = min(twodd * tw / 4 / dth[j - 1], HUGE) if dth[j - 1] > 0 else HUGE
+        gq = min(gg * q, HUGE * 0.1)
+        if gg >= HUGE: gq = HUGE   # (sign marker dropped: forward only)
+        g[j] = 0.0 if q < 1e-12 else gq
+    return rho, g, A, cap, twodd * amax
+
+
+def step(u, w, rho, g, A, cap, amaxp):
+    t = u - rho * w
+    y = amaxp - np.abs(t) * g
+    return np.minimum(u + np.clip(y, 0, A), cap)
+
+
+def step_jac(u, w, du, dw, rho, g, A, cap, amaxp):
+    """u' and its tangent (du', rows = d/du_in, d/dw_in)."""
+    t = u - rho * w
+    y = amaxp - np.abs(t) * g
+    r = u + np.clip(y, 0, A)
+    mid = (y > 0) & (y < A)
+    m = np.where(mid, -np.sign(t) * g, 0.0)
+    dt = du - rho * dw
+    dr = du + m * dt
+    capped = r > cap
+    return np.where(capped, cap, r), np.where(capped, 0.0, dr)
+
+
+def sequential(co, u0):
+    rho, g, A, cap, amaxp = co
+    N = len(rho)
+    u = np.empty(N); u[0] = u0
+    w = 0.0
+    for j in range(1, N):
+        u[j] = step(u[j - 1], w, rho[j], g[j], A[j], cap[j], amaxp)
+        w = u[j - 1]
+    return u
+
+
+def chunk_eval(co, Lc, T, in_u, in_w, u0):
+    """All chunks at once: chunk i owns samples [i*Lc, (i+1)*Lc); returns out (u,w) per chunk."""
+    rho, g, A, cap, amaxp = co
+    N = len(rho)
+    pad = T * Lc - N
+    def P(a, fill): return np.concatenate([a, np.full(pad, fill)]).reshape(T, Lc)
+    R, G, AA, C = P(rho, 0.0), P(g, 0.0), P(A, HUGE), P(cap, HUGE)
+    u = in_u.copy(); w = in_w.copy()
+    for s in range(Lc):
+        nu = step(u, w, R[:, s], G[:, s], AA[:, s], C[:, s], amaxp)
+        if s == 0:
+            nu[0] = u0     # sample 0 is given
+            w = u.copy(); w[0] = 0.0
+            u = nu
+            continue
+        w = u
+        u = nu
+    # idle slots (past N): A=cap=huge, g=0: u' = min(u + amaxp, huge) -- the kernel handles them by masking; here chunks past N are ignored
+    return u, w
+
+
+def chunk_eval_jac(co, Lc, T, in_u, in_w, u0):
+    rho, g, A, cap, amaxp = co
+    N = len(rho)
+    pad = T * Lc - N
+    def P(a, fill): return np.concatenate([a, np.full(pad, fill)]).reshape(T, Lc)
+    R, G, AA, C = P(rho, 0.0), P(g, 0.0), P(A, HUGE), P(cap, HUGE)
+    u = in_u.copy(); w = in_w.copy()
+    # tangents: columns (d/du_in, d/dw_in)
+    du = np.stack([np.ones(T), np.zeros(T)], 1); dw = np.stack([np.zeros(T), np.ones(T)], 1)
+    for s in range(Lc):
+        nu, ndu0 = step_jac(u, w, du[:, 0], dw[:, 0], R[:, s], G[:, s], AA[:, s], C[:, s], amaxp)
+        _, ndu1 = step_jac(u, w, du[:, 1], dw[:, 1], R[:, s], G[:, s], AA[:, s], C[:, s], amaxp)
+        ndu = np.stack([ndu0, ndu1], 1)
+        if s == 0:
+            nu[0] = u0; ndu[0] = 0
+            w = u.copy(); w[0] = 0.0
+            dw = du.copy(); dw[0] = 0
+            u = nu; du = ndu
+            continue
+        w = u; dw = du
+        u = nu; du = ndu
+    return u, w, du, dw
+
+
+def jacobi(co, Lc, T, u0, tol=0.0):
+    _, _, _, cap, _ = co
+    N = len(cap)
+    seeds = np.concatenate([cap, np.full(T * Lc - N, HUGE)]).reshape(T, Lc)[:, 0].copy()
+    in_u = seeds.copy(); in_w = seeds.copy(); in_u[0] = u0; in_w[0] = 0
+    active = np.arange(T) * Lc <= N - 1
+    it = 0
+    while True:
+        ou, ow = chunk_eval(co, Lc, T, in_u, in_w, u0)
+        nu = in_u.copy(); nw = in_w.copy()
+        nu[1:] = ou[:-1]; nw[1:] = ow[:-1]
+        ch = active & ((np.abs(nu - in_u) > tol * np.abs(nu)) | (np.abs(nw - in_w) > tol * np.abs(nw)))
+        it += 1
+        if not ch.any():
+            return it, in_u, in_w
+        in_u = np.where(active, nu, in_u); in_w = np.where(active, nw, in_w)
+
+
+def alpha_free(co, u0):
+    rho, g, A, cap, amaxp = co
+    N = len(rho)
+    u = np.empty(N); u[0] = u0
+    for j in range(1, N):
+        u[j] = min(u[j - 1] + min(A[j], amaxp), cap[j])
+    return u
+
+
+def newton(co, Lc, T, u0, tol=1e-13, maxit=40, exact=True, seed_scan=False):
+    _, _, _, cap, _ = co
+    N = len(cap)
+    seeds = np.concatenate([cap, np.full(T * Lc - N, HUGE)]).reshape(T, Lc)[:, 0].copy()
+    in_u = seeds.copy(); in_w = seeds.copy(); in_u[0] = u0; in_w[0] = 0
+    if seed_scan:
+        uf = alpha_free(co, u0)
+        nact = (N - 1) // Lc + 1
+        idx = np.arange(1, nact) * Lc - 1
+        in_u[1:nact] = uf[idx]; in_w[1:nact] = uf[idx - 1]
+    nact = (N - 1) // Lc + 1
+    for it in range(1, maxit + 1):
+        ou, ow, du, dw = chunk_eval_jac(co, Lc, T, in_u, in_w, u0)
+        # consistency
+        ru = ou[:nact - 1] - in_u[1:nact]; rw = ow[:nact - 1] - in_w[1:nact]
+        bad = (np.abs(ru) > tol * np.abs(ou[:nact - 1])) | (np.abs(rw) > tol * np.abs(ow[:nact - 1]))
+        if not bad.any():
+            return it, in_u, in_w
+        # solve the linearised recurrence sequentially (stands for the affine scan)
+        nu = in_u.copy(); nw = in_w.copy()
+        for i in range(nact - 1):
+            d0 = nu[i] - in_u[i]; d1 = nw[i] - in_w[i]
+            nu[i + 1] = ou[i] + du[i, 0] * d0 + du[i, 1] * d1
+            nw[i + 1] = ow[i] + dw[i, 0] * d0 + dw[i, 1] * d1
+        in_u, in_w = nu, nw
+    return maxit + 1, in_u, in_w
+
+
+def main():
+    B, W, S = int(sys.argv[1]) if len(sys.argv) > 1 else 24, 32, 10000
+    Lc, T = 20, 512
+    wp = make_waypoints(B, W, 12345)
+    out = oracle.profile_batch(wp, S, DEFAULT_CONSTRAINTS, want=("heading", "curvature", "velocity"))
+    res = []
+    for b in range(B):
+        co = coefficients(out["curvature"][b], out["heading"][b], out["total_length"][b], S, DEFAULT_CONSTRAINTS)
+        u0 = 0.01 ** 2
+        useq = sequential(co, u0)
+        jit, ju, jw = jacobi(co, Lc, T, u0)
+        jit_t, _, _ = jacobi(co, Lc, T, u0, tol=1e-13)
+        nit, nu, nw = newton(co, Lc, T, u0)
+        nit2, _, _ = newton(co, Lc, T, u0, seed_scan=True)
+        # check: the Newton solution's inputs equal the sequential states at chunk starts
+        nact = (S - 1) // Lc + 1
+        idx = np.arange(1, nact) * Lc - 1
+        err = np.max(np.abs(nu[1:nact] - useq[idx]) / useq[idx])
+        res.append((jit, jit_t, nit, err))
+        print(f"path {b}: jacobi {jit} (tol {jit_t})  newton {nit} seeded {nit2} err {err:.2e}")
+    r = np.array(res)
+    print("mean jacobi", r[:, 0].mean(), "mean newton", r[:, 2].mean(), "max newton", r[:, 2].max(), "worst err", r[:, 3].max())
+
+
+if __name__ == "__main__":
+    main()

@@ -2435,13 +2435,13 @@ static hipError_t velocity_long_t(hipStream_t st, int B, int S, const double c[6
 
 size_t velocity_long_state_bytes(bool f64, int B, int S)
 {
-    const int SC = f64 ? 512 * 16 : 64 * 40;   // the smallest super-chunk launch_velocity_long may pick
+    const int SC = f64 ? 64 * 16 : 64 * 40;   // the smallest super-chunk launch_velocity_long may pick
     const int nsc = (S + SC - 1) / SC;
     return (f64 ? 8 : 4) * ((size_t)2 * B * (nsc + 1) * 2 + (size_t)2 * B * nsc * 2) + 64;
 }
 size_t velocity_long_counter_bytes(bool f64, int B, int S)
 {
-    const int SC = f64 ? 512 * 16 : 64 * 40;
+    const int SC = f64 ? 64 * 16 : 64 * 40;   // as above: the smallest super-chunk
     const int nsc = (S + SC - 1) / SC;
     return sizeof(int) * ((size_t)B + 2 * (nsc + 2)) + 64;
 }
@@ -2450,8 +2450,18 @@ hipError_t launch_velocity_long(hipStream_t st, bool f64, bool io64, int B, int 
                                 const double *meta, const void *curv, const void *dth, void *vel, uint32_t *flags,
                                 void *ufwd, void *state, int *counters)
 {
-    if (f64 && io64) return velocity_long_t<double, double, 16, 512, 2>(st, B, S, c, sv, ev, meta, curv, dth, vel, flags, ufwd, state, counters);
-    if (f64) return velocity_long_t<double, float, 16, 512, 2>(st, B, S, c, sv, ev, meta, curv, dth, vel, flags, ufwd, state, counters);
+    // super-chunk = 512, 128 or 64 threads x 16 samples (fp64): few long rows (config 2: one) are cut finer so that the
+    // chip has more workgroups to run and a super-round is shorter
+    static const char *cfg64 = getenv("VAP_LONG_T64");   // developer knob (tuning only): 64, 128 or 512
+    const int forced64 = cfg64 ? atoi(cfg64) : 0;
+    if (f64) {
+        const long blocks512 = (long)B * ((S + 512 * 16 - 1) / (512 * 16));
+        const int t64 = forced64 ? forced64 : (blocks512 < 256 ? 64 : (blocks512 < 1024 ? 128 : 512));
+#define VAP_LONG64(IO_, T_) velocity_long_t<double, IO_, 16, T_, 2>(st, B, S, c, sv, ev, meta, curv, dth, vel, flags, ufwd, state, counters)
+        if (io64) return t64 == 64 ? VAP_LONG64(double, 64) : (t64 == 128 ? VAP_LONG64(double, 128) : VAP_LONG64(double, 512));
+        return t64 == 64 ? VAP_LONG64(float, 64) : (t64 == 128 ? VAP_LONG64(float, 128) : VAP_LONG64(float, 512));
+#undef VAP_LONG64
+    }
     // super-chunk = 256 or 64 threads x 40 samples: few long rows (config 2: one) are cut finer so that the
     // chip has more workgroups to run and a super-round is shorter
     static const char *cfg = getenv("VAP_LONG_T");   // developer knob (tuning only): 64 or 256
