@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — trajectory sample-points/s of the batched hot path on N MI355X (one rank per GPU).
 
-    python bench.py [--gpus N --steps K --warmup W] [--workload c3|c5|c2] [--dtype f32|f64]
+    python bench.py [--gpus N --steps K --warmup W] [--workload c3|c5|c2|c4] [--dtype f32|f64]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -16,6 +16,7 @@ Workloads (BASELINE.json configs):
                 "sample-points/s (batched paths)" is quoted on
   c5          : 131 072 paths x 8 waypoints x 1024 samples per GPU
   c2          : 1 path x 256 waypoints x 1 000 000 samples
+  c4          : 8192 paths x 32 waypoints x 10 000 samples — one GPU's share of config 4's 65 536 paths
 """
 import argparse
 import json
@@ -32,6 +33,7 @@ WORKLOADS = {
     "c3": dict(paths=4096, W=32, S=10000, seed=3, name="c3: 4096 paths x 32 waypoints x 10000 samples per GPU"),
     "c5": dict(paths=131072, W=8, S=1024, seed=5, name="c5: 131072 paths x 8 waypoints x 1024 samples per GPU"),
     "c2": dict(paths=1, W=256, S=1000000, seed=2, name="c2: 1 path x 256 waypoints x 1e6 samples"),
+    "c4": dict(paths=8192, W=32, S=10000, seed=4, name="c4: 65536 paths x 32 waypoints x 10000 samples over 8 GPUs, the share of one (8192 paths)"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
