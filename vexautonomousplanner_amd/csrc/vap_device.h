@@ -538,6 +538,27 @@ __device__ __forceinline__ double vmax_(double a, double b) { return fmax(a, b);
 __device__ __forceinline__ float clamp0(float x, float hi) { return __builtin_amdgcn_fmed3f(x, 0.0f, hi); }
 __device__ __forceinline__ double clamp0(double x, double hi) { return fmin(fmax(x, 0.0), hi); }
 
+// A wave-uniform double moved to scalar registers (v_readfirstlane of both halves): a VALU instruction reads it from
+// there, and it stops competing with the per-sample arrays for vector registers.
+__device__ __forceinline__ double uniform(double x)
+{
+    const uint64_t v = __builtin_bit_cast(uint64_t, x);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+// ... and kept there: the value passes through a scalar register operand of an (empty) asm statement, so the compiler
+// cannot fold the move back into the vector arithmetic that produced it
+__device__ __forceinline__ double uniform_pinned(double x)
+{
+    asm volatile("" : "+v"(x));   // (a value the compiler knows to be uniform would have its v_readfirstlane folded away)
+    const uint64_t v = __builtin_bit_cast(uint64_t, x);
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+
 // Hides a value from code motion (loop-invariant hoisting, sinking into branches).
 __device__ __forceinline__ float opaque(float x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ double opaque(double x) { asm volatile("" : "+v"(x)); return x; }
@@ -593,6 +614,18 @@ __device__ __forceinline__ R fast_gq(R gg, R q)
 {
     R r = vmin(gg * q, Huge<R>::v * (R)0.1);
     r = gg >= Huge<R>::v ? -Huge<R>::v : r;
+    return q < (R)1e-12 ? (R)0 : r;
+}
+
+// The same two with kHuge handed in (a kernel that keeps it in scalar registers: as a 64-bit literal the compiler
+// parks it in a vector register pair for the selects and, under pressure, spills and reloads it at every use).
+template <typename R>
+__device__ __forceinline__ R fast_gg(const FastConsts<R> &c, R dth, R hugev) { return vmin(c.gk * fast_rcp(dth), hugev); }
+template <typename R>
+__device__ __forceinline__ R fast_gq(R gg, R q, R hugev)
+{
+    R r = vmin(gg * q, Huge<R>::v * (R)0.1);
+    r = gg >= hugev ? -hugev : r;
     return q < (R)1e-12 ? (R)0 : r;
 }
 
