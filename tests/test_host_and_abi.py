@@ -192,3 +192,50 @@ def test_trajectory_file_formats(tmp_path):
     js = tio.route_json([[1.5, -2.0, 1, 0, 0, 0, 0, 0, None, None, None]], [[0.0, 1.0, 2.5, 0, 0]])
     assert js == "[[[1.5,-2.0,1,0,0,0,0,0,null,null,null]],[[0.0,1.0,2.5,0,0]]]"
     assert tio.parse_route_json(js)[1][0][2] == 2.5
+
+
+# ------------------------------------------------------------------------------------------------
+# file formats against a file the reference itself wrote (src/routes.h of the reference; the
+# fixture keeps its skeleton and the exact text of a slice of its rows — oracle/gen_routes_fixture.py)
+# ------------------------------------------------------------------------------------------------
+def _routes_fixture():
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "files", "routes_h_slice.json")) as f:
+        return json.load(f)
+
+
+def _parse_row(text):
+    import re
+    return [int(tok) if re.fullmatch(r"-?\d+", tok) else float(tok) for tok in text.split(", ")]
+
+
+def test_routes_header_entry_reproduces_the_reference_file_text():
+    from vexautonomousplanner_amd import trajectory_io as tio
+    fx = _routes_fixture()
+    rows = [_parse_row(t) for t in fx["rows_text"]]
+    want = "std::vector<std::vector<double>> %s = {%s};\n" % (fx["name"], ", ".join("{" + t + "}" for t in fx["rows_text"]))
+    assert tio.routes_header_entry(fx["name"], rows) == want
+    # the same values as a .txt trajectory: one row per line, every value followed by one space (gui_manager.py:220-230)
+    txt = tio.format_txt(rows)
+    assert txt.split("\n")[:-1] == [t.replace(", ", " ") + " " for t in fx["rows_text"]]
+    # shape of what the reference wrote: time steps of 25 ms in 7-value rows, action rows first and last
+    steps = [r for r in rows if r[0] == 0]
+    assert all(len(r) == 7 for r in rows) and rows[0][0] == 1 and rows[-1][0] == 1
+    assert abs(steps[1][1] - steps[0][1] - 0.025) < 1e-12
+
+
+def test_update_routes_header_writes_the_reference_skeleton(tmp_path):
+    from vexautonomousplanner_amd import trajectory_io as tio
+    fx = _routes_fixture()
+    rows = [_parse_row(t) for t in fx["rows_text"]]
+    entry = tio.routes_header_entry(fx["name"], rows)
+    path = tmp_path / "routes.h"
+    tio.update_routes_header(str(path), fx["name"], rows)          # new file
+    want = "\n".join(entry[:-1] if l == "<ENTRY>" else l for l in fx["skeleton"])
+    assert path.read_text() == want
+    tio.update_routes_header(str(path), fx["name"], rows[:10])     # replace in place: still one entry, same skeleton
+    lines = path.read_text().split("\n")
+    assert [("<ENTRY>" if l.startswith("std::vector") else l) for l in lines] == fx["skeleton"]
+    tio.update_routes_header(str(path), "other", rows[:3])         # a second route goes in front of #endif
+    lines = path.read_text().split("\n")
+    assert sum(l.startswith("std::vector") for l in lines) == 2 and lines[-2] == "#endif"
