@@ -360,6 +360,14 @@ int vap_route_create(vap_ctx *ctx, const vap_route_desc *desc, vap_route **out);
 int vap_route_destroy(vap_route *route);
 /* number of splines and lookup_table.total_length (SM:320-330) */
 int vap_route_info(vap_route *route, int *n_splines, double *total_length);
+/* build_lookup_table(min_samples = lut_samples) and precompute_path_properties(samples_per_node) with sizes other than
+ * the defaults every caller in the reference uses (1000 / 1000; SM:426-427, 477): rebuilds the route's arc-length
+ * table with lut_samples entries per spline (np.linspace, trapezoid increments, np.cumsum — same operations, same
+ * order) and makes the step lookup of get_heading / get_curvature (SM:550-580) read a table of
+ * samples_per_node * len(nodes) entries.  Every later call on the route (lookups, forward_backward, motion_profile)
+ * uses the new tables.  VAP_ERR_INVALID for lut_samples < 2 (the reference indexes local_params[1], SM:444). */
+int vap_route_set_table_sizes(vap_route *route, int lut_samples, int samples_per_node);
+int vap_route_table_sizes(vap_route *route, int *lut_samples, int *samples_per_node);
 /* Per-spline results for the host mirrors of the drop-in classes; any pointer may be NULL.
  * start/npts/param_last [n_splines]; segments [(W-1)][6][2]; segment_lengths [W-1];
  * lut_distances / lut_parameters [n_splines*1000] = PathLookupTable (SM:466-475). */

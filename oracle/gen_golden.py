@@ -298,6 +298,52 @@ def run_api_pins(mods):
     print(f"api/pin_spline_api: {len(d)} arrays, {os.path.getsize(path) / 1024:.0f} KiB", flush=True)
 
 
+def run_table_size_pins(mods):
+    """build_lookup_table(min_samples != 1000) and precompute_path_properties(samples_per_node != 1000) (SM:426-475,
+    477-548): tables, lookups and the velocity pass of the reference with non-default sizes, on a plain path and on a
+    route that a reverse node splits."""
+    sm_mod, _, mpg = mods
+    d = {}
+    wp8 = np.asarray(make_waypoints(1, 8, 11)[0], dtype=np.float64)
+    na = [{} for _ in range(8)]
+    na[3] = {"is_reverse_node": True}
+    cases = (("plain", None, 257, 64), ("plain_big", None, 3001, 1500), ("split", na, 129, 333), ("tiny", None, 2, 1))
+    for tag, attrs, lut_n, spn in cases:
+        mgr = build_manager(sm_mod, wp8, attrs)
+        mgr.build_lookup_table(min_samples=lut_n)
+        mgr.precompute_path_properties(samples_per_node=spn)
+        total = float(mgr.get_total_arc_length())
+        d[f"{tag}_sizes"] = np.array([lut_n, spn], dtype=np.int64)
+        d[f"{tag}_reverse"] = np.array([float((attrs[i] if attrs else {}).get("is_reverse_node", 0)) for i in range(8)])
+        d[f"{tag}_lut_distances"] = np.asarray(mgr.lookup_table.distances)
+        d[f"{tag}_lut_parameters"] = np.asarray(mgr.lookup_table.parameters)
+        d[f"{tag}_total_length"] = np.float64(total)
+        s_q = np.concatenate([np.linspace(0.0, total, 37), [total * 0.5001, 1e-9, total - 1e-9]])
+        d[f"{tag}_s"] = s_q
+        d[f"{tag}_distance_to_time"] = np.array([float(mgr.distance_to_time(float(v))) for v in s_q])
+        ts = np.concatenate([np.linspace(0.0, 7.0, 57), [0.5, 3.0, 6.999999, 3.3333]])
+        d[f"{tag}_t"] = ts
+        d[f"{tag}_heading"] = np.array([float(mgr.get_heading(float(t))) for t in ts])
+        d[f"{tag}_curvature"] = np.array([float(mgr.get_curvature(float(t))) for t in ts])
+        c = mpg.Constraints(*DEFAULT_CONSTRAINTS)
+        dd = total / (400 - 1.5)
+        d[f"{tag}_dd"] = np.float64(dd)
+        d[f"{tag}_velocity"] = np.array(mpg.forward_backward_pass(mgr, c, dd), dtype=np.float64)   # MPG:70-316: no rebuild
+    d["wp"] = wp8
+    # min_samples = 1: np.linspace(..., 1)[1] raises IndexError (SM:444)
+    mgr = build_manager(sm_mod, wp8, None)
+    try:
+        mgr.build_lookup_table(min_samples=1)
+        d["one_sample_raises"] = np.int64(0)
+    except IndexError:
+        d["one_sample_raises"] = np.int64(1)
+    out = os.path.join(OUT, "api")
+    os.makedirs(out, exist_ok=True)
+    path = os.path.join(out, "pin_table_sizes.npz")
+    np.savez_compressed(path, **d)
+    print(f"api/pin_table_sizes: {len(d)} arrays, {os.path.getsize(path) / 1024:.0f} KiB", flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--c2", action="store_true", help="also run the 1e6-sample single-path case")
@@ -400,6 +446,8 @@ def main():
         run_case(mods, "feat_split2", wp6, node_attrs=na, full_profile=True)
     if want("api_pins"):
         run_api_pins(mods)
+    if want("table_size_pins"):
+        run_table_size_pins(mods)
     if want("feat_mixed"):
         na = [{} for _ in range(8)]
         na[2] = {"is_reverse_node": True, "wait_time": 0.1}

@@ -376,3 +376,54 @@ def test_route_with_two_node_split_splines(mods):
         assert len(arr) == len(ref), nm
         np.testing.assert_allclose(arr, ref, rtol=1e-8, atol=1e-8, err_msg=nm)
     assert list(res[6]) == [int(x) for x in g["profile_nodes_map"]]
+
+
+# ------------------------------------------------------------------------------------------------
+# build_lookup_table(min_samples) / precompute_path_properties(samples_per_node) with other sizes than the defaults
+# (SM:426-475, 477-548): tests/golden/api/pin_table_sizes.npz holds what the real reference returns
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def size_pins():
+    return dict(np.load(os.path.join(ROOT, "tests", "golden", "api", "pin_table_sizes.npz")))
+
+
+@pytest.mark.parametrize("tag", ["plain", "plain_big", "split", "tiny"])
+def test_tables_of_other_sizes_match_reference(mods, size_pins, tag):
+    Manager, mpg, Node, _ = mods
+    p = size_pins
+    nodes = [Node() for _ in p["wp"]]
+    for i, r in enumerate(p[f"{tag}_reverse"]):
+        nodes[i].is_reverse_node = bool(r)
+    m = Manager()
+    assert m.build_path(p["wp"], nodes, []) is True
+    lut_n, spn = (int(v) for v in p[f"{tag}_sizes"])
+    m.build_lookup_table(min_samples=lut_n)
+    m.precompute_path_properties(samples_per_node=spn)
+    assert len(m.lookup_table.distances) == len(m.splines) * lut_n
+    np.testing.assert_allclose(m.lookup_table.distances, p[f"{tag}_lut_distances"], rtol=1e-15, atol=1e-15)
+    np.testing.assert_allclose(m.lookup_table.parameters, p[f"{tag}_lut_parameters"], rtol=1e-15, atol=1e-16)
+    np.testing.assert_allclose(m.get_total_arc_length(), float(p[f"{tag}_total_length"]), rtol=1e-15)
+    got = np.array([m.distance_to_time(float(s)) for s in p[f"{tag}_s"]])
+    np.testing.assert_allclose(got, p[f"{tag}_distance_to_time"], rtol=1e-12, atol=1e-13)
+    hd = np.array([m.get_heading(float(t)) for t in p[f"{tag}_t"]])
+    kp = np.array([m.get_curvature(float(t)) for t in p[f"{tag}_t"]])
+    assert np.max(np.abs(hd - p[f"{tag}_heading"])) <= 1e-12
+    np.testing.assert_allclose(kp, p[f"{tag}_curvature"], rtol=1e-10, atol=1e-11)
+    # the velocity pass reads the same tables (forward_backward_pass does not rebuild them, MPG:70-316)
+    from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS
+    v = np.array(mpg.forward_backward_pass(m, mpg.Constraints(*DEFAULT_CONSTRAINTS), float(p[f"{tag}_dd"])))
+    ref = p[f"{tag}_velocity"]
+    assert len(v) == len(ref)
+    assert np.max(np.abs(v - ref) / np.abs(ref)) <= 1e-9
+    # and rebuild_tables() goes back to the reference's defaults
+    m.rebuild_tables()
+    assert len(m.lookup_table.distances) == len(m.splines) * 1000
+
+
+def test_one_sample_table_raises_like_the_reference(mods, size_pins):
+    Manager, _, Node, _ = mods
+    m = Manager()
+    assert m.build_path(size_pins["wp"], [Node() for _ in size_pins["wp"]], []) is True
+    assert int(size_pins["one_sample_raises"]) == 1
+    with pytest.raises(IndexError):
+        m.build_lookup_table(min_samples=1)

@@ -192,13 +192,38 @@ class DeviceRoute:
         self.sp_param_last = np.zeros(n)
         self.segments = np.zeros((W - 1, 6, 2))
         self.segment_lengths = np.zeros(W - 1)
-        self.lut_distances = np.zeros(n * _lib.LUT_SAMPLES)
-        self.lut_parameters = np.zeros(n * _lib.LUT_SAMPLES)
-        _lib.check(self._L.vap_route_get_splines(h, self.sp_start.ctypes.data_as(ip), self.sp_npts.ctypes.data_as(ip),
-                                                 self.sp_param_last.ctypes.data_as(dp), self.segments.ctypes.data_as(dp),
-                                                 self.segment_lengths.ctypes.data_as(dp),
-                                                 self.lut_distances.ctypes.data_as(dp),
-                                                 self.lut_parameters.ctypes.data_as(dp)), "vap_route_get_splines")
+        self.lut_samples, self.samples_per_node = _lib.LUT_SAMPLES, _lib.LUT_SAMPLES
+        self._fetch_tables(with_splines=True)
+
+    def _fetch_tables(self, with_splines=False):
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+        n = self.n_splines
+        self.lut_distances = np.zeros(n * self.lut_samples)
+        self.lut_parameters = np.zeros(n * self.lut_samples)
+        _lib.check(self._L.vap_route_get_splines(
+            self.handle,
+            self.sp_start.ctypes.data_as(ip) if with_splines else None,
+            self.sp_npts.ctypes.data_as(ip) if with_splines else None,
+            self.sp_param_last.ctypes.data_as(dp) if with_splines else None,
+            self.segments.ctypes.data_as(dp) if with_splines else None,
+            self.segment_lengths.ctypes.data_as(dp) if with_splines else None,
+            self.lut_distances.ctypes.data_as(dp), self.lut_parameters.ctypes.data_as(dp)), "vap_route_get_splines")
+
+    def set_table_sizes(self, lut_samples=None, samples_per_node=None):
+        """build_lookup_table(min_samples) / precompute_path_properties(samples_per_node) with other sizes than the
+        reference's defaults (SM:426-427, 477): the device rebuilds the route's tables."""
+        ls = self.lut_samples if lut_samples is None else int(lut_samples)
+        sn = self.samples_per_node if samples_per_node is None else int(samples_per_node)
+        if (ls, sn) == (self.lut_samples, self.samples_per_node):
+            return
+        _lib.check(self._L.vap_route_set_table_sizes(self.handle, ls, sn), "vap_route_set_table_sizes")
+        changed = ls != self.lut_samples
+        self.lut_samples, self.samples_per_node = ls, sn
+        if changed:
+            ns, tot = C.c_int(), C.c_double()
+            _lib.check(self._L.vap_route_info(self.handle, C.byref(ns), C.byref(tot)), "vap_route_info")
+            self.total = tot.value
+            self._fetch_tables()
 
     def close(self):
         if getattr(self, "handle", None):

@@ -39,7 +39,7 @@ EXPORTS = (
     "vap_ctx_set_timing",
     "vap_last_timing", "vap_fit", "vap_build_lut", "vap_sample", "vap_velocity_pass",
     "vap_time_profile", "vap_profile_batch", "vap_profile_batch_host", "vap_eval_host", "vap_lookup_host",
-    "vap_route_create", "vap_route_destroy", "vap_route_info", "vap_route_get_splines", "vap_route_eval",
+    "vap_route_create", "vap_route_destroy", "vap_route_info", "vap_route_set_table_sizes", "vap_route_table_sizes", "vap_route_get_splines", "vap_route_eval",
     "vap_route_lookup", "vap_route_sample_count", "vap_route_forward_backward", "vap_route_motion_profile",
     "vap_grid_distances", "vap_route_limits", "vap_velocity_pass_limits", "vap_time_insert_waits", "vap_fit_ex",
     "vap_profile_routes", "vap_time_profile_routes", "vap_time_insert_events",
@@ -132,6 +132,8 @@ def lib():
     L.vap_route_create.argtypes = [vp, C.POINTER(RouteDesc), C.POINTER(vp)]
     L.vap_route_destroy.argtypes = [vp]
     L.vap_route_info.argtypes = [vp, ip, dp]
+    L.vap_route_set_table_sizes.argtypes = [vp, C.c_int, C.c_int]
+    L.vap_route_table_sizes.argtypes = [vp, ip, ip]
     L.vap_route_get_splines.argtypes = [vp, ip, ip, dp, dp, dp, dp, dp]
     L.vap_route_eval.argtypes = [vp, C.c_int, C.c_int, dp, dp]
     L.vap_route_lookup.argtypes = [vp, C.c_int, C.c_int, dp, dp]

@@ -266,15 +266,20 @@ __device__ __forceinline__ void lutv_map_parameter(const LutView &v, int W, doub
 // SM:550-580 _interpolate_property reduced to what it always does (a step lookup):
 // returns the index into the linspace(0, W-1, 1000*W) property table that the reference reads for
 // parameter t.  tab_n = 1000*W, end_param = W-1.
-__device__ __forceinline__ int table_index(double t, int tab_n, double end_param)
+// np.searchsorted(linspace(0, end_param, tab_n), t) (side "left"; t <= end_param): first j with tp[j] >= t
+__device__ __forceinline__ int table_search(double t, int tab_n, double end_param)
 {
     const double step = end_param / (double)(tab_n - 1);
-    // searchsorted-left over tp[j] = j*step (tp[tab_n-1] = end_param): first j with tp[j] >= t
     long j = (long)ceil(t / step);
     if (j < 0) j = 0;
     if (j > tab_n - 1) j = tab_n - 1;
     while (j > 0 && linspace_at(end_param, tab_n, (int)(j - 1)) >= t) j--;
     while (j < tab_n - 1 && linspace_at(end_param, tab_n, (int)j) < t) j++;
+    return (int)j;
+}
+__device__ __forceinline__ int table_index(double t, int tab_n, double end_param)
+{
+    const int j = table_search(t, tab_n, end_param);
     if (j == 0) return 0;
     const double frac = t - floor(t);  // t % 1 for t >= 0
     return (int)(frac > 0.5 ? j - 1 : j);

@@ -33,7 +33,10 @@ struct RouteDev {
     int *sp_start, *sp_npts, *sp_seg0;         // [W]
     double *sp_tmax, *sp_dist0, *sp_param0;    // [W]
     double *seg, *seglen;                      // [W-1][12], [W-1]
-    double *lut;                               // [n_splines][1000] partial distances
+    double *lut;                               // [n_splines][lut_n] partial distances
+    double *lut_mag;                           // [n_splines][lut_n] scratch of the table build (sizes other than 1000)
+    int lut_n;                                 // samples per spline of the arc-length table   (SM:427 min_samples)
+    int spn;                                   // property-table entries per node               (SM:477 samples_per_node)
     double *info;                              // [0]=n_splines [1]=total [2]=status
 };
 
@@ -188,31 +191,38 @@ __global__ void k_route_fit(RouteDev r, double *work)
     r.info[2] = (double)status;
 }
 
-// SM:426-475, one workgroup per spline: partial (un-offset) distances of that spline
+// SM:426-475, one workgroup per spline: partial (un-offset) distances of that spline.  The default 1000-sample table
+// is built in LDS; any other min_samples (vap_route_set_table_sizes) goes through the global scratch r.lut_mag —
+// same operations in the same order (np.linspace, the trapezoid increments, np.cumsum's sequential sum).
 __global__ __launch_bounds__(256) void k_route_lut(RouteDev r)
 {
     constexpr int kPad = (kLutN + 15) / 16 * 16;
-    __shared__ double mag[kPad], cum[kPad];
+    __shared__ double mag_s[kPad], cum_s[kPad];
     const int si = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int n = r.lut_n;
+    const bool in_lds = n == kLutN;
+    double *mag = in_lds ? mag_s : r.lut_mag + (size_t)si * n;
+    double *cum = in_lds ? cum_s : r.lut + (size_t)si * n;
     const int G = r.sp_npts[si] - 1;
     const double t_max = r.sp_tmax[si];
     const double *seg = r.seg + (size_t)r.sp_seg0[si] * 12;
-    for (int j = tid; j < kLutN; j += nt) {
-        const double t = linspace_at(t_max, kLutN, j);
+    for (int j = tid; j < n; j += nt) {
+        const double t = linspace_at(t_max, n, j);
         double dx, dy;
         hermite_eval_ref(seg, t_max, G, 1, t, dx, dy);
         mag[j] = sqrt(dx * dx + dy * dy);
     }
     __syncthreads();
-    const double dt = linspace_at(t_max, kLutN, 1) - linspace_at(t_max, kLutN, 0);
-    for (int j = tid; j < kPad; j += nt) cum[j] = (j > 0 && j < kLutN) ? (mag[j - 1] + mag[j]) * 0.5 * dt : 0.0;
+    const double dt = linspace_at(t_max, n, 1) - linspace_at(t_max, n, 0);
+    for (int j = tid; j < n; j += nt) cum[j] = (j > 0) ? (mag[j - 1] + mag[j]) * 0.5 * dt : 0.0;
     __syncthreads();
     if (tid == 0) {
         double acc = 0.0;
-        for (int j = 0; j < kLutN; j++) { acc += cum[j]; cum[j] = acc; }
+        for (int j = 0; j < n; j++) { acc += cum[j]; cum[j] = acc; }
     }
     __syncthreads();
-    for (int j = tid; j < kLutN; j += nt) r.lut[(size_t)si * kLutN + j] = cum[j];
+    if (in_lds)
+        for (int j = tid; j < n; j += nt) r.lut[(size_t)si * n + j] = cum[j];
 }
 
 // SM:456-464: distance / parameter offsets of the concatenated table
@@ -224,7 +234,7 @@ __global__ void k_route_offsets(RouteDev r)
     for (int si = 0; si < n; si++) {
         r.sp_dist0[si] = current_dist;
         r.sp_param0[si] = prev_param;
-        current_dist = r.lut[(size_t)si * kLutN + kLutN - 1] + current_dist;   // spline_distances[-1]
+        current_dist = r.lut[(size_t)si * r.lut_n + r.lut_n - 1] + current_dist;   // spline_distances[-1]
         prev_param += r.sp_tmax[si] - 0.0;
     }
     r.info[1] = current_dist;
@@ -249,13 +259,13 @@ __device__ __forceinline__ void route_eval(const RouteDev &r, int n_spl, double 
 // lookup_table.distances / parameters entry e of the concatenated table (SM:457-462)
 __device__ __forceinline__ double route_lut_d(const RouteDev &r, int e)
 {
-    const int si = e / kLutN, j = e % kLutN;
-    return r.lut[(size_t)si * kLutN + j] + r.sp_dist0[si];
+    const int si = e / r.lut_n, j = e % r.lut_n;
+    return r.lut[(size_t)si * r.lut_n + j] + r.sp_dist0[si];
 }
 __device__ __forceinline__ double route_lut_p(const RouteDev &r, int e)
 {
-    const int si = e / kLutN, j = e % kLutN;
-    return linspace_at(r.sp_tmax[si], kLutN, j) + r.sp_param0[si];
+    const int si = e / r.lut_n, j = e % r.lut_n;
+    return linspace_at(r.sp_tmax[si], r.lut_n, j) + r.sp_param0[si];
 }
 
 // SM:291-318
@@ -263,7 +273,7 @@ __device__ double route_distance_to_time(const RouteDev &r, int n_spl, double to
 {
     if (s <= 0) return 0.0;
     if (s >= total) return (double)(r.W - 1);
-    int lo = 0, hi = n_spl * kLutN;
+    int lo = 0, hi = n_spl * r.lut_n;
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
         if (route_lut_d(r, mid) < s) lo = mid + 1;
@@ -275,13 +285,10 @@ __device__ double route_distance_to_time(const RouteDev &r, int n_spl, double to
     return t0 + (t1 - t0) * (s - d0) / (d1 - d0);
 }
 
-// SM:332-346, 550-580: step lookup into the (never materialised) property table
-__device__ double route_property(const RouteDev &r, int n_spl, double t, int which /*1 curvature, 2 heading*/)
+// SM:332-346, 550-580 on the (never materialised) property table: entry jj of linspace(0, W-1, spn*W)
+__device__ double route_property_entry(const RouteDev &r, int n_spl, int tab_n, int jj, int which)
 {
-    const double end_param = (double)(r.W - 1);
-    const int tab_n = r.W * kSamplesPerNode;
-    const int jj = table_index(t, tab_n, end_param);
-    const double tp = linspace_at(end_param, tab_n, jj);
+    const double tp = linspace_at((double)(r.W - 1), tab_n, jj);
     double d1x, d1y;
     route_eval(r, n_spl, tp, 1, d1x, d1y);
     if (which == 2) return atan2(d1y, d1x);
@@ -290,6 +297,25 @@ __device__ double route_property(const RouteDev &r, int n_spl, double t, int whi
     const double ss = d1x * d1x + d1y * d1y;
     const double num = d1x * d2y - d1y * d2x;
     return (ss >= 1e-10) ? num / (ss * sqrt(ss)) : 0.0;
+}
+// _interpolate_property in full (SM:550-580).  With the default samples_per_node the two neighbouring table
+// parameters never have equal fractional parts (their distance is below 1), so the reference always takes the step
+// lookup at SM:577-578 — what table_index returns and what the batched kernels build on.  Only a table with one
+// entry per node (samples_per_node = 1: the parameters are the integers) reaches the linear interpolation.
+__device__ double route_property(const RouteDev &r, int n_spl, double t, int which /*1 curvature, 2 heading*/)
+{
+    const double end_param = (double)(r.W - 1);
+    const int tab_n = r.W * r.spn;
+    const int idx = table_search(t, tab_n, end_param);
+    if (idx == 0) return route_property_entry(r, n_spl, tab_n, 0, which);
+    const double t0 = linspace_at(end_param, tab_n, idx - 1), t1 = linspace_at(end_param, tab_n, idx);
+    if (t0 - floor(t0) != t1 - floor(t1)) {
+        const double frac = t - floor(t);   // t % 1 for t >= 0
+        return route_property_entry(r, n_spl, tab_n, frac > 0.5 ? idx - 1 : idx, which);
+    }
+    const double v0 = route_property_entry(r, n_spl, tab_n, idx - 1, which);
+    const double v1 = route_property_entry(r, n_spl, tab_n, idx, which);
+    return v0 + (v1 - v0) * (t - t0) / (t1 - t0);
 }
 
 __global__ void k_route_eval(RouteDev r, int order, int n, const double *__restrict__ t, double *__restrict__ out)
@@ -590,6 +616,7 @@ struct vap_route {
     int W = 0, M = 0, n_splines = 0;
     double total = 0.0;
     void *blob = nullptr;   // one device allocation holding everything below
+    void *lut_blob = nullptr;   // arc-length table of a size other than the default (vap_route_set_table_sizes)
     vap::RouteDev d{};
     // cached distance-domain result of the last forward_backward call
     int N = 0;
@@ -678,6 +705,9 @@ int vap_route_create(vap_ctx *ctx, const vap_route_desc *desc, vap_route **out)
     d.info = carve<double>(p, 8);
     double *fitwork = carve<double>(p, 9 * (size_t)W);
     d.lut = carve<double>(p, (size_t)(W - 1) * vap::kLutN);
+    d.lut_mag = nullptr;
+    d.lut_n = vap::kLutN;
+    d.spn = vap::kSamplesPerNode;
     d.wp = wp; d.turn = turn; d.wait = wait; d.maxv = maxv; d.maxa = maxa; d.tangent = tan; d.mag = mag;
     d.ap_t = apt; d.ap_wait = apw; d.ap_maxv = apv; d.ap_maxa = apa; d.rev = rev; d.stop = stop; d.ap_stop = aps;
 #define UP(dst, vec) if (!(vec).empty() && hipMemcpyAsync(dst, (vec).data(), (vec).size() * sizeof((vec)[0]), hipMemcpyHostToDevice, st) != hipSuccess) goto hip_fail
@@ -713,8 +743,49 @@ int vap_route_destroy(vap_route *rt)
     if (!rt) return VAP_OK;
     if (rt->ctx) (void)hipSetDevice(rt->ctx->device);
     if (rt->blob) (void)hipFree(rt->blob);
+    if (rt->lut_blob) (void)hipFree(rt->lut_blob);
     if (rt->work) (void)hipFree(rt->work);
     delete rt;
+    return VAP_OK;
+}
+
+int vap_route_set_table_sizes(vap_route *rt, int lut_samples, int samples_per_node)
+{
+    if (!rt) return vap_fail(VAP_ERR_INVALID, "null route");
+    if (lut_samples < 2 || samples_per_node < 1)
+        return vap_fail(VAP_ERR_INVALID, "table sizes: min_samples >= 2 (np.linspace + the [1] - [0] step, SM:443-444) and "
+                                         "samples_per_node >= 1");
+    if ((long long)lut_samples * (rt->W - 1) > (1LL << 27) || (long long)samples_per_node * rt->W > (1LL << 30))
+        return vap_fail(VAP_ERR_INVALID, "table sizes out of range");
+    VAP_TRY(vap_set_device(rt->ctx));
+    hipStream_t st = rt->ctx->stream;
+    rt->d.spn = samples_per_node;
+    rt->N = 0;   // a cached distance-domain result belongs to the old tables
+    if (lut_samples == rt->d.lut_n) return VAP_OK;
+    HIP_TRY(hipStreamSynchronize(st));
+    void *nb = nullptr;
+    const size_t per = (size_t)(rt->W - 1) * lut_samples;
+    HIP_TRY(hipMalloc(&nb, sizeof(double) * 2 * per));
+    if (rt->lut_blob) (void)hipFree(rt->lut_blob);
+    rt->lut_blob = nb;
+    rt->d.lut = (double *)nb;
+    rt->d.lut_mag = (double *)nb + per;
+    rt->d.lut_n = lut_samples;
+    hipLaunchKernelGGL(vap::k_route_lut, dim3(rt->n_splines), dim3(256), 0, st, rt->d);
+    hipLaunchKernelGGL(vap::k_route_offsets, dim3(1), dim3(1), 0, st, rt->d);
+    HIP_TRY(hipGetLastError());
+    double info[8];
+    HIP_TRY(hipMemcpyAsync(info, rt->d.info, sizeof(info), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    rt->total = info[1];
+    return VAP_OK;
+}
+
+int vap_route_table_sizes(vap_route *rt, int *lut_samples, int *samples_per_node)
+{
+    if (!rt) return vap_fail(VAP_ERR_INVALID, "null route");
+    if (lut_samples) *lut_samples = rt->d.lut_n;
+    if (samples_per_node) *samples_per_node = rt->d.spn;
     return VAP_OK;
 }
 
@@ -740,7 +811,8 @@ int vap_route_get_splines(vap_route *rt, int *h_start, int *h_npts, double *h_pa
     if (h_segment_lengths) HIP_TRY(hipMemcpyAsync(h_segment_lengths, rt->d.seglen, sizeof(double) * (W - 1), hipMemcpyDeviceToHost, st));
     if (h_lut_distances || h_lut_parameters) {
         // the concatenated table of SM:456-475 (offsets applied exactly as the lookups apply them)
-        const size_t ne = (size_t)n * vap::kLutN;
+        const int LN = rt->d.lut_n;
+        const size_t ne = (size_t)n * LN;
         std::vector<double> lut(ne), dist0(n), par0(n), tmax(n);
         HIP_TRY(hipMemcpyAsync(lut.data(), rt->d.lut, sizeof(double) * ne, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(dist0.data(), rt->d.sp_dist0, sizeof(double) * n, hipMemcpyDeviceToHost, st));
@@ -748,12 +820,12 @@ int vap_route_get_splines(vap_route *rt, int *h_start, int *h_npts, double *h_pa
         HIP_TRY(hipMemcpyAsync(tmax.data(), rt->d.sp_tmax, sizeof(double) * n, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         for (int si = 0; si < n; si++)
-            for (int j = 0; j < vap::kLutN; j++) {
-                const size_t e = (size_t)si * vap::kLutN + j;
+            for (int j = 0; j < LN; j++) {
+                const size_t e = (size_t)si * LN + j;
                 if (h_lut_distances) h_lut_distances[e] = lut[e] + dist0[si];
                 if (h_lut_parameters) {
-                    const double step = tmax[si] / (double)(vap::kLutN - 1);
-                    h_lut_parameters[e] = (j == vap::kLutN - 1 ? tmax[si] : (double)j * step) + par0[si];
+                    const double step = tmax[si] / (double)(LN - 1);
+                    h_lut_parameters[e] = (j == LN - 1 ? tmax[si] : (double)j * step) + par0[si];
                 }
             }
     }

@@ -13,6 +13,7 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
+from .. import _lib
 from .._device_path import DeviceRoute
 from .quintic_hermite_spline import QuinticHermiteSpline
 
@@ -116,21 +117,27 @@ class QuinticHermiteSplineManager:
 
     # -- tables ---------------------------------------------------------------------------------------
     def build_lookup_table(self, min_samples=1000, max_samples=20000, tolerance=1e-6) -> None:
+        """SM:426-475.  The table is built on the device (with the fit for the default size; any other min_samples
+        makes the device rebuild it, vap_route_set_table_sizes).  max_samples / tolerance are unused in the reference
+        too."""
         if not self.splines:
             raise ValueError("No splines initialized")
-        if min_samples != 1000:
-            raise NotImplementedError("the device table has the reference's default 1000 samples")
-        r = self._route   # the table was built on the device together with the fit
+        r = self._route
+        try:
+            r.set_table_sizes(lut_samples=min_samples)
+        except _lib.VapError as e:
+            if e.status == _lib.VAP_ERR_INVALID:
+                raise IndexError("index 1 is out of bounds for axis 0 with size %d" % max(int(min_samples), 0))  # SM:444
+            raise
         self.lookup_table = PathLookupTable(distances=r.lut_distances, parameters=r.lut_parameters,
                                             total_length=r.total)
 
     def precompute_path_properties(self, samples_per_node: int = 1000) -> None:
-        """The reference fills 1000*len(nodes) curvature/heading entries here (SM:477-548); the device
+        """The reference fills samples_per_node*len(nodes) curvature/heading entries here (SM:477-548); the device
         path evaluates the one entry a lookup needs on demand, so only the table geometry is kept."""
         if not self.splines:
             raise ValueError("No splines initialized")
-        if samples_per_node != 1000:
-            raise NotImplementedError("the device lookup uses the reference's default 1000 samples per node")
+        self._route.set_table_sizes(samples_per_node=samples_per_node)
         self._precomputed_properties = {"samples": len(self.nodes) * samples_per_node, "on_demand": True}
 
     def rebuild_tables(self):
