@@ -162,6 +162,8 @@ def main():
                     help="paths of rank 0's batch checked against the CPU oracle after the timed region (0 = skip)")
     ap.add_argument("--paths-per-gpu", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-mode", action="store_true",
+                    help="skip the after-the-fact measurement of the other recurrence arithmetic (fp32 rows, N = 1)")
     ap.add_argument("--time-domain", action="store_true",
                     help="also time the batched time-domain resample (vap_time_profile) after the timed region")
     ap.add_argument("--tolerance-sweep", action="store_true",
@@ -278,6 +280,28 @@ def main():
     if rank == 0 and args.parity_paths > 0:
         parity = parity_check(out, wp, S, constraints, min(args.parity_paths, B), args.dtype)
 
+    # after the timed region, N = 1, fp32 rows only: the OTHER recurrence arithmetic on the same batch, for the record —
+    # never `value`.  (default mode: fp64 recurrence, holds 1e-5 everywhere; "f32": round 1's, faster, leaves the bound)
+    other_mode = None
+    if world == 1 and args.dtype == "f32" and not args.no_other_mode:
+        orec = "f32" if args.recurrence == "f64" else "f64"
+        ogen = BatchedTrajectoryGenerator(local_rank, "f32", recurrence=orec)
+        oout = None
+        for _ in range(2):
+            oout = ogen.profile(wp, constraints=constraints, samples=S, out=oout)
+        torch.cuda.synchronize(dev)
+        k = max(3, min(args.steps, 10))
+        t1 = time.perf_counter()
+        for _ in range(k):
+            oout = ogen.profile(wp, constraints=constraints, samples=S, out=oout)
+        torch.cuda.synchronize(dev)
+        oms = (time.perf_counter() - t1) / k * 1e3
+        other_mode = {"recurrence": "f64 behind fp32 rows" if orec == "f64" else "f32", "ms_per_step": oms,
+                      "value": B * S / (oms * 1e-3), "steps": k}
+        if args.parity_paths > 0:
+            other_mode["parity"] = parity_check(oout, wp, S, constraints, min(args.parity_paths, B), "f32")
+        del ogen, oout
+
     # BASELINE config 5, "fp64 vs fp32 tolerance sweep": this rank's whole batch in every mode, compared on the device
     sweep = None
     if args.tolerance_sweep:
@@ -326,6 +350,8 @@ def main():
         }
         if parity is not None:
             line["parity"] = parity
+        if other_mode is not None:
+            line["other_mode"] = other_mode
         if sweep is not None:
             line["tolerance_sweep"] = sweep
         if time_domain is not None:
