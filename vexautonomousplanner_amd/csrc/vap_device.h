@@ -990,8 +990,34 @@ __device__ __forceinline__ int grid_index(double x, double dd, double inv_dd, in
     if (!(e >= -1.0)) e = -1.0;            // also NaN
     if (e > (double)(n - 1)) e = (double)(n - 1);
     int i = (int)e;
-    while (i + 1 < n && (double)(i + 1) * dd <= x) i++;
-    while (i >= 0 && !((double)i * dd <= x)) i--;
+    // The answer is the i in [-1, n-1] with i*dd <= x < (i+1)*dd (products as rounded).  x*inv_dd is within 2^-52 of
+    // x/dd relatively, so the floor is off by at most one: one step up, one step down, selects only — the two
+    // `while` loops this replaces compiled to ~50 instructions each and were most of a time step of k_time_integrate.
+    // The loops remain behind a check of the two conditions (never taken for finite input).
+    // (bitwise & and |: the products are evaluated unconditionally, no short-circuit branches)
+    const bool up = (i + 1 < n) & ((double)(i + 1) * dd <= x);
+    i += up ? 1 : 0;
+    const bool down = (i >= 0) & !((double)i * dd <= x);
+    i -= down ? 1 : 0;
+    const bool ok = ((i + 1 >= n) | !((double)(i + 1) * dd <= x)) & ((i < 0) | ((double)i * dd <= x));
+    if (__builtin_expect(!ok, 0)) {
+        while (i + 1 < n && (double)(i + 1) * dd <= x) i++;
+        while (i >= 0 && !((double)i * dd <= x)) i--;
+    }
+    return i;
+}
+
+// grid_index from a guess (the time loop: the position one grid step ahead lands one sample further) — the same
+// answer by the same two conditions, without the multiplication / floor / clamps of the general entry.
+__device__ __forceinline__ int grid_index_from(double x, double dd, double inv_dd, int n, int guess)
+{
+    int i = guess < -1 ? -1 : (guess > n - 1 ? n - 1 : guess);
+    const bool up = (i + 1 < n) & ((double)(i + 1) * dd <= x);
+    i += up ? 1 : 0;
+    const bool down = (i >= 0) & !((double)i * dd <= x);
+    i -= down ? 1 : 0;
+    const bool ok = ((i + 1 >= n) | !((double)(i + 1) * dd <= x)) & ((i < 0) | ((double)i * dd <= x));
+    if (__builtin_expect(!ok, 0)) return grid_index(x, dd, inv_dd, n);
     return i;
 }
 

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(64) void k_time_integrate(int B, int S, const doubl
         // MPG:566-570: mean of the profile at the current position and one grid step ahead.  The four
         // samples are fetched together: one memory round trip per step instead of two.
         const double ahead = current_pos + dd;
-        const int i0 = grid_index(current_pos, dd, inv_dd, N), i1 = grid_index(ahead, dd, inv_dd, N);
+        const int i0 = grid_index(current_pos, dd, inv_dd, N), i1 = grid_index_from(ahead, dd, inv_dd, N, i0 + 1);
         const double a0 = (double)v[clamp_index(i0, N)], a1 = (double)v[clamp_index(i0 + 1, N)];
         const double c0 = (double)v[clamp_index(i1, N)], c1 = (double)v[clamp_index(i1 + 1, N)];
         double target_vel = lerp_at(current_pos, dd, i0, N, a0, a1);
