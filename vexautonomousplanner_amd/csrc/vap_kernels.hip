@@ -323,14 +323,19 @@ __global__ __launch_bounds__(kLutManyThreads) void k_lut_many(int B, int W, cons
     constexpr int P = kLutManyPaths, TE = kLutManyTile, ST = TE + 1;   // row stride 33: lane = path reads hit 64 banks
     extern __shared__ __attribute__((aligned(16))) double s_seg[];     // the 64 paths' segment rows: P * G * 12
     __shared__ double s_mag[P * ST], s_inc[P * ST];
-    __shared__ double s_prev_mag[P], s_carry[P], s_prev_cum[P], s_tmax[P];
+    __shared__ double s_prev_mag[P], s_carry[P], s_prev_cum[P], s_tmax[P], s_step[P];
     const int tid = threadIdx.x, b0 = blockIdx.x * P;
     const int G = W - 1;
     const int n_paths = B - b0 < P ? B - b0 : P;
     lds_fill<4>(s_seg, segments + (size_t)b0 * G * 12, n_paths * G * 12, tid, kLutManyThreads);
     if (tid < P) {
         s_prev_mag[tid] = 0.0; s_carry[tid] = 0.0; s_prev_cum[tid] = 0.0;
-        s_tmax[tid] = tid < n_paths ? meta[(size_t)(b0 + tid) * kMetaStride + 0] : 1.0;
+        const double tm = tid < n_paths ? meta[(size_t)(b0 + tid) * kMetaStride + 0] : 1.0;
+        s_tmax[tid] = tm;
+        // np.linspace's step (SM:443), once per path: the per-entry expressions below used to repeat this division —
+        // and its twin in dt and in the slope — for every one of the 1000 entries (five IEEE divisions per entry
+        // where one is needed)
+        s_step[tid] = tm / (double)(kLutN - 1);
     }
     __syncthreads();
     constexpr int kTiles = (kLutN + TE - 1) / TE;
@@ -344,7 +349,7 @@ __global__ __launch_bounds__(kLutManyThreads) void k_lut_many(int B, int W, cons
             double m = 0.0;
             if (b < B && j < kLutN) {
                 const double t_max = s_tmax[p];
-                const double t = linspace_at(t_max, kLutN, j);
+                const double t = (j == kLutN - 1) ? t_max : (double)j * s_step[p];   // linspace_at(t_max, kLutN, j)
                 double lt;
                 int idx;
                 normalize_parameter(t, t_max, G, lt, idx);
@@ -361,8 +366,7 @@ __global__ __launch_bounds__(kLutManyThreads) void k_lut_many(int B, int W, cons
             const int it = tid + r * kLutManyThreads, p = it / TE, e = it % TE, j = j0 + e, b = b0 + p;
             double inc = 0.0;
             if (b < B && j > 0 && j < kLutN) {
-                const double t_max = s_tmax[p];
-                const double dt = linspace_at(t_max, kLutN, 1) - linspace_at(t_max, kLutN, 0);   // SM:444
+                const double dt = (double)1 * s_step[p] - (double)0 * s_step[p];   // SM:444: local_params[1] - local_params[0]
                 const double mp = e > 0 ? s_mag[p * ST + e - 1] : s_prev_mag[p];
                 inc = (mp + s_mag[p * ST + e]) * 0.5 * dt;
             }
@@ -401,7 +405,7 @@ __global__ __launch_bounds__(kLutManyThreads) void k_lut_many(int B, int W, cons
                     double w = 0.0;
                     if (j > 0) {
                         const double t_max = s_tmax[p];
-                        const double lstep = t_max / (double)(kLutN - 1);
+                        const double lstep = s_step[p];
                         const double t0 = (double)(j - 1) * lstep, t1 = (j == kLutN - 1) ? t_max : (double)j * lstep;
                         const double cp = e > 0 ? s_mag[p * ST + e - 1] : s_prev_cum[p];
                         w = (t1 - t0) / (c - cp);
