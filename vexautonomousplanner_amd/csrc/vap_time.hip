@@ -22,12 +22,14 @@ namespace vap {
 constexpr int kRowWidth = 8;   // time, position, velocity, acceleration, heading, angular velocity, x, y
 
 // One lane per path (the recurrence is scalar and sequential, so a lane is all a path can use; the
-// instruction stream of a step is shared by the 64 paths of a wavefront).  The two lerps of a step read
-// the path's velocity row where the position stands — a dependent access, but consecutive steps stay
-// within a few cache lines of each other, so it is served by L2.  Variants measured on config 3
-// (4096 paths, ~1280 steps each): this one 2.5 ms; one wavefront per path with an LDS window of the
-// row 4.7 ms (64 lanes repeat the same arithmetic: issue-bound); per-lane LDS windows refilled
-// wave-wide 6.9 ms (some lane's window runs out nearly every step).
+// instruction stream of a step is shared by the 64 paths of a wavefront).  A step is ~240 instructions
+// issued by a single wavefront per SIMD, i.e. bound by instruction count times issue latency (SQ counters,
+// round 2: 342 VALU + 163 SALU per step before grid_index lost its two `while` loops).  The two lerps of a
+// step read the path's velocity row where the position stands; consecutive steps stay within a few cache
+// lines of each other, so L2 serves them (a quarter of a step's time).  Variants measured on config 3
+// (4096 paths, ~1280 steps each): this one 1.6 ms (2.5 ms with the loops); eight lanes per path with a
+// prefetched LDS ring of the row 2.4 ms against 2.5 (before the loops went: the arithmetic hid the gain); one
+// wavefront per path with an LDS window 4.7 ms; per-lane LDS windows refilled wave-wide 6.9 ms.
 template <typename R>
 __global__ __launch_bounds__(64) void k_time_integrate(int B, int S, const double *__restrict__ meta,
                                                        const R *__restrict__ vel, double max_acc, double max_dec,
