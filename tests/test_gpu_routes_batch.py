@@ -263,3 +263,27 @@ def test_bad_routes_are_flagged(torch_mod):
     st = gen._L.vap_time_profile(gen.ctx.handle, gen.vdtype, 3, 6, 4000, None, None, p(r["meta"]), p(r["velocity"]), C.byref(c), 0.01, 512,
                                  p(rows), p(counts), p(nmap), p(r["flags"]))
     assert st == _lib.VAP_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_routes_without_splits_equal_the_plain_path_bit_for_bit(torch_mod, dtype):
+    """profile_routes on a batch in which no node splits (max_splines == 1) goes through the plain path's kernels:
+    the rows equal BatchedTrajectoryGenerator.profile's bit for bit, and node limits / the time domain work on it."""
+    torch = torch_mod
+    from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
+    gen = make_gen(dtype)
+    B, W, S = 37, 8, 2000
+    wp = torch.tensor(make_waypoints(B, W, 77), dtype=gen.tdtype, device=gen.device)
+    plain = {k: v.clone() for k, v in gen.profile(wp, DEFAULT_CONSTRAINTS, samples=S).items()}
+    none = np.zeros((B, W), dtype=bool)
+    r = gen.profile_routes(wp, node_reverse=none, node_turn=np.zeros((B, W)), constraints=DEFAULT_CONSTRAINTS, samples=S)
+    torch.cuda.synchronize()
+    assert int(r["spline_counts"].max()) == 1
+    for k in ("x", "y", "heading", "curvature", "velocity", "meta", "flags"):
+        assert torch.equal(r[k], plain[k]), k
+    mv = np.zeros((B, W))
+    mv[:, 3] = 2.0
+    gen.apply_node_limits(r, DEFAULT_CONSTRAINTS, node_max_velocity=mv)
+    tp = gen.time_profile(r, DEFAULT_CONSTRAINTS, dt=0.01, capacity_rows=4096, node_reverse=none)
+    torch.cuda.synchronize()
+    assert int(tp["counts"][:, 0].min()) > 50 and not r["flags"].any().item()

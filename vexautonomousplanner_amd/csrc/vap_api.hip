@@ -499,15 +499,27 @@ int vap_profile_routes(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double d
     rt.sptab = sptab;
     rt.nspl = nspl;
     rt.NS = NS;
-    HIP_TRY(vap::launch_lut(ctx->stream, B, W, (const double *)ctx->seg.ptr, (double *)ctx->lut.ptr, nullptr, meta, flags,
-                            vap::GridArgs(), rt));
+    // No route of the batch has a split (max_splines == 1: tangent overrides at most): every route is one spline with
+    // zero offsets, i.e. a plain path — the persistent sampling kernel of vap_profile_batch takes it (it wants the
+    // interval slopes next to the table), same rows bit for bit as that entry point and 3-4x faster than the
+    // thread-per-sample kernel the concatenated tables need.
+    const bool single = NS == 1;
+    if (single) VAP_TRY(ctx->ensure(ctx->slopes, (size_t)B * VAP_LUT_SAMPLES * sizeof(double)));
+    HIP_TRY(vap::launch_lut(ctx->stream, B, W, (const double *)ctx->seg.ptr, (double *)ctx->lut.ptr,
+                            single ? (double *)ctx->slopes.ptr : nullptr, meta, flags, vap::GridArgs(), rt));
     HIP_TRY(vap::launch_route_offsets(ctx->stream, B, W, NS, S, dd, (const double *)ctx->lut.ptr, sptab, nspl, meta,
                                       (double *)ctx->aux.ptr, (double *)ctx->runs.ptr, flags));
     tm.mark(VAP_T_LUT);
-    HIP_TRY(vap::launch_sample_routes(ctx->stream, f64, B, W, NS, S, (const double *)ctx->power.ptr, (const double *)ctx->lut.ptr,
-                                      sptab, nspl, meta, (const double *)ctx->aux.ptr, (const double *)ctx->runs.ptr, d_x, d_y,
-                                      d_heading, curv, hi ? nullptr : ctx->dth.ptr, hi ? (double *)ctx->k64.ptr : nullptr,
-                                      hi ? (double *)ctx->dth64.ptr : nullptr));
+    if (single)
+        HIP_TRY(vap::launch_sample(ctx->stream, f64, B, W, S, (const double *)ctx->power.ptr, (const double *)ctx->lut.ptr,
+                                   (const double *)ctx->slopes.ptr, meta, (const double *)ctx->aux.ptr,
+                                   (const double *)ctx->runs.ptr, d_x, d_y, d_heading, curv, hi ? nullptr : ctx->dth.ptr,
+                                   hi ? (double *)ctx->k64.ptr : nullptr, hi ? (double *)ctx->dth64.ptr : nullptr));
+    else
+        HIP_TRY(vap::launch_sample_routes(ctx->stream, f64, B, W, NS, S, (const double *)ctx->power.ptr, (const double *)ctx->lut.ptr,
+                                          sptab, nspl, meta, (const double *)ctx->aux.ptr, (const double *)ctx->runs.ptr, d_x, d_y,
+                                          d_heading, curv, hi ? nullptr : ctx->dth.ptr, hi ? (double *)ctx->k64.ptr : nullptr,
+                                          hi ? (double *)ctx->dth64.ptr : nullptr));
     tm.mark(VAP_T_SAMPLE);
     if (hi)
         VAP_TRY(run_velocity(ctx, true, false, B, S, cc, start_vel, end_vel, meta, ctx->k64.ptr, ctx->dth64.ptr, nullptr,
