@@ -236,46 +236,102 @@ __global__ void k_route_offsets(int B, int W, int NS, int S, double dd, const do
     grid_define_route(b, W, S, dd, current_dist, meta, aux, runs, flags);
 }
 
-// K3+K4 for routes: a thread per sample (the plain kernel's four-sample walk relies on one table).  fp64 index path,
-// the exact step lookup (table_index), coefficient blocks for the evaluations: the same arithmetic as k_sample.
+// K3+K4 for routes: four consecutive samples per thread, 1024 per workgroup.  The concatenated table stays in HBM / L2
+// (up to W-1 splines x 8 KB per route: too much to stage per workgroup), but a thread searches it once — the spline by
+// the distance offsets, then that spline's 1000 entries — and walks on from there for its other three samples; the
+// spline table and the linspace step of every spline sit in LDS.  Same arithmetic as the general functions of
+// vap_device.h (lutv_distance_to_time, table_index, lutv_map_parameter): np.searchsorted-left over the concatenated
+// distances, the reference's lerp, the exact step lookup wherever the fast index is within rounding of a decision.
+constexpr int kRouteSPT = 4, kRouteThreads = 256, kRouteChunk = kRouteSPT * kRouteThreads;
 template <typename OT, bool HI>
-__global__ __launch_bounds__(256) void k_sample_routes(int W, int NS, int S, const double *__restrict__ power,
-                                                       const double *__restrict__ lut, const double *__restrict__ sptab,
-                                                       const int *__restrict__ nspl, const double *__restrict__ meta,
-                                                       const double *__restrict__ aux, const double *__restrict__ runs,
-                                                       OT *__restrict__ ox, OT *__restrict__ oy, OT *__restrict__ oh,
-                                                       OT *__restrict__ ok, OT *__restrict__ odth, double *__restrict__ ok64,
-                                                       double *__restrict__ odth64)
+__global__ __launch_bounds__(kRouteThreads) void k_sample_routes(int W, int NS, int S, const double *__restrict__ power,
+                                                                 const double *__restrict__ lut, const double *__restrict__ sptab,
+                                                                 const int *__restrict__ nspl, const double *__restrict__ meta,
+                                                                 const double *__restrict__ aux, const double *__restrict__ runs,
+                                                                 OT *__restrict__ ox, OT *__restrict__ oy, OT *__restrict__ oh,
+                                                                 OT *__restrict__ ok, OT *__restrict__ odth, double *__restrict__ ok64,
+                                                                 double *__restrict__ odth64)
 {
-    __shared__ double s_dx[257], s_dy[257];
-    __shared__ int s_j[257];
-    __shared__ OT s_th[257];
+    extern __shared__ __attribute__((aligned(16))) double s_sp[];   // NS * (kSplineStride + 1): the spline table + linspace steps
+    __shared__ double s_dx[kRouteThreads + 1], s_dy[kRouteThreads + 1];
+    __shared__ int s_j[kRouteThreads + 1];
+    __shared__ OT s_th[kRouteThreads + 1];
     const int b = blockIdx.y, tid = threadIdx.x;
     const int G = W - 1;
     const double *m = meta + (size_t)b * kMetaStride;
     const double total = m[1];
     const int N = (int)m[3];
-    const int n_runs = (int)aux[(size_t)b * kAuxStride + 3];
+    const double *ax = aux + (size_t)b * kAuxStride;
+    const double inv_tstep = ax[2];
+    const int n_runs = (int)ax[3];
     const double *tab = runs + (size_t)b * kGridRunDoubles;
     const double dd = m[2];
+    const int n_spl = nspl[b];
+    double *s_step = s_sp + NS * kSplineStride;
+    for (int i = tid; i < n_spl * kSplineStride; i += kRouteThreads) s_sp[i] = sptab[(size_t)b * NS * kSplineStride + i];
+    for (int i = tid; i < n_spl; i += kRouteThreads)
+        s_step[i] = sptab[((size_t)b * NS + i) * kSplineStride + 0] / (double)(kLutN - 1);   // np.linspace's step (SM:443)
+    __syncthreads();
     LutView v;
     v.D = lut + (size_t)b * NS * kLutN;
-    v.sp = sptab + (size_t)b * NS * kSplineStride;
-    v.n_spl = nspl[b];
+    v.sp = s_sp;
+    v.n_spl = n_spl;
     v.total = total;
     v.end_param = (double)(W - 1);
     const double *pw = power + (size_t)b * G * kCoefDoubles;
     const int tab_n = W * kSamplesPerNode;
     const size_t row = (size_t)b * S;
-    const int k0 = blockIdx.x * 256;
+    const int k0 = blockIdx.x * kRouteChunk;
     struct Eval { double ex, ey, kap; OT th, x, y; int jj; };
+    // position in the concatenated table: spline si, entry j (1 <= j <= 999) with dist[si][j-1] < s <= dist[si][j] in the
+    // searchsorted-left sense over the whole table
+    int si = 0, j = 1;
+    bool located = false;
+    auto dist_at = [&](int sp_i, int e) { return v.D[(size_t)sp_i * kLutN + e] + s_sp[sp_i * kSplineStride + 1]; };
+    auto locate = [&](double s) {
+        // the first spline whose last entry reaches s, then np.searchsorted-left inside it
+        si = 0;
+        while (si < n_spl - 1 && dist_at(si, kLutN - 1) < s) si++;
+        int lo = 0, hi = kLutN - 1;     // (entry 999 >= s by the choice of the spline, or it is the last spline and s < total)
+#pragma unroll 1
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (dist_at(si, mid) < s) lo = mid + 1;
+            else hi = mid;
+        }
+        j = lo;
+        located = true;
+    };
     auto eval = [&](int k) {
         Eval e;
         const int kk = k < N - 1 ? k : N - 1;
         int r = grid_run_hint(dd, kk, n_runs);
         const double s = (kk == N - 1) ? total : grid_s(tab, n_runs, kk, r);     // MPG:112-122, 172-175
-        const double t = lutv_distance_to_time(v, s);                            // SM:291-318
-        const int jj = table_index(t, tab_n, v.end_param);                       // SM:340-346 / 550-580
+        double t;
+        if (s <= 0) {
+            t = 0.0;                                                             // SM:291-318 early returns
+        } else if (s >= total) {
+            t = v.end_param;
+        } else {
+            if (!located) {
+                locate(s);
+            } else {   // samples come in increasing distance: walk on (entries, then splines)
+                while (dist_at(si, j) < s) {
+                    if (j < kLutN - 1) j++;
+                    else { si++; j = 0; }
+                }
+            }
+            // global entry e = si*1000 + j is the first with distances[e] >= s.  e == 0 cannot be (s > 0 = distances[0]);
+            // j == 0 of a later spline: its predecessor is the previous spline's last entry (SM:457-462 concatenation)
+            const int ps = j > 0 ? si : si - 1, pj = j > 0 ? j - 1 : kLutN - 1;
+            const double d0 = dist_at(ps, pj), d1 = dist_at(si, j);
+            const double t0 = (pj == kLutN - 1 ? s_sp[ps * kSplineStride + 0] : (double)pj * s_step[ps]) + s_sp[ps * kSplineStride + 2];
+            const double t1 = (j == kLutN - 1 ? s_sp[si * kSplineStride + 0] : (double)j * s_step[si]) + s_sp[si * kSplineStride + 2];
+            t = t0 + (t1 - t0) * (s - d0) / (d1 - d0);
+        }
+        bool near;
+        int jj = table_index_fast(t, tab_n, inv_tstep, near);                    // SM:340-346 / 550-580
+        if (near) jj = table_index(t, tab_n, v.end_param);
         const double tp = linspace_at(v.end_param, tab_n, jj);
         int sg;
         double lt;
@@ -300,40 +356,51 @@ __global__ __launch_bounds__(256) void k_sample_routes(int W, int NS, int S, con
         }
         return e;
     };
-    const int k = k0 + tid;
-    Eval me{};
-    if (k < S && k < N) me = eval(k);
-    s_dx[tid] = me.ex; s_dy[tid] = me.ey; s_j[tid] = me.jj; s_th[tid] = me.th;
-    if (tid == 255) {
+    const int kb = k0 + tid * kRouteSPT;
+    Eval ev[kRouteSPT];
+#pragma unroll
+    for (int i = 0; i < kRouteSPT; i++) {
+        ev[i] = Eval{};
+        if (kb + i < S && kb + i < N) ev[i] = eval(kb + i);
+    }
+    s_dx[tid] = ev[0].ex; s_dy[tid] = ev[0].ey; s_j[tid] = ev[0].jj; s_th[tid] = ev[0].th;
+    if (tid == kRouteThreads - 1) {
         Eval nx{};
-        if (k + 1 < N) nx = eval(k + 1);
-        s_dx[256] = nx.ex; s_dy[256] = nx.ey; s_j[256] = nx.jj; s_th[256] = nx.th;
+        if (kb + kRouteSPT < N) nx = eval(kb + kRouteSPT);
+        s_dx[kRouteThreads] = nx.ex; s_dy[kRouteThreads] = nx.ey; s_j[kRouteThreads] = nx.jj; s_th[kRouteThreads] = nx.th;
     }
     __syncthreads();
-    if (k >= S) return;
-    OT dth = (OT)0;
-    double dth64 = 0.0;
-    if (k < N - 1) {
-        const double nx = s_dx[tid + 1], ny = s_dy[tid + 1];
-        const OT nth = s_th[tid + 1];
-        if constexpr (sizeof(OT) == 8) {
-            dth = fabs(nth - me.th);
-        } else if constexpr (HI) {
-            if (s_j[tid + 1] != me.jj) dth64 = dtheta_f64(me.ex, me.ey, nx, ny, me.th, nth);
-            dth = (OT)dth64;
-        } else {
-            if (s_j[tid + 1] != me.jj) dth = dtheta_f32(me.ex, me.ey, nx, ny, me.th, nth);
+#pragma unroll
+    for (int i = 0; i < kRouteSPT; i++) {
+        const int k = kb + i;
+        if (k >= S) break;
+        const Eval &me = ev[i];
+        OT dth = (OT)0;
+        double dth64 = 0.0;
+        if (k < N - 1) {
+            const double nx = i + 1 < kRouteSPT ? ev[(i + 1) % kRouteSPT].ex : s_dx[tid + 1];
+            const double ny = i + 1 < kRouteSPT ? ev[(i + 1) % kRouteSPT].ey : s_dy[tid + 1];
+            const OT nth = i + 1 < kRouteSPT ? ev[(i + 1) % kRouteSPT].th : s_th[tid + 1];
+            const int nj = i + 1 < kRouteSPT ? ev[(i + 1) % kRouteSPT].jj : s_j[tid + 1];
+            if constexpr (sizeof(OT) == 8) {
+                dth = fabs(nth - me.th);
+            } else if constexpr (HI) {
+                if (nj != me.jj) dth64 = dtheta_f64(me.ex, me.ey, nx, ny, me.th, nth);
+                dth = (OT)dth64;
+            } else {
+                if (nj != me.jj) dth = dtheta_f32(me.ex, me.ey, nx, ny, me.th, nth);
+            }
         }
-    }
-    const bool in = k < N;
-    if (ox) ox[row + k] = in ? me.x : (OT)0;
-    if (oy) oy[row + k] = in ? me.y : (OT)0;
-    if (oh) oh[row + k] = in ? me.th : (OT)0;
-    if (ok) ok[row + k] = in ? (OT)me.kap : (OT)0;
-    if (odth) odth[row + k] = in ? dth : (OT)0;
-    if constexpr (HI) {
-        ok64[row + k] = in ? me.kap : 0.0;
-        odth64[row + k] = in ? dth64 : 0.0;
+        const bool in = k < N;
+        if (ox) ox[row + k] = in ? me.x : (OT)0;
+        if (oy) oy[row + k] = in ? me.y : (OT)0;
+        if (oh) oh[row + k] = in ? me.th : (OT)0;
+        if (ok) ok[row + k] = in ? (OT)me.kap : (OT)0;
+        if (odth) odth[row + k] = in ? dth : (OT)0;
+        if constexpr (HI) {
+            ok64[row + k] = in ? me.kap : 0.0;
+            odth64[row + k] = in ? dth64 : 0.0;
+        }
     }
 }
 
@@ -360,10 +427,11 @@ hipError_t launch_sample_routes(hipStream_t st, bool f64, int B, int W, int NS, 
                                 const double *sptab, const int *nspl, const double *meta, const double *aux, const double *runs,
                                 void *x, void *y, void *h, void *k, void *dth, double *k64, double *dth64)
 {
-    const dim3 grid((S + 255) / 256, B);
+    const dim3 grid((S + kRouteChunk - 1) / kRouteChunk, B);
     const bool hi = !f64 && k64 && dth64;
+    const size_t lds = sizeof(double) * (size_t)NS * (kSplineStride + 1);
 #define VAP_SR(OT_, HI_)                                                                                                     \
-    hipLaunchKernelGGL((k_sample_routes<OT_, HI_>), grid, dim3(256), 0, st, W, NS, S, pw, lut, sptab, nspl, meta, aux, runs, \
+    hipLaunchKernelGGL((k_sample_routes<OT_, HI_>), grid, dim3(kRouteThreads), lds, st, W, NS, S, pw, lut, sptab, nspl, meta, aux, runs, \
                        (OT_ *)x, (OT_ *)y, (OT_ *)h, (OT_ *)k, (OT_ *)dth, k64, dth64)
     if (f64) VAP_SR(double, false);
     else if (hi) VAP_SR(float, true);
