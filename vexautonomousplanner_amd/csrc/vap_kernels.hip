@@ -1108,7 +1108,38 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
     constexpr int kInner = 8;
     const int wv = tid >> 6, lane = tid & 63;
     int f_cur = 0, f_nxt = 1, f_prv = 2;
+    const bool fwd_nb = lane > 0 && fwd_active;
     while (true) {
+        if constexpr (CM) {
+            // Commit mode keeps no per-sample result, so re-running a chunk whose incoming state has not changed is
+            // harmless: the whole wavefront evaluates whenever any of its lanes has to (no per-lane branch, no exec
+            // bookkeeping between an evaluation and the next — ~35 instructions on the chain of a ramp otherwise), and
+            // the loop is left on the ballot of the lanes whose incoming state moved.
+            if (__ballot(need) != 0) {
+#pragma unroll 1
+                for (int k = 0; k < kInner; k++) {
+                    R uu = in_u, wp = in_w;
+#pragma unroll
+                    for (int s = 0; s < L; s++) {
+                        const R nx = step_fwd(am[PSA ? s : 0], q[s], g[s], A[s], cp[s], uu, wp);
+                        if (s == 0) {   // sample 0 is the given start velocity (MPG:189): thread 0 skips its first slot
+                            const R w1 = wp;               // (step_fwd has moved uu into wp)
+                            wp = tid == 0 ? in_w : w1;
+                            uu = tid == 0 ? in_u : nx;
+                        } else {
+                            uu = nx;
+                        }
+                    }
+                    out_u = uu;
+                    out_w = wp;
+                    const R nu = wave_shift_up(out_u), nw = wave_shift_up(out_w);
+                    need = fwd_nb && !(same_bits(nu, in_u) && same_bits(nw, in_w));
+                    in_u = fwd_nb ? nu : in_u;
+                    in_w = fwd_nb ? nw : in_w;
+                    if (__ballot(need) == 0) break;
+                }
+            }
+        } else {
 #pragma unroll 1
         for (int k = 0; k < kInner; k++) {
             if (need) {
@@ -1130,6 +1161,7 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
                 in_w = nw;
             }
             if (__ballot(need) == 0) break;
+        }
         }
         const int pb = rounds & 1;
         if (lane == 63) s_bs[pb][wv + 1] = BoundaryState<R>{out_u, out_w};
@@ -1233,7 +1265,30 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
     if (tid == 0) { s_any[0] = 0; s_any[1] = 0; s_any[2] = 0; }
     __syncthreads();
     f_cur = 0; f_nxt = 1; f_prv = 2;
+    const bool bwd_nb = lane < 63 && tid < last_chunk;
     while (true) {   // mirror image: states move one lane down, wave w+1 hands its first chunk's state to wave w
+        if constexpr (CM) {
+            if (__ballot(need) != 0) {   // (as in the forward sweep: the wavefront evaluates as one)
+#pragma unroll 1
+                for (int k = 0; k < kInner; k++) {
+                    R uu = in_u, wp = in_w;
+                    if (any_dup) {
+#pragma unroll
+                        for (int s = L - 1; s >= 0; s--) uu = bwd_step<true, true>(am[PSA ? s : 0], q[s], g[s], A[s], cp[s], uu, wp, (R)0);
+                    } else {
+#pragma unroll
+                        for (int s = L - 1; s >= 0; s--) uu = bwd_step<false, true>(am[PSA ? s : 0], q[s], g[s], A[s], cp[s], uu, wp, (R)0);
+                    }
+                    out_u = uu;
+                    out_w = wp;
+                    const R nu = wave_shift_down(out_u), nw = wave_shift_down(out_w);
+                    need = bwd_nb && !(same_bits(nu, in_u) && same_bits(nw, in_w));
+                    in_u = bwd_nb ? nu : in_u;
+                    in_w = bwd_nb ? nw : in_w;
+                    if (__ballot(need) == 0) break;
+                }
+            }
+        } else
 #pragma unroll 1
         for (int k = 0; k < kInner; k++) {
             if (need) {
