@@ -2950,8 +2950,8 @@ static hipError_t velocity_long_t(hipStream_t st, int B, int S, const double c[6
     // profiles batch after batch of similar routes — the bench loop — then pays one round trip per sweep instead of
     // one per three rounds); purely a launch-count heuristic, the result does not depend on it.
     constexpr int kRoundsPerCheck = 3;
-    static int expect_rounds[2] = {kRoundsPerCheck, kRoundsPerCheck};
-    static int expect_nsc = -1;
+    static thread_local int expect_rounds[2] = {kRoundsPerCheck, kRoundsPerCheck};
+    static thread_local int expect_nsc = -1;
     if (expect_nsc != nsc) { expect_rounds[0] = expect_rounds[1] = kRoundsPerCheck; expect_nsc = nsc; }
     for (int dir = 0; dir < 2; dir++) {
         int round = 0;
