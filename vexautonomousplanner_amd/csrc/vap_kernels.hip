@@ -2899,14 +2899,18 @@ hipError_t launch_velocity_relax(hipStream_t st, bool r64, bool io64, int B, int
 #define VAP_RELAX(R_, IO_, L_, MAXT_, W_) launch_relax_t<R_, IO_, L_, MAXT_, W_>(st, B, S, c, sv, ev, meta, curv, dth, vcap, acc, vel, flags)
     // chunk length: the longest instantiated L whose thread count still covers the row — fewer, longer
     // chunks mean fewer rounds (rounds ~ longest unclamped run / L) and fewer waves to synchronise
+    static const char *w16 = getenv("VAP_RELAX_W16");   // developer knob: 0 = no single-wavefront variant
+    const bool one_wave = !(w16 && atoi(w16) == 0) && S > 64 * 4 && S <= 64 * 16;
     if (r64 && io64) {
         if (S <= 64 * 4) VAP_RELAX(double, double, 4, 256, 4);
+        else if (one_wave) VAP_RELAX(double, double, 16, 64, 2);   // one wavefront per path: no workgroup barrier at all
         else if (S <= 512 * 8) VAP_RELAX(double, double, 8, 512, 4);
         else VAP_RELAX(double, double, 20, 512, 2);
         return hipGetLastError();
     }
     if (r64) {
         if (S <= 64 * 4) VAP_RELAX(double, float, 4, 256, 4);
+        else if (one_wave) VAP_RELAX(double, float, 16, 64, 2);
         else if (S <= 512 * 8) VAP_RELAX(double, float, 8, 512, 4);
         else VAP_RELAX(double, float, 20, 512, 2);
         return hipGetLastError();
