@@ -52,6 +52,8 @@ def lib():
         for f in ("vapo_point", "vapo_derivative", "vapo_second_derivative"):
             getattr(L, f).argtypes = [C.c_void_p, C.c_double, c_double_p]
         L.vapo_rebuild_tables.argtypes = [C.c_void_p]
+        L.vapo_build_tables_sized.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.vapo_build_tables_sized.restype = C.c_int
         L.vapo_lut_size.argtypes = [C.c_void_p]
         L.vapo_get_lut.argtypes = [C.c_void_p, c_double_p, c_double_p, c_double_p]
         L.vapo_table_size.argtypes = [C.c_void_p]
@@ -165,6 +167,10 @@ class OraclePath:
 
     def rebuild_tables(self):
         self._L.vapo_rebuild_tables(self._h)
+
+    def build_tables_sized(self, min_samples, samples_per_node):
+        if self._L.vapo_build_tables_sized(self._h, int(min_samples), int(samples_per_node)) != 0:
+            raise IndexError("min_samples < 2 (spline_manager.py:444)")
 
     def lut(self):
         n = self._L.vapo_lut_size(self._h)

@@ -47,6 +47,8 @@ struct vapo_path {
     int tab_n;
     double *tab_p, *tab_k, *tab_h;
     int have_tab;
+    /* build_lookup_table(min_samples) / precompute_path_properties(samples_per_node): 0 = the defaults (SM:427, 477) */
+    int min_samples, samples_per_node;
 };
 
 static double norm2(double dx, double dy) { return sqrt(dx * dx + dy * dy); }
@@ -382,7 +384,7 @@ void vapo_get_segments(const vapo_path *p, double *seg, double *seglen, double *
 /* SM:426-475 build_lookup_table */
 static void build_lookup_table(vapo_path *p)
 {
-    int n = LUT_MIN_SAMPLES;
+    int n = p->min_samples > 0 ? p->min_samples : LUT_MIN_SAMPLES;
     free(p->lut_d); free(p->lut_p);
     p->lut_n = n * p->n_splines;
     p->lut_d = (double *)malloc(sizeof(double) * p->lut_n);
@@ -416,7 +418,7 @@ static void build_lookup_table(vapo_path *p)
 /* SM:477-548 precompute_path_properties */
 static void precompute_path_properties(vapo_path *p)
 {
-    int n = p->W * SAMPLES_PER_NODE;
+    int n = p->W * (p->samples_per_node > 0 ? p->samples_per_node : SAMPLES_PER_NODE);
     free(p->tab_p); free(p->tab_k); free(p->tab_h);
     p->tab_n = n;
     p->tab_p = (double *)malloc(sizeof(double) * n);
@@ -437,8 +439,20 @@ static void precompute_path_properties(vapo_path *p)
 
 void vapo_rebuild_tables(vapo_path *p)
 {
+    p->min_samples = p->samples_per_node = 0;   /* SM:582-594: both builders with their defaults */
     build_lookup_table(p);
     precompute_path_properties(p);
+}
+
+/* build_lookup_table(min_samples=...) and precompute_path_properties(samples_per_node=...) with explicit sizes */
+int vapo_build_tables_sized(vapo_path *p, int min_samples, int samples_per_node)
+{
+    if (min_samples < 2 || samples_per_node < 1) return -1;   /* SM:444 indexes local_params[1] */
+    p->min_samples = min_samples;
+    p->samples_per_node = samples_per_node;
+    build_lookup_table(p);
+    precompute_path_properties(p);
+    return 0;
 }
 
 int vapo_lut_size(const vapo_path *p) { return p->lut_n; }

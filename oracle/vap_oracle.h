@@ -57,6 +57,8 @@ void vapo_second_derivative(const vapo_path *p, double t, double out[2]);
 
 /* rebuild_tables (spline_manager.py:582-594): build_lookup_table + precompute_path_properties */
 void vapo_rebuild_tables(vapo_path *p);
+/* the two builders with explicit sizes (spline_manager.py:426-427, 477); -1 for min_samples < 2 */
+int vapo_build_tables_sized(vapo_path *p, int min_samples, int samples_per_node);
 int vapo_lut_size(const vapo_path *p);
 void vapo_get_lut(const vapo_path *p, double *dist, double *param, double *total);
 int vapo_table_size(const vapo_path *p);
