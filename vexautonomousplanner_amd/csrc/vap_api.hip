@@ -287,11 +287,9 @@ int vap_sample(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd, const
     if (!d_segments || !d_lut || !d_meta) return vap_fail(VAP_ERR_INVALID, "null buffer");
     const size_t n_seg = (size_t)B * (W - 1);
     VAP_TRY(ctx->ensure(ctx->power, n_seg * vap::kCoefBlockDoubles * sizeof(double)));
-    VAP_TRY(ctx->ensure(ctx->slopes, (size_t)B * VAP_LUT_SAMPLES * sizeof(double)));
     VAP_TRY(ctx->ensure(ctx->aux, (size_t)B * 4 * sizeof(double)));
     VAP_TRY(ctx->ensure(ctx->runs, (size_t)B * vap::kGridRunBlockDoubles * sizeof(double)));
     HIP_TRY(vap::launch_power(ctx->stream, (int)n_seg, d_segments, (double *)ctx->power.ptr));
-    HIP_TRY(vap::launch_lut_slopes(ctx->stream, B, d_lut, d_meta, (double *)ctx->slopes.ptr));
     HIP_TRY(vap::launch_grid(ctx->stream, B, W, S, dd, d_meta, (double *)ctx->aux.ptr, (double *)ctx->runs.ptr, d_flags));
     const bool hi = dt == VAP_F32 && ctx->f32_recurrence == VAP_RECURRENCE_F64;
     if (hi) {
@@ -299,7 +297,7 @@ int vap_sample(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd, const
         VAP_TRY(ctx->ensure(ctx->dth64, (size_t)B * S * sizeof(double)));
     }
     HIP_TRY(vap::launch_sample(ctx->stream, dt == VAP_F64, B, W, S, (const double *)ctx->power.ptr, d_lut,
-                               (const double *)ctx->slopes.ptr, d_meta, (const double *)ctx->aux.ptr,
+                               nullptr, d_meta, (const double *)ctx->aux.ptr,
                                (const double *)ctx->runs.ptr, d_x, d_y, d_heading, d_curvature, d_dtheta,
                                hi ? (double *)ctx->k64.ptr : nullptr, hi ? (double *)ctx->dth64.ptr : nullptr));
     ctx->grid_B = B;
@@ -372,7 +370,6 @@ int vap_profile_batch(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd
     VAP_TRY(ctx->ensure(ctx->seg, n_seg * 12 * sizeof(double)));
     VAP_TRY(ctx->ensure(ctx->power, n_seg * vap::kCoefBlockDoubles * sizeof(double)));
     VAP_TRY(ctx->ensure(ctx->lut, (size_t)B * VAP_LUT_SAMPLES * sizeof(double)));
-    VAP_TRY(ctx->ensure(ctx->slopes, (size_t)B * VAP_LUT_SAMPLES * sizeof(double)));
     VAP_TRY(ctx->ensure(ctx->aux, (size_t)B * 4 * sizeof(double)));
     VAP_TRY(ctx->ensure(ctx->runs, (size_t)B * vap::kGridRunBlockDoubles * sizeof(double)));
     // VAP_F32 with the fp64 recurrence (the default): the velocity pass reads fp64 curvature / |dtheta| rows
@@ -413,10 +410,10 @@ int vap_profile_batch(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd
     grid.aux = (double *)ctx->aux.ptr;
     grid.runs = (double *)ctx->runs.ptr;
     HIP_TRY(vap::launch_lut(ctx->stream, B, W, (const double *)ctx->seg.ptr, (double *)ctx->lut.ptr,
-                            (double *)ctx->slopes.ptr, meta, flags, grid));
+                            nullptr, meta, flags, grid));   // (the sampling kernel forms the interval slopes itself)
     tm.mark(VAP_T_LUT);
     HIP_TRY(vap::launch_sample(ctx->stream, f64, B, W, S, (const double *)ctx->power.ptr,
-                               (const double *)ctx->lut.ptr, (const double *)ctx->slopes.ptr, meta,
+                               (const double *)ctx->lut.ptr, nullptr, meta,
                                (const double *)ctx->aux.ptr, (const double *)ctx->runs.ptr, d_x, d_y, d_heading, curv,
                                hi ? nullptr : ctx->dth.ptr, hi ? (double *)ctx->k64.ptr : nullptr,
                                hi ? (double *)ctx->dth64.ptr : nullptr));
@@ -500,19 +497,17 @@ int vap_profile_routes(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double d
     rt.nspl = nspl;
     rt.NS = NS;
     // No route of the batch has a split (max_splines == 1: tangent overrides at most): every route is one spline with
-    // zero offsets, i.e. a plain path — the persistent sampling kernel of vap_profile_batch takes it (it wants the
-    // interval slopes next to the table), same rows bit for bit as that entry point and 3-4x faster than the
+    // zero offsets, i.e. a plain path — the persistent sampling kernel of vap_profile_batch takes it, same rows bit for bit as that entry point and 3-4x faster than the
     // thread-per-sample kernel the concatenated tables need.
     const bool single = NS == 1;
-    if (single) VAP_TRY(ctx->ensure(ctx->slopes, (size_t)B * VAP_LUT_SAMPLES * sizeof(double)));
-    HIP_TRY(vap::launch_lut(ctx->stream, B, W, (const double *)ctx->seg.ptr, (double *)ctx->lut.ptr,
-                            single ? (double *)ctx->slopes.ptr : nullptr, meta, flags, vap::GridArgs(), rt));
+    HIP_TRY(vap::launch_lut(ctx->stream, B, W, (const double *)ctx->seg.ptr, (double *)ctx->lut.ptr, nullptr, meta, flags,
+                            vap::GridArgs(), rt));
     HIP_TRY(vap::launch_route_offsets(ctx->stream, B, W, NS, S, dd, (const double *)ctx->lut.ptr, sptab, nspl, meta,
                                       (double *)ctx->aux.ptr, (double *)ctx->runs.ptr, flags));
     tm.mark(VAP_T_LUT);
     if (single)
         HIP_TRY(vap::launch_sample(ctx->stream, f64, B, W, S, (const double *)ctx->power.ptr, (const double *)ctx->lut.ptr,
-                                   (const double *)ctx->slopes.ptr, meta, (const double *)ctx->aux.ptr,
+                                   nullptr, meta, (const double *)ctx->aux.ptr,
                                    (const double *)ctx->runs.ptr, d_x, d_y, d_heading, curv, hi ? nullptr : ctx->dth.ptr,
                                    hi ? (double *)ctx->k64.ptr : nullptr, hi ? (double *)ctx->dth64.ptr : nullptr));
     else

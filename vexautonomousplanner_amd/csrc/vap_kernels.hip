@@ -506,7 +506,7 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int 
     const double run_touch = runs[(size_t)b * kGridRunDoubles + (tid < 120 ? tid : 0)];
     if (tile0 * tile < N) {
         lds_fill<4>(sD, lut + (size_t)b * kLutN, kLutN, tid, kSampleThreads);
-        lds_fill<4>(sWt, slopes + (size_t)b * kLutN, kLutN, tid, kSampleThreads);
+        if (slopes) lds_fill<4>(sWt, slopes + (size_t)b * kLutN, kLutN, tid, kSampleThreads);
         if constexpr (COEF_LDS) lds_fill<4>(s_coef, pw, G * kCoefDoubles, tid, kSampleThreads);
     }
     // MPG:112-122 distance grid: the reference accumulates current_dist += dd.  A thread's first sample of a
@@ -535,6 +535,21 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int 
     };
     // the first tile's lookup goes out together with the staging loads
     const double sk_first = tile0 * tile < N ? grid_first(tile0 * tile + tid * kSPT) : 0.0;
+    if (!slopes) {
+        // the interval slopes (t1 - t0)/(d1 - d0) of SM:311-317 from the staged distances — the expression k_lut uses, so
+        // the same numbers, without 8 KB per path going to HBM and back (config 5: a fifth of the step's traffic)
+        __syncthreads();
+        if (tile0 * tile < N) {
+            for (int j = tid; j < kLutN; j += kSampleThreads) {
+                double w = 0.0;
+                if (j > 0) {
+                    const double t0 = (double)(j - 1) * lstep, t1 = (j == kLutN - 1) ? t_max : (double)j * lstep;
+                    w = (t1 - t0) / (sD[j] - sD[j - 1]);
+                }
+                sWt[j] = w;
+            }
+        }
+    }
     __syncthreads();
     asm volatile("" ::"v"(run_touch));
     const double *coef = COEF_LDS ? s_coef : pw;
