@@ -287,3 +287,39 @@ def test_routes_without_splits_equal_the_plain_path_bit_for_bit(torch_mod, dtype
     tp = gen.time_profile(r, DEFAULT_CONSTRAINTS, dt=0.01, capacity_rows=4096, node_reverse=none)
     torch.cuda.synchronize()
     assert int(tp["counts"][:, 0].min()) > 50 and not r["flags"].any().item()
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-5), ("f64", 1e-8)])
+def test_large_batch_of_split_routes_matches_oracle_on_a_sample(torch_mod, dtype, tol):
+    """A config-3-shaped batch of routes (1024 x 32 nodes x 6000 samples, ~10 % reverse / turn nodes: 4 splines per route on
+    average, up to 10): flags clean, every velocity finite and positive, and 12 random routes against the oracle."""
+    from oracle import oracle
+    from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
+    torch = torch_mod
+    rng = np.random.default_rng(2024)
+    gen = make_gen(dtype)
+    B, W, S = 1024, 32, 6000
+    wp = make_waypoints(B, W, 31).astype(np.float32).astype(np.float64)
+    rev = rng.random((B, W)) < 0.05
+    turn = np.where(rng.random((B, W)) < 0.05, rng.choice([-120.0, -45.0, 60.0, 90.0], size=(B, W)), 0.0)
+    rev[:, -1] = False
+    turn[:, -1] = turn[:, 0] = 0.0
+    r = gen.profile_routes(torch.tensor(wp, dtype=gen.tdtype, device=gen.device), node_reverse=rev, node_turn=turn,
+                           constraints=DEFAULT_CONSTRAINTS, samples=S)
+    torch.cuda.synchronize()
+    assert not r["flags"].any().item()
+    assert int(r["spline_counts"].max()) >= 6 and int(r["spline_counts"].min()) >= 1
+    v = r["velocity"]
+    # (no 0.01 floor here: the cusp at a reverse / turn node has a huge curvature and the reference's cap goes down with it)
+    assert torch.isfinite(v).all().item() and float(v.min()) > 0.0 and float(v.max()) <= DEFAULT_CONSTRAINTS[0] * (1 + 1e-6)
+    for b in rng.choice(B, size=12, replace=False):
+        nodes = dict(is_reverse=rev[b].astype(float), turn=turn[b], stop=np.zeros(W), wait_time=np.zeros(W), max_velocity=np.zeros(W),
+                     max_acceleration=np.zeros(W), tangent=np.full((W, 2), np.nan), magnitudes=np.zeros((W, 2)))
+        op = oracle.OraclePath(wp[b], nodes=nodes)
+        op.rebuild_tables()
+        ref = op.forward_backward(DEFAULT_CONSTRAINTS, dd=op.dd_for_samples(S))
+        assert len(ref["velocity"]) == S and int(r["meta"][b, 3]) == S
+        for k, floor in (("velocity", 0.0), ("curvature", 1e-2), ("x", 1.0), ("y", 1.0)):
+            got = r[k][b].cpu().numpy().astype(np.float64)
+            err = np.max(np.abs(got - ref[k]) / np.maximum(np.abs(ref[k]), floor))
+            assert err <= (tol if k == "velocity" or dtype == "f32" else 1e-9), (int(b), k, err)
