@@ -1,7 +1,9 @@
 """Experiment (CPU, numpy): how many parallel iterations does the forward velocity sweep of a config-3 path need
-under (a) the kernel's chunk relaxation (one chunk per iteration along a chain), (b) a quasi-Newton iteration whose
-chunk maps are modelled as affine u_out = out + J (u_in - in) with a secant J and solved by a scan, (c) Newton with
-the exact 2x2 chunk Jacobians (the recurrence is piecewise linear)?  Rows come from the oracle.  Developer tool.
+under (a) the kernel's chunk relaxation (one chunk per iteration along a chain), with the bit-identity criterion and
+with a 1e-13 tolerance, (b) Newton on the chunk boundary states with the exact 2x2 chunk Jacobians (the recurrence is
+piecewise linear; the linearised recurrence is solved sequentially here, standing for an affine scan), from the cap
+seeds and from the seeds of the alpha-free (min,+) recurrence?  Rows come from the oracle.  Developer tool (DESIGN.md
+section 5 quotes its output: 40-75 evaluations for (a), 15-24 / 10-14 Newton iterations for (b)).
 """
 import sys, os
 import numpy as np
