@@ -209,3 +209,28 @@ def test_many_paths_table_kernel_is_bit_identical(torch_mod, W):
     assert int(big["flags"].abs().max().item()) == 0
     for k in ("meta", "x", "y", "heading", "curvature", "velocity"):
         assert torch.equal(big[k][idx], small[k]), k
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_full_size_batch_is_deterministic_and_order_independent(torch_mod, dtype):
+    """Size-independent properties at config 3's full size (4096 x 32 x 10 000): the same batch twice gives the same bits
+    (the relaxation's fixed point does not depend on scheduling), and a permuted batch gives the permuted rows — a
+    path's result does not depend on its neighbours or on its position in the batch."""
+    torch = torch_mod
+    from vexautonomousplanner_amd.batch import BatchedTrajectoryGenerator
+    from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
+    gen = BatchedTrajectoryGenerator(0, dtype)
+    B, W, S = 4096, 32, 10000
+    wp = torch.tensor(make_waypoints(B, W, 3), dtype=gen.tdtype, device=gen.device)
+    first = {k: v.clone() for k, v in gen.profile(wp, DEFAULT_CONSTRAINTS, samples=S, want=("curvature", "velocity")).items()
+             if k in ("curvature", "velocity", "meta", "flags")}
+    again = gen.profile(wp, DEFAULT_CONSTRAINTS, samples=S, want=("curvature", "velocity"))
+    torch.cuda.synchronize()
+    for k in first:
+        assert torch.equal(first[k], again[k]), k
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(5)).to(gen.device)
+    shuffled = gen.profile(wp[perm].contiguous(), DEFAULT_CONSTRAINTS, samples=S, want=("curvature", "velocity"))
+    torch.cuda.synchronize()
+    for k in first:
+        assert torch.equal(first[k][perm], shuffled[k]), k
+    assert int(first["flags"].abs().max().item()) == 0
