@@ -2,6 +2,7 @@
 """bench.py — trajectory sample-points/s of the batched hot path on N MI355X (one rank per GPU).
 
     python bench.py [--gpus N --steps K --warmup W] [--workload c3|c5|c2|c4] [--dtype f32|f64]
+        (N > 1 without a launcher: the script starts its own N ranks as a child torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -148,6 +149,21 @@ def profiled_traffic(stage, workload, dtype, paths, recurrence):
     return (sum(vals), name) if vals else (None, f"{name} has no {kern} entry")
 
 
+def launch_ranks(n):
+    """Run this script under torch.distributed.run with n ranks on this node (rendezvous on 127.0.0.1, a free
+    port); rank 0's JSON line goes to this process's stdout, the return value is the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -174,6 +190,11 @@ def main():
     ap.add_argument("--share-device", action="store_true", help="(rehearsal) every rank uses cuda:0")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: start the N ranks (one per GPU) as a CHILD torch.distributed.run and
+        # hand its output and exit code through.  Nothing in this process has touched the GPU yet (no torch import).
+        sys.exit(launch_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
 
@@ -184,9 +205,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+        args.gpus = world        # under a launcher the launcher's world size is the truth
     if args.share_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)

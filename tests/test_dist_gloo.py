@@ -66,3 +66,19 @@ def test_sharded_equals_unsharded_world2(tmp_path, n_paths):
         lo, hi = vd.shard_bounds(10, r, 3)
         cover += list(range(lo, hi))
     assert cover == list(range(10))
+
+
+def test_bench_self_launch_hands_a_failing_rank_through():
+    """`python bench.py --gpus 2` with no launcher in the environment starts its own two ranks as a child
+    torch.distributed.run.  Without a GPU the ranks cannot run (the product has no CPU path), so what this CPU test
+    shows is the plumbing: the child is started, its failure comes back as a non-zero exit code, no JSON line."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--paths-per-gpu", "4", "--no-cpu-baseline", "--parity-paths", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    if torch.cuda.is_available():
+        pytest.skip("a GPU box: tests/test_gpu_sharding.py::test_bench_starts_its_own_ranks covers the launch")
+    assert p.returncode != 0
+    assert "torch.distributed" in p.stderr or "ChildFailedError" in p.stderr or "rank" in p.stderr.lower()
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]

@@ -1,0 +1,128 @@
+"""K5w, the lane-per-path velocity kernel (vap_velocity_lanes.hip, MPG:188-311): every sample is evaluated once per
+direction with the step and the coefficient expressions the sequential sweep k_velocity_seq<FAST> uses, so its rows
+must equal that sweep's BIT FOR BIT — for every group size (16 / 32 / 64 paths per workgroup), fp32 and fp64 rows,
+plain rows, ragged rows, rows longer than any tile, dense grids with zero heading differences (the sign-aware
+backward step), per-sample initial velocities and per-sample max_acceleration rows — and hold the oracle's bound."""
+import numpy as np
+import pytest
+
+import test_gpu_parity as tp
+from test_gpu_parity import make_gen, run_gpu, torch_mod  # noqa: F401  (fixture)
+
+pytestmark = pytest.mark.gpu
+
+GROUPS = ["lanes16", "lanes32", "lanes64"]
+DTYPES = ["f32", "f64"]      # "f32" = fp32 rows, fp64 recurrence (the default mode); the fp32 recurrence has no lanes kernel
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,W,S,seed", [(8, 32, 10000, 3), (33, 8, 1024, 5), (5, 5, 257, 10), (70, 8, 300, 11),
+                                        (3, 2, 64, 9), (2, 16, 7001, 13), (4, 4, 2, 14), (3, 4, 3, 15), (130, 5, 65, 16),
+                                        (2, 64, 30001, 41)])
+def test_lanes_rows_are_bit_identical_to_the_sequential_sweep(torch_mod, B, W, S, seed, dtype):
+    from vexautonomousplanner_amd.synth import make_waypoints
+    wp = make_waypoints(B, W, seed).astype(np.float64)
+    ref = run_gpu(torch_mod, make_gen(dtype, velocity_kernel="seq_fast"), wp, samples=S)
+    assert np.all(ref["flags"] == 0)
+    for which in GROUPS:
+        r = run_gpu(torch_mod, make_gen(dtype, velocity_kernel=which), wp, samples=S)
+        assert np.all(r["flags"] == 0), which
+        assert np.array_equal(r["velocity"], ref["velocity"]), (which, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_lanes_ragged_rows(torch_mod, dtype):
+    """dd mode: every path of a group has its own sample count; rows are zero past it."""
+    from vexautonomousplanner_amd.synth import make_waypoints
+    wp = make_waypoints(21, 8, 21).astype(np.float64)
+    ref = run_gpu(torch_mod, make_gen(dtype, velocity_kernel="seq_fast"), wp, dd=0.005, capacity=2048)
+    n = ref["meta"][:, 3].astype(int)
+    assert len(set(n.tolist())) > 5
+    for which in GROUPS:
+        r = run_gpu(torch_mod, make_gen(dtype, velocity_kernel=which), wp, dd=0.005, capacity=2048)
+        assert np.array_equal(r["velocity"], ref["velocity"]), which
+        for b in range(len(wp)):
+            assert np.all(r["velocity"][b][n[b]:] == 0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_lanes_dense_grid_sign_aware_backward_step(torch_mod, dtype):
+    """Samples sharing a table entry (zero heading difference): the reference's +-inf / NaN decisions (MPG:52-59)."""
+    from vexautonomousplanner_amd.synth import make_waypoints
+    for w, S in ((make_waypoints(3, 3, 32).astype(np.float64), 8000), (make_waypoints(3, 2, 31).astype(np.float64), 7000)):
+        ref = run_gpu(torch_mod, make_gen(dtype, velocity_kernel="seq_fast"), w, samples=S)
+        k = ref["curvature"]
+        assert np.mean(k[:, 1:] == k[:, :-1]) > 0.3          # the regime this test is about
+        for which in GROUPS:
+            r = run_gpu(torch_mod, make_gen(dtype, velocity_kernel=which), w, samples=S)
+            assert np.array_equal(r["velocity"], ref["velocity"]), which
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,W,S", [(6, 8, 1000), (3, 32, 10000), (20, 5, 257), (4, 2, 64)])
+def test_lanes_initial_velocities(torch_mod, dtype, B, W, S):
+    """d_vcap (per-sample initial velocities, MPG:121,127,153,172) through the staged C-ABI."""
+    from vexautonomousplanner_amd import _lib
+    from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
+    rng = np.random.default_rng(B * 1000 + W)
+    wp = make_waypoints(B, W, 77).astype(np.float64)
+    vcap = np.empty((B, S))
+    for b in range(B):
+        edges = np.sort(rng.integers(1, S - 1, size=5))
+        vals = rng.uniform(0.8, 4.0, size=6)
+        vcap[b] = vals[np.searchsorted(edges, np.arange(S), side="right")]
+        vcap[b, rng.integers(1, S - 1, size=3)] = 0.01
+    v_seq, _ = tp._staged_velocity(torch_mod, dtype, wp, DEFAULT_CONSTRAINTS, vcap, 0.0, S, _lib.VELOCITY_SEQ_FAST)
+    for kernel in (_lib.VELOCITY_LANES_16, _lib.VELOCITY_LANES_32, _lib.VELOCITY_LANES_64, _lib.VELOCITY_LANES):
+        v, _ = tp._staged_velocity(torch_mod, dtype, wp, DEFAULT_CONSTRAINTS, vcap, 0.0, S, kernel)
+        assert np.array_equal(v, v_seq), kernel
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_lanes_node_limits_with_accelerations(torch_mod, dtype):
+    """Per-node / action-point max_velocity, max_acceleration and stops (the VCAP + ACC instantiation) on random
+    routes: rows equal the sequential sweep's under the same limit rows."""
+    from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
+    rng = np.random.default_rng(5)
+    B, W = 19, 8
+    wp = make_waypoints(B, W, 61).astype(np.float64)
+    mv = np.where(rng.random((B, W)) < 0.4, rng.uniform(1.0, 3.5, (B, W)), 0.0)
+    ma = np.where(rng.random((B, W)) < 0.5, rng.uniform(3.0, 14.0, (B, W)), 0.0)
+    stop = (rng.random((B, W)) < 0.2).astype(np.int32)
+    stop[:, 0] = stop[:, -1] = 0
+    rows = {}
+    for which in ["seq_fast"] + GROUPS:
+        gen = make_gen(dtype, velocity_kernel=which)
+        wpt = torch_mod.tensor(wp, dtype=gen.tdtype, device=gen.device)
+        r = gen.profile(wpt, DEFAULT_CONSTRAINTS, dd=0.005, capacity=2048)
+        gen.apply_node_limits(r, DEFAULT_CONSTRAINTS, node_max_velocity=mv, node_stop=stop, node_max_acceleration=ma)
+        torch_mod.cuda.synchronize()
+        assert int(r["flags"].abs().max().item()) == 0
+        rows[which] = r["velocity"].cpu().numpy()
+    for which in GROUPS:
+        assert np.array_equal(rows[which], rows["seq_fast"]), which
+
+
+def test_lanes_refuses_the_fp32_recurrence(torch_mod):
+    from vexautonomousplanner_amd import _lib
+    from vexautonomousplanner_amd.synth import make_waypoints
+    gen = make_gen("f32r32", velocity_kernel="lanes")
+    with pytest.raises(_lib.VapError):
+        run_gpu(torch_mod, gen, make_waypoints(4, 4, 1).astype(np.float64), samples=100)
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-5), ("f64", 1e-9)])
+def test_auto_takes_lanes_for_large_batches_and_holds_the_oracle_bound(torch_mod, dtype, tol):
+    """2048 paths and more: AUTO is the lanes kernel (same rows as forcing it), and the rows hold the parity bound."""
+    from oracle import oracle
+    from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
+    B, W, S = 2100, 8, 700
+    wp = make_waypoints(B, W, 88).astype(np.float64)
+    a = run_gpu(torch_mod, make_gen(dtype), wp, samples=S)
+    f = run_gpu(torch_mod, make_gen(dtype, velocity_kernel="lanes"), wp, samples=S)
+    s = run_gpu(torch_mod, make_gen(dtype, velocity_kernel="seq_fast"), wp, samples=S)
+    assert np.array_equal(a["velocity"], f["velocity"]) and np.array_equal(a["velocity"], s["velocity"])
+    idx = np.arange(0, B, 97)
+    ref = oracle.profile_batch(wp[idx], S, DEFAULT_CONSTRAINTS, n_threads=8)
+    err = np.max(np.abs(a["velocity"][idx] - ref["velocity"]) / ref["velocity"])
+    assert err <= tol, err

@@ -113,3 +113,25 @@ def test_two_ranks_on_one_gpu_equal_the_single_process_run(torch_mod, tmp_path, 
     s0, s1 = np.load(tmp_path / "summ0.npy"), np.load(tmp_path / "summ1.npy")
     assert np.array_equal(s0, s1) and np.array_equal(s0[:, :2], ref_summ[:, :2])
     np.testing.assert_allclose(s0[:, 2], ref_summ[:, 2], rtol=1e-14)
+
+
+def test_bench_starts_its_own_ranks(torch_mod):
+    """`python bench.py --gpus 2` without a launcher: the script starts the two ranks itself as a child
+    torch.distributed.run (rehearsed here on one GPU: gloo, both ranks on cuda:0), prints rank 0's one JSON line and
+    returns the launcher's exit code."""
+    import json
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-device", "--steps", "3",
+           "--warmup", "1", "--paths-per-gpu", "256", "--no-cpu-baseline", "--parity-paths", "0"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_paths"] == 512 and rec["value"] > 0
+    # a rank that fails takes the exit code with it
+    bad = subprocess.run(cmd[:-5] + ["--paths-per-gpu", "-5", "--no-cpu-baseline", "--parity-paths", "0"], capture_output=True,
+                         text=True, timeout=600, env=env)
+    assert bad.returncode != 0
+    assert not [ln for ln in bad.stdout.splitlines() if ln.startswith("{")]

@@ -57,6 +57,8 @@ int check_shape(int B, int W, int S)
 }
 
 
+constexpr int kLanesMinPaths = 2048;   // AUTO: batches from here on take the lane-per-path kernel (fp64 recurrence)
+
 // K5 dispatch.  auto: register-resident relaxation whenever the row fits, else the sequential sweep.
 // f64 = arithmetic type of the recurrence = type of the curv / dth rows; io64 = type of the caller's rows (vcap,
 // acc, vel).  f64 && !io64: the fp64 recurrence behind fp32 outputs (VAP_F32 with VAP_RECURRENCE_F64).
@@ -67,6 +69,20 @@ int run_velocity(vap_ctx *ctx, bool f64, bool io64, int B, int S, const double c
     // per-sample initial velocities: the register-resident relaxation kernel takes them, the two-level one for
     // long rows and the wave-per-path variant do not (the sequential sweep does)
     const int relax_limit = acc.fwd ? vap::velocity_relax_acc_max_samples(f64) : vap::velocity_relax_max_samples(f64, vcap != nullptr);
+    // fp64 recurrence, many paths: a wavefront of paths (K5w) — its time does not grow with the batch up to 256
+    // workgroups, the relaxation kernel's does (one path per CU at a time for rows of ~10^4 samples)
+    if (mode == VAP_VELOCITY_AUTO && f64 && B >= kLanesMinPaths) mode = VAP_VELOCITY_LANES;
+    if (mode >= VAP_VELOCITY_LANES && mode <= VAP_VELOCITY_LANES_64) {
+        if (!f64) return vap_fail(VAP_ERR_UNSUPPORTED, "the lane-per-path velocity kernel runs the fp64 recurrence only");
+        void *ufwd = nullptr;
+        if (!io64) {
+            VAP_TRY(ctx->ensure(ctx->ufwd, (size_t)B * S * 8));
+            ufwd = ctx->ufwd.ptr;
+        }
+        const int group = mode == VAP_VELOCITY_LANES ? 0 : (mode == VAP_VELOCITY_LANES_16 ? 16 : (mode == VAP_VELOCITY_LANES_32 ? 32 : 64));
+        HIP_TRY(vap::launch_velocity_lanes(ctx->stream, io64, B, S, cc, sv, ev, meta, curv, dth, vcap, acc, vel, ufwd, group));
+        return VAP_OK;
+    }
     if (mode == VAP_VELOCITY_AUTO)
         mode = (vcap && S > relax_limit) ? VAP_VELOCITY_SEQ_FAST : VAP_VELOCITY_RELAX;
     const int forced = mode;
@@ -205,7 +221,7 @@ int vap_ctx_synchronize(vap_ctx *ctx)
 int vap_ctx_set_option(vap_ctx *ctx, int option, int value)
 {
     if (!ctx) return vap_fail(VAP_ERR_INVALID, "null context");
-    if (option == VAP_OPT_VELOCITY_KERNEL && value >= VAP_VELOCITY_AUTO && value <= VAP_VELOCITY_RELAX_WAVE) {
+    if (option == VAP_OPT_VELOCITY_KERNEL && value >= VAP_VELOCITY_AUTO && value <= VAP_VELOCITY_LANES_64) {
         ctx->velocity_kernel = value;
         return VAP_OK;
     }

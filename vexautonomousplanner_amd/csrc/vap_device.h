@@ -396,6 +396,17 @@ struct VelConsts {
     R almax;   // max_angular_accel = 2*max_acc/track_width   (MPG:82)
 };
 
+// Per-sample max_acceleration rows for routes whose nodes / action points change it (all NULL: the constraints'):
+//   fwd [B][S]  max_acc (= max_dec) in force for the forward step FROM sample i     MPG:194-196
+//   bwd [B][S]  max_acc the backward sweep has in force for its step FROM sample i  MPG:256-257
+//   dec [B]     max_dec of the whole backward sweep (what the forward sweep left)
+template <typename R>
+struct AccRows {
+    const R *fwd = nullptr;
+    const R *bwd = nullptr;
+    const R *dec = nullptr;
+};
+
 // Curvature-only limits of one sample (MPG:204-233 / 264-293), in squared-velocity space.
 template <typename R>
 struct SampleLimits {

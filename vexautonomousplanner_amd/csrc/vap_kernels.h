@@ -84,6 +84,12 @@ size_t velocity_long_counter_bytes(bool f64, int B, int S);
 hipError_t launch_velocity_long(hipStream_t st, bool f64, bool io64, int B, int S, const double c[6], double sv, double ev,
                                 const double *meta, const void *curv, const void *dth, void *vel, uint32_t *flags,
                                 void *ufwd, void *state, int *counters);
+// K5w (vap_velocity_lanes.hip), fp64 recurrence only: lane per path, `group` paths per workgroup (0 = by batch size).
+// ufwd: [B][S] doubles of scratch for the forward sweep's squared velocities (unused when io64: the rows are used in place)
+int velocity_lanes_group(int B);
+hipError_t launch_velocity_lanes(hipStream_t st, bool io64, int B, int S, const double c[6], double sv, double ev,
+                                 const double *meta, const void *curv, const void *dth, const void *vcap, const AccRowsV &acc,
+                                 void *vel, void *ufwd, int group = 0);
 // fp32, one wave per path, one launch per window of 2560 samples and direction (no host synchronisation)
 size_t velocity_windows_state_bytes(int B, int S);
 hipError_t launch_velocity_windows(hipStream_t st, int B, int S, const double c[6], double sv, double ev,

@@ -735,12 +735,7 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int 
 //   fwd [B][S]  max_acc (= max_dec) in force for the forward step FROM sample i     MPG:194-196
 //   bwd [B][S]  max_acc the backward sweep has in force for its step FROM sample i  MPG:256-257
 //   dec [B]     max_dec of the whole backward sweep (what the forward sweep left)
-template <typename R>
-struct AccRows {
-    const R *fwd = nullptr;
-    const R *bwd = nullptr;
-    const R *dec = nullptr;
-};
+// (AccRows<R>: vap_device.h)
 
 // R = arithmetic type (and type of the curvature / dtheta rows), IO = type of the caller's rows (initial
 // velocities, max_acceleration rows, the velocity output): IO = float with R = double is the fp64 recurrence

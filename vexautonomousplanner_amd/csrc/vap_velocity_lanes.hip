@@ -1,0 +1,495 @@
+// vap_velocity_lanes.hip — K5w, the velocity pass (MPG:188-311) as "a wavefront of paths".
+//
+// The recurrence is sequential along a path and has no closed-form scan, but paths are independent:
+// here a LANE is a path.  One workgroup takes P paths (16 / 32 / 64, so that a batch still spreads over the chip):
+//   * wave 0, the CHAIN wave, walks all P recurrences in lock step, one sample per step — forward over every tile of
+//     the rows, then backward — with the hand-scheduled loops of vap_chain_asm.h (four dependent fp64 instructions
+//     per step; the step's five coefficients come out of LDS in blocks of eight steps, because an LDS instruction
+//     between two dependent VALU instructions costs the wave ~15 cycles and ~4 back to back — tools/ubench_chain_lds.hip);
+//   * waves 1..7, the PRODUCERS, stream the curvature / heading-difference rows from HBM (coalesced along a row, one
+//     tile ahead of the chain, loads in flight across the tile barrier), derive the step coefficients of vap_device.h
+//     for tiles of 1024 (path, sample) slots and write them as 48-byte records into a double-buffered LDS tile in
+//     [sample][path] order (the chain's reads are conflict-free, the producers' writes too: the step stride is
+//     P*48+16 bytes); they also move the chain's results (one double per slot, LDS) to HBM: the forward sweep's
+//     squared velocities to a scratch row, which the backward sweep's producers fold into its caps (commit mode of
+//     k_velocity_relax), the backward sweep's as velocities in the caller's type.
+// No speculation and no convergence test: every sample is evaluated exactly once per direction, in order, so the
+// result IS the sequential sweep's — the coefficient expressions are k_velocity_relax's, the step is step4 — bit for
+// bit (tests/test_gpu_parity.py holds every instantiation to k_velocity_seq<FAST>).
+// Cost: the chain's ~57 cycles per sample and direction whatever the batch size up to 256 workgroups, against
+// k_velocity_relax's one path per CU at a time; HBM: 8+8 B/pt read per direction, 8 B/pt scratch write + read, and
+// the velocity row.
+#include "vap_chain_asm.h"
+#include "vap_device.h"
+#include "vap_kernels.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+#include <vector>
+
+namespace vap {
+
+namespace {
+
+constexpr int kLanesThreads = 512;
+constexpr int kLanesProducers = kLanesThreads / 64 - 1;   // wave 0 is the chain wave
+constexpr int kRecBytes = 48;
+constexpr int kTileRecords = 1024;                        // (path, sample) slots per tile = 16 producer batches of 64
+constexpr int kTileBatches = kTileRecords / 64;
+constexpr int kBatchesPerProducer = (kTileBatches + kLanesProducers - 1) / kLanesProducers;
+
+template <int P>
+struct LanesGeo {
+    static constexpr int TS = kTileRecords / P;            // samples per tile
+    static constexpr int stride = P * kRecBytes + 16;      // bytes between consecutive samples' records
+    static constexpr int rec_bytes = TS * stride;          // one record tile
+    static constexpr int out_row = TS + 2;                 // doubles per path in a result tile (padded: bank spread)
+    static constexpr int out_bytes = P * out_row * 8;
+    static constexpr size_t lds_bytes = 2 * (size_t)rec_bytes + 2 * (size_t)out_bytes;
+};
+
+// Workgroup barrier for LDS hand-offs only: this wave's LDS operations have completed (they complete in order), global
+// loads stay in flight across it (__syncthreads() would drain them: the producers' row prefetch lives on that).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// what a producer lane holds for one slot between the load and the arithmetic
+template <typename IO>
+struct SlotIn {
+    double k0, k1, dth, uf;
+    IO acc, vc;
+};
+
+struct PathConsts {   // per path (its own sample spacing), in LDS
+    double twodd, amaxp, adecp, gk, aangp, adecp_b;
+    int N;
+};
+
+template <typename IO, int P, bool VCAP, bool ACC>
+struct Lanes {
+    using G = LanesGeo<P>;
+    static constexpr int TS = G::TS;
+
+    int B, S, blk;
+    const double *K, *DT;
+    const IO *VC;
+    AccRows<IO> acc;
+    IO *V;
+    double *UF;
+    double vmax, h, end_u;
+    const PathConsts *pc;   // LDS
+    unsigned char *rec;     // LDS: two record tiles
+    double *out;            // LDS: two result tiles
+    int *path_dup;          // LDS [P]: the path has a sample with a zero heading difference (forward sweep's finding)
+    int *tile_dup;          // LDS [2]: the backward record tile (by parity) holds such a sample
+
+    __device__ __forceinline__ static void slot_of(int q, int lane, int &p, int &s)
+    {
+        const int f = q * 64 + lane;
+        p = f / TS;
+        s = f % TS;
+    }
+    __device__ __forceinline__ FastConsts<double> consts_of(const PathConsts &c) const
+    {
+        FastConsts<double> f;
+        f.vmax = vmax;
+        f.amaxp = c.amaxp;
+        f.adecp = c.adecp;
+        f.h = h;
+        f.gk = c.gk;
+        f.aangp = c.aangp;
+        return f;
+    }
+
+    // ---- forward: the step (j-1 -> j) into slot j uses k[j-1], dth[j-1] (and k[j-2] for rho); slot 0 and the slots
+    // past the end hold the state (u' = u)
+    // Row loads are unconditional (indices clamped into the buffers, the values of slots that hold no step are
+    // discarded by put_*): straight-line loads keep the compiler's vmcnt accounting exact.
+    __device__ __forceinline__ size_t clamped(int b, int j) const
+    {
+        const int bb = b < B ? b : B - 1;
+        const int jj = j < 0 ? 0 : (j < S ? j : S - 1);
+        return (size_t)bb * S + jj;
+    }
+    __device__ __forceinline__ void load_fwd(int tile, int q, int lane, SlotIn<IO> &in) const
+    {
+        int p, s;
+        slot_of(q, lane, p, s);
+        const int j = tile * TS + s, b = blk * P + p;
+        const size_t i1 = clamped(b, j - 1);
+        in.k0 = K[i1];
+        in.k1 = K[clamped(b, j - 2)];
+        in.dth = DT[i1];
+        if constexpr (ACC) in.acc = acc.fwd[i1];
+        if constexpr (VCAP) in.vc = VC[clamped(b, j)];
+    }
+    __device__ __forceinline__ void put_fwd(int tile, int q, int lane, const SlotIn<IO> &in, unsigned char *rt) const
+    {
+        int p, s;
+        slot_of(q, lane, p, s);
+        const int j = tile * TS + s, b = blk * P + p;
+        const PathConsts c = pc[p];
+        const bool valid = b < B && j >= 1 && j <= c.N - 1;
+        const FastConsts<double> fc = consts_of(c);
+        const double kc = fabs(in.k0), kp = j >= 2 ? fabs(in.k1) : 0.0;
+        double base = fc.amaxp;
+        if constexpr (ACC) base = valid ? c.twodd * (double)in.acc : fc.amaxp;   // MPG:194-196
+        double rho, q2, A, cap;
+        fast_derive_k(fc, kc, kp, base, rho, q2, A, cap);
+        if constexpr (ACC) A = fast_cap_A(fc, kc, A);
+        const double gq = fast_gq(fast_gg(fc, in.dth), q2);
+        double am, g;
+        fast_scale(ACC ? base : fc.amaxp, gq, A, am, g);
+        if constexpr (VCAP) {   // MPG:121,127,153,172: the sample's own initial velocity also bounds the step into it
+            const double vc = (double)in.vc;
+            if (valid && j <= c.N - 2) cap = vmin(cap, vc * vc);
+        }
+        if (valid && g < 0.0) path_dup[p] = 1;
+        if (!valid) { rho = 0.0; g = 0.0; am = 0.0; A = 0.0; cap = Huge<double>::v; }
+        unsigned char *r = rt + s * G::stride + p * kRecBytes;
+        *reinterpret_cast<double2 *>(r) = make_double2(rho, g);
+        *reinterpret_cast<double2 *>(r + 16) = make_double2(am, A);
+        *reinterpret_cast<double *>(r + 32) = cap;
+    }
+    __device__ __forceinline__ void flush_fwd(int tile, int q, int lane, const double *ot) const
+    {
+        int p, s;
+        slot_of(q, lane, p, s);
+        const int j = tile * TS + s, b = blk * P + p;
+        if (b < B && j < pc[p].N) UF[(size_t)b * S + j] = ot[p * G::out_row + s];
+    }
+
+    // ---- backward: the step (j+1 -> j) into slot j uses k[j+1], dth[j] (and k[j+2] for rho) and the forward value of
+    // the sample, folded into the cap; slots at or past the end sample hold end_u (MPG:252-253)
+    __device__ __forceinline__ void load_bwd(int tile, int q, int lane, SlotIn<IO> &in) const
+    {
+        int p, s;
+        slot_of(q, lane, p, s);
+        const int j = tile * TS + s, b = blk * P + p;
+        const size_t i0 = clamped(b, j), i1 = clamped(b, j + 1);
+        in.k0 = K[i1];
+        in.k1 = K[clamped(b, j + 2)];
+        in.dth = DT[i0];
+        in.uf = UF[i0];
+        if constexpr (ACC) in.acc = acc.bwd[i1];
+    }
+    __device__ __forceinline__ void put_bwd(int tile, int q, int lane, const SlotIn<IO> &in, unsigned char *rt, int parity) const
+    {
+        int p, s;
+        slot_of(q, lane, p, s);
+        const int j = tile * TS + s, b = blk * P + p;
+        const PathConsts c = pc[p];
+        const bool valid = b < B && j <= c.N - 2;
+        const FastConsts<double> fc = consts_of(c);
+        const double kc = fabs(in.k0), kn = (j + 2 <= c.N - 1) ? fabs(in.k1) : 0.0;
+        double rho, q2, A, cap;
+        fast_derive_k(fc, kc, kn, ACC ? c.adecp_b : fc.adecp, rho, q2, A, cap);
+        const double g0 = fast_gq(fast_gg(fc, in.dth), q2);
+        double am_in = fc.amaxp;
+        if constexpr (ACC) {
+            // the clamp comes from the sweep's max_dec, the wheel limit from the max_acc the sweep has at j+1
+            // (MPG:256-257); a straight sample, or one with a zero heading difference, has max_dec alone
+            A = fast_cap_A(fc, kc, A);
+            am_in = (!(kc < 1e-6) && !(g0 < 0.0)) ? c.twodd * (double)in.acc : A;
+        }
+        cap = vmin(cap, in.uf);
+        double am, g;
+        fast_scale(am_in, g0, A, am, g);
+        if (!valid) { rho = 0.0; g = 0.0; am = 0.0; A = 0.0; cap = end_u; }
+        // A zero heading difference (g < 0) needs the sign-aware step (MPG:52-59): the chain takes it for the whole
+        // tile (on every other sample it equals the plain step bit for bit).  k_velocity_seq decides per PATH, from the
+        // forward sweep's coefficients; the two findings agree (the same dtheta, the same curvature on both sides of
+        // it) — should they ever not, the sample keeps the plain step, as there.
+        if (g < 0.0) {
+            if (path_dup[p]) tile_dup[parity] = 1;
+            else g = -g;
+        }
+        unsigned char *r = rt + s * G::stride + p * kRecBytes;
+        *reinterpret_cast<double2 *>(r) = make_double2(rho, g);
+        *reinterpret_cast<double2 *>(r + 16) = make_double2(am, A);
+        *reinterpret_cast<double *>(r + 32) = cap;
+    }
+    __device__ __forceinline__ void flush_bwd(int tile, int q, int lane, const double *ot) const
+    {
+        int p, s;
+        slot_of(q, lane, p, s);
+        const int j = tile * TS + s, b = blk * P + p;
+        if (b < B && j < S) V[(size_t)b * S + j] = j < pc[p].N ? (IO)vel_sqrt(ot[p * G::out_row + s]) : (IO)0;
+    }
+
+    // One pipeline step of a producer wave: derive tile `t_put` from the rows in `cur` (loaded during the previous step),
+    // move the results of tile `t_flush` out, then start the loads of tile `t_load` (the next step's t_put) — they are in
+    // flight while this wave waits at the barrier for the chain.  Tiles outside [0, NT) are skipped (fill and drain).
+    template <bool BWD>
+    __device__ __forceinline__ void producer_step(int pw, int lane, int NT, int t_load, int t_put, int t_flush, int parity,
+                                                  SlotIn<IO> (&cur)[kBatchesPerProducer], SlotIn<IO> (&nxt)[kBatchesPerProducer]) const
+    {
+        if (t_put >= 0 && t_put < NT) {
+            unsigned char *rt = rec + (size_t)parity * G::rec_bytes;
+#pragma unroll
+            for (int i = 0; i < kBatchesPerProducer; i++) {
+                const int q = pw + i * kLanesProducers;
+                if (q < kTileBatches) {
+                    if constexpr (BWD) put_bwd(t_put, q, lane, cur[i], rt, parity);
+                    else put_fwd(t_put, q, lane, cur[i], rt);
+                }
+            }
+        }
+        if (t_flush >= 0 && t_flush < NT) {
+            const double *ot = out + (size_t)parity * (G::out_bytes / 8);   // the tile two steps back shares this step's parity
+#pragma unroll
+            for (int i = 0; i < kBatchesPerProducer; i++) {
+                const int q = pw + i * kLanesProducers;
+                if (q < kTileBatches) {
+                    if constexpr (BWD) flush_bwd(t_flush, q, lane, ot);
+                    else flush_fwd(t_flush, q, lane, ot);
+                }
+            }
+        }
+        if (t_load >= 0 && t_load < NT) {
+#pragma unroll
+            for (int i = 0; i < kBatchesPerProducer; i++) {
+                const int q = pw + i * kLanesProducers;
+                if (q < kTileBatches) {
+                    if constexpr (BWD) load_bwd(t_load, q, lane, nxt[i]);
+                    else load_fwd(t_load, q, lane, nxt[i]);
+                }
+            }
+        }
+    }
+};
+
+// Pipeline, per direction, steps it = 0 .. NT+1 with a barrier after each:
+//   step it: producers derive tile #it into record buffer it&1 (rows loaded during step it-1) and start the loads of
+//            tile #(it+1); the chain walks tile #(it-1) out of buffer (it-1)&1 into result buffer (it-1)&1; producers move
+//            tile #(it-2)'s results out of result buffer it&1.
+// (tile #n of the backward sweep is tile NT-1-n of the row.)
+template <typename IO, int P, bool VCAP, bool ACC>
+__global__ __launch_bounds__(kLanesThreads, 2) void k_velocity_lanes(int B, int S, VelConsts<double> c, double start_u, double end_u,
+                                                                     const double *__restrict__ meta,
+                                                                     const double *__restrict__ curv,
+                                                                     const double *__restrict__ dtheta,
+                                                                     const IO *__restrict__ vcap, AccRows<IO> acc,
+                                                                     IO *__restrict__ vel, double *__restrict__ ufwd,
+                                                                     long long *__restrict__ stats)
+{
+    using G = LanesGeo<P>;
+    constexpr int TS = G::TS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ PathConsts s_pc[P];
+    __shared__ int s_nmax, s_pdup[P], s_tdup[2];
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    if (tid == 0) { s_nmax = 0; s_tdup[0] = 0; s_tdup[1] = 0; }
+    if (tid < P) s_pdup[tid] = 0;
+    __syncthreads();
+    if (tid < P) {
+        const int b = blockIdx.x * P + tid;
+        PathConsts pc;
+        pc.N = 0;
+        pc.twodd = pc.amaxp = pc.adecp = pc.gk = pc.aangp = pc.adecp_b = 0.0;
+        if (b < B) {
+            const double *m = meta + (size_t)b * kMetaStride;
+            const double twodd = 2.0 * m[2];
+            const FastConsts<double> fc = make_fast(c, twodd);
+            int N = (int)m[3];
+            N = N < S ? N : S;
+            pc.N = N;
+            pc.twodd = twodd;
+            pc.amaxp = fc.amaxp;
+            pc.adecp = fc.adecp;
+            pc.gk = fc.gk;
+            pc.aangp = fc.aangp;
+            if constexpr (ACC) pc.adecp_b = twodd * (double)acc.dec[b];
+            atomicMax(&s_nmax, N);
+        }
+        s_pc[tid] = pc;
+    }
+    __syncthreads();
+    const int NT = (s_nmax + TS - 1) / TS;
+
+    Lanes<IO, P, VCAP, ACC> L;
+    L.B = B; L.S = S; L.blk = blockIdx.x;
+    L.K = curv; L.DT = dtheta; L.VC = vcap; L.acc = acc; L.V = vel;
+    if constexpr (std::is_same<IO, double>::value) L.UF = reinterpret_cast<double *>(vel);   // fp64 rows: in place
+    else L.UF = ufwd;
+    L.vmax = c.vmax; L.h = c.tw / 2.0; L.end_u = end_u;
+    L.pc = s_pc;
+    L.rec = smem_raw;
+    L.out = reinterpret_cast<double *>(smem_raw + 2 * (size_t)G::rec_bytes);
+    L.path_dup = s_pdup;
+    L.tile_dup = s_tdup;
+
+    if (wv == 0) {
+        // ---------------- the chain wave
+        __builtin_amdgcn_s_setprio(2);
+        const uint32_t rec0 = (uint32_t)(uintptr_t)(L.rec + lane * kRecBytes);
+        const uint32_t out0 = (uint32_t)(uintptr_t)(L.out + lane * G::out_row);
+        double u = start_u, up = 0.0;
+        long long t_chain = 0, t_all = stats ? __builtin_amdgcn_s_memtime() : 0;
+        for (int it = 0; it <= NT + 1; it++) {
+            const long long t0 = stats ? __builtin_amdgcn_s_memtime() : 0;
+            if (it >= 1 && it <= NT && lane < P) {
+                const int par = (it - 1) & 1;
+                chain_fwd<G::stride, TS>(rec0 + par * G::rec_bytes, out0 + par * G::out_bytes, u, up);
+            }
+            if (stats) t_chain += __builtin_amdgcn_s_memtime() - t0;
+            lds_barrier();
+        }
+        const long long t_fwd_all = stats ? __builtin_amdgcn_s_memtime() - t_all : 0;
+        __syncthreads();                       // the turn: the forward values are in memory (see the producers)
+        int dup_tiles = 0;
+        u = end_u;
+        up = 0.0;
+        long long t_chain_b = 0;
+        for (int it = 0; it <= NT + 1; it++) {
+            const long long t0 = stats ? __builtin_amdgcn_s_memtime() : 0;
+            if (it >= 1 && it <= NT && lane < P) {
+                const int par = (it - 1) & 1;
+                const bool dup = s_tdup[par] != 0;
+                if (!dup) {
+                    chain_bwd<G::stride, TS>(rec0 + par * G::rec_bytes, out0 + par * G::out_bytes, u, up);
+                } else {
+                    // a path with a zero heading difference somewhere (dense grids): the sign-aware step, MPG:52-59
+                    const unsigned char *rt = L.rec + (size_t)par * G::rec_bytes + lane * kRecBytes;
+                    double *ot = L.out + (size_t)par * (G::out_bytes / 8) + lane * G::out_row;
+                    for (int s = TS - 1; s >= 0; s--) {
+                        const double2 a = *reinterpret_cast<const double2 *>(rt + s * G::stride);
+                        const double2 b2 = *reinterpret_cast<const double2 *>(rt + s * G::stride + 16);
+                        const double cap = *reinterpret_cast<const double *>(rt + s * G::stride + 32);
+                        u = fast_backward_a<true, false>(b2.x, a.x, a.y, b2.y, cap, u, up, 0.0);
+                        ot[s] = u;
+                    }
+                    if (lane == 0) s_tdup[par] = 0;   // (the producers raise it again two steps on, behind a barrier)
+                    dup_tiles++;
+                }
+            }
+            if (stats) t_chain_b += __builtin_amdgcn_s_memtime() - t0;
+            lds_barrier();
+        }
+        if (stats && lane == 0) {
+            long long *st = stats + (size_t)blockIdx.x * 8;
+            st[0] = NT;
+            st[1] = t_chain;                                   // cycles inside the forward chain loops
+            st[2] = t_fwd_all;                                 // the forward sweep as the chain wave saw it
+            st[3] = t_chain_b;
+            st[4] = __builtin_amdgcn_s_memtime() - t_all;      // both sweeps
+            st[6] = dup_tiles;
+        }
+        return;
+    }
+
+    // ---------------- the producer waves
+    const int pw = wv - 1;
+    SlotIn<IO> ia[kBatchesPerProducer], ib[kBatchesPerProducer];
+    long long t_busy = 0;
+    L.template producer_step<false>(pw, lane, NT, 0, -1, -1, 0, ib, ia);          // rows of tile 0
+    for (int it = 0; it <= NT + 1; it += 2) {
+        long long t0 = stats ? __builtin_amdgcn_s_memtime() : 0;
+        L.template producer_step<false>(pw, lane, NT, it + 1, it, it - 2, 0, ia, ib);
+        if (stats) t_busy += __builtin_amdgcn_s_memtime() - t0;
+        lds_barrier();
+        if (it + 1 <= NT + 1) {
+            t0 = stats ? __builtin_amdgcn_s_memtime() : 0;
+            L.template producer_step<false>(pw, lane, NT, it + 2, it + 1, it - 1, 1, ib, ia);
+            if (stats) t_busy += __builtin_amdgcn_s_memtime() - t0;
+            lds_barrier();
+        }
+    }
+    if (stats && tid == 64) stats[(size_t)blockIdx.x * 8 + 5] = t_busy;   // producer 0 (three batches per tile), forward
+    // the turn: every forward value this workgroup stored has reached memory before any wave of it reads one back
+    __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0) expcnt(0) lgkmcnt(0)
+    __syncthreads();
+    {
+        // backward: pipeline tile #n is row tile NT-1-n
+        auto rt = [NT](int n) { return (n >= 0 && n < NT) ? NT - 1 - n : -1; };
+        L.template producer_step<true>(pw, lane, NT, rt(0), -1, -1, 0, ib, ia);
+        for (int it = 0; it <= NT + 1; it += 2) {
+            L.template producer_step<true>(pw, lane, NT, rt(it + 1), rt(it), rt(it - 2), 0, ia, ib);
+            lds_barrier();
+            if (it + 1 <= NT + 1) {
+                L.template producer_step<true>(pw, lane, NT, rt(it + 2), rt(it + 1), rt(it - 1), 1, ib, ia);
+                lds_barrier();
+            }
+        }
+    }
+    // rows longer than the longest path of the group: zeros past the last tile
+    for (int p = 0; p < P; p++) {
+        const int b = blockIdx.x * P + p;
+        if (b >= B) break;
+        for (int j = NT * TS + (tid - 64); j < S; j += kLanesThreads - 64) vel[(size_t)b * S + j] = (IO)0;
+    }
+}
+
+template <typename IO, int P>
+hipError_t launch_lanes_p(hipStream_t st, int B, int S, const double c[6], double sv, double ev, const double *meta,
+                          const double *curv, const double *dth, const void *vcap, const AccRowsV &accv, void *vel, double *ufwd)
+{
+    using G = LanesGeo<P>;
+    VelConsts<double> vc;
+    vc.vmax = c[0]; vc.amax = c[1]; vc.adec = c[2]; vc.tw = c[5];
+    vc.wmax = 2.0 * vc.vmax / vc.tw;
+    vc.almax = 2.0 * vc.amax / vc.tw;
+    AccRows<IO> acc;
+    acc.fwd = (const IO *)accv.fwd; acc.bwd = (const IO *)accv.bwd; acc.dec = (const IO *)accv.dec;
+    const dim3 grid((B + P - 1) / P), block(kLanesThreads);
+    const size_t lds = G::lds_bytes;
+    // developer knob: VAP_LANES_STATS=1 prints in-kernel cycle shares (synchronises!)
+    static const bool want_stats = getenv("VAP_LANES_STATS") != nullptr;
+    long long *stats = nullptr;
+    if (want_stats) {
+        (void)hipMalloc(&stats, (size_t)grid.x * 8 * sizeof(long long));
+        (void)hipMemsetAsync(stats, 0, (size_t)grid.x * 8 * sizeof(long long), st);
+    }
+#define VAP_LANES_LAUNCH(VCAP_, ACC_)                                                                                       \
+    do {                                                                                                                    \
+        auto kern = k_velocity_lanes<IO, P, VCAP_, ACC_>;                                                                   \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return e;                                                                                      \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, B, S, vc, sv * sv, ev * ev, meta, curv, dth, (const IO *)vcap, acc,  \
+                           (IO *)vel, ufwd, stats);                                                                         \
+    } while (0)
+    if (acc.fwd) VAP_LANES_LAUNCH(true, true);      // (routes with max_acceleration rows always carry initial velocities too)
+    else if (vcap) VAP_LANES_LAUNCH(true, false);
+    else VAP_LANES_LAUNCH(false, false);
+#undef VAP_LANES_LAUNCH
+    if (stats) {
+        std::vector<long long> h((size_t)grid.x * 8);
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(h.data(), stats, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+        (void)hipFree(stats);
+        double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (unsigned w = 0; w < grid.x; w++)
+            for (int k = 0; k < 8; k++) sum[k] += (double)h[(size_t)w * 8 + k] / grid.x;
+        fprintf(stderr, "[lanes P=%d, %u workgroups] tiles %.0f | mean ticks: forward chain loops %.0f of sweep %.0f | backward chain loops %.0f | both sweeps %.0f | producer 0 busy (forward) %.0f | per step: chain %.1f, sweep %.1f | backward tiles with a zero heading difference %.2f\n",
+                P, grid.x, sum[0], sum[1], sum[2], sum[3], sum[4], sum[5], sum[1] / (sum[0] * G::TS), sum[2] / (sum[0] * G::TS), sum[6]);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// paths per workgroup: the smallest group that still leaves at most one workgroup per CU (the chain's latency is the
+// same for 16 and for 64 lanes; fewer paths per group = more CUs streaming rows)
+int velocity_lanes_group(int B)
+{
+    if (B <= 16 * 256) return 16;
+    if (B <= 32 * 256) return 32;
+    return 64;
+}
+
+hipError_t launch_velocity_lanes(hipStream_t st, bool io64, int B, int S, const double c[6], double sv, double ev,
+                                 const double *meta, const void *curv, const void *dth, const void *vcap, const AccRowsV &acc,
+                                 void *vel, void *ufwd, int group)
+{
+    if (acc.fwd && !vcap) return hipErrorInvalidValue;
+    const int P = group > 0 ? group : velocity_lanes_group(B);
+#define VAP_LANES(IO_)                                                                                                          \
+    (P == 16 ? launch_lanes_p<IO_, 16>(st, B, S, c, sv, ev, meta, (const double *)curv, (const double *)dth, vcap, acc, vel, (double *)ufwd) \
+     : P == 32 ? launch_lanes_p<IO_, 32>(st, B, S, c, sv, ev, meta, (const double *)curv, (const double *)dth, vcap, acc, vel, (double *)ufwd) \
+               : launch_lanes_p<IO_, 64>(st, B, S, c, sv, ev, meta, (const double *)curv, (const double *)dth, vcap, acc, vel, (double *)ufwd))
+    if (io64) return VAP_LANES(double);
+    return VAP_LANES(float);
+#undef VAP_LANES
+}
+
+}  // namespace vap
