@@ -217,13 +217,37 @@ struct Lanes {
         if (b < B && j < S) V[(size_t)b * S + j] = j < pc[p].N ? (IO)vel_sqrt(ot[p * G::out_row + s]) : (IO)0;
     }
 
-    // One pipeline step of a producer wave: derive tile `t_put` from the rows in `cur` (loaded during the previous step),
-    // move the results of tile `t_flush` out, then start the loads of tile `t_load` (the next step's t_put) — they are in
-    // flight while this wave waits at the barrier for the chain.  Tiles outside [0, NT) are skipped (fill and drain).
+    // One pipeline step of a producer wave.  `rows` holds the rows of tile `t_put`, loaded during the previous step:
+    // take them (the one wait for memory, exact: nothing younger is in flight), start the loads of tile `t_load` (the
+    // next step's t_put) into the same registers — they fly while this step derives its records, moves the results of
+    // tile `t_flush` out and waits at the barrier — then do that work.  Tiles outside [0, NT) are skipped (fill, drain).
     template <bool BWD>
     __device__ __forceinline__ void producer_step(int pw, int lane, int NT, int t_load, int t_put, int t_flush, int parity,
-                                                  SlotIn<IO> (&cur)[kBatchesPerProducer], SlotIn<IO> (&nxt)[kBatchesPerProducer]) const
+                                                  SlotIn<IO> (&rows)[kBatchesPerProducer]) const
     {
+        SlotIn<IO> cur[kBatchesPerProducer];
+#pragma unroll
+        for (int i = 0; i < kBatchesPerProducer; i++) {
+            cur[i].k0 = opaque(rows[i].k0);
+            cur[i].k1 = opaque(rows[i].k1);
+            cur[i].dth = opaque(rows[i].dth);
+            if constexpr (BWD) cur[i].uf = opaque(rows[i].uf);
+            if constexpr (ACC) cur[i].acc = opaque(rows[i].acc);
+            if constexpr (VCAP && !BWD) cur[i].vc = opaque(rows[i].vc);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            // (unconditional: a tile index outside the row loads clamped, unused values)
+#pragma unroll
+            for (int i = 0; i < kBatchesPerProducer; i++) {
+                const int q = pw + i * kLanesProducers;
+                if (q < kTileBatches) {
+                    if constexpr (BWD) load_bwd(t_load, q, lane, rows[i]);
+                    else load_fwd(t_load, q, lane, rows[i]);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
         if (t_put >= 0 && t_put < NT) {
             unsigned char *rt = rec + (size_t)parity * G::rec_bytes;
 #pragma unroll
@@ -243,16 +267,6 @@ struct Lanes {
                 if (q < kTileBatches) {
                     if constexpr (BWD) flush_bwd(t_flush, q, lane, ot);
                     else flush_fwd(t_flush, q, lane, ot);
-                }
-            }
-        }
-        if (t_load >= 0 && t_load < NT) {
-#pragma unroll
-            for (int i = 0; i < kBatchesPerProducer; i++) {
-                const int q = pw + i * kLanesProducers;
-                if (q < kTileBatches) {
-                    if constexpr (BWD) load_bwd(t_load, q, lane, nxt[i]);
-                    else load_fwd(t_load, q, lane, nxt[i]);
                 }
             }
         }
@@ -380,38 +394,28 @@ __global__ __launch_bounds__(kLanesThreads, 2) void k_velocity_lanes(int B, int 
 
     // ---------------- the producer waves
     const int pw = wv - 1;
-    SlotIn<IO> ia[kBatchesPerProducer], ib[kBatchesPerProducer];
     long long t_busy = 0;
-    L.template producer_step<false>(pw, lane, NT, 0, -1, -1, 0, ib, ia);          // rows of tile 0
-    for (int it = 0; it <= NT + 1; it += 2) {
-        long long t0 = stats ? __builtin_amdgcn_s_memtime() : 0;
-        L.template producer_step<false>(pw, lane, NT, it + 1, it, it - 2, 0, ia, ib);
-        if (stats) t_busy += __builtin_amdgcn_s_memtime() - t0;
-        lds_barrier();
-        if (it + 1 <= NT + 1) {
-            t0 = stats ? __builtin_amdgcn_s_memtime() : 0;
-            L.template producer_step<false>(pw, lane, NT, it + 2, it + 1, it - 1, 1, ib, ia);
+    auto sweep = [&](auto bwd_tag) {
+        constexpr bool BWD = decltype(bwd_tag)::value;
+        // pipeline tile #n -> row tile (clamped outside [0, NT): those loads are never used)
+        auto rt = [NT](int n) { return BWD ? NT - 1 - n : n; };
+        SlotIn<IO> rows[kBatchesPerProducer] = {};
+        L.template producer_step<BWD>(pw, lane, NT, rt(0), -1, -1, 0, rows);
+        for (int it = 0; it <= NT + 1; it++) {
+            const long long t0 = stats ? __builtin_amdgcn_s_memtime() : 0;
+            L.template producer_step<BWD>(pw, lane, NT, rt(it + 1), it < NT ? rt(it) : -1, (it >= 2 && it - 2 < NT) ? rt(it - 2) : -1,
+                                          it & 1, rows);
             if (stats) t_busy += __builtin_amdgcn_s_memtime() - t0;
             lds_barrier();
         }
-    }
+    };
+    sweep(std::false_type());
     if (stats && tid == 64) stats[(size_t)blockIdx.x * 8 + 5] = t_busy;   // producer 0 (three batches per tile), forward
     // the turn: every forward value this workgroup stored has reached memory before any wave of it reads one back
     __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0) expcnt(0) lgkmcnt(0)
     __syncthreads();
-    {
-        // backward: pipeline tile #n is row tile NT-1-n
-        auto rt = [NT](int n) { return (n >= 0 && n < NT) ? NT - 1 - n : -1; };
-        L.template producer_step<true>(pw, lane, NT, rt(0), -1, -1, 0, ib, ia);
-        for (int it = 0; it <= NT + 1; it += 2) {
-            L.template producer_step<true>(pw, lane, NT, rt(it + 1), rt(it), rt(it - 2), 0, ia, ib);
-            lds_barrier();
-            if (it + 1 <= NT + 1) {
-                L.template producer_step<true>(pw, lane, NT, rt(it + 2), rt(it + 1), rt(it - 1), 1, ib, ia);
-                lds_barrier();
-            }
-        }
-    }
+    sweep(std::true_type());
+    if (stats && tid == 64) stats[(size_t)blockIdx.x * 8 + 7] = t_busy;   // ... both sweeps
     // rows longer than the longest path of the group: zeros past the last tile
     for (int p = 0; p < P; p++) {
         const int b = blockIdx.x * P + p;
@@ -460,8 +464,8 @@ hipError_t launch_lanes_p(hipStream_t st, int B, int S, const double c[6], doubl
         double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (unsigned w = 0; w < grid.x; w++)
             for (int k = 0; k < 8; k++) sum[k] += (double)h[(size_t)w * 8 + k] / grid.x;
-        fprintf(stderr, "[lanes P=%d, %u workgroups] tiles %.0f | mean ticks: forward chain loops %.0f of sweep %.0f | backward chain loops %.0f | both sweeps %.0f | producer 0 busy (forward) %.0f | per step: chain %.1f, sweep %.1f | backward tiles with a zero heading difference %.2f\n",
-                P, grid.x, sum[0], sum[1], sum[2], sum[3], sum[4], sum[5], sum[1] / (sum[0] * G::TS), sum[2] / (sum[0] * G::TS), sum[6]);
+        fprintf(stderr, "[lanes P=%d, %u workgroups] tiles %.0f | mean ticks: forward chain loops %.0f of sweep %.0f | backward chain loops %.0f | both sweeps %.0f | producer 0 busy forward %.0f, both %.0f | per step: chain %.1f, sweep %.1f | backward tiles with a zero heading difference %.2f\n",
+                P, grid.x, sum[0], sum[1], sum[2], sum[3], sum[4], sum[5], sum[7], sum[1] / (sum[0] * G::TS), sum[2] / (sum[0] * G::TS), sum[6]);
     }
     return hipGetLastError();
 }
