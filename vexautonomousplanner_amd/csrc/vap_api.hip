@@ -105,12 +105,7 @@ int run_velocity(vap_ctx *ctx, bool f64, bool io64, int B, int S, const double c
             HIP_TRY(vap::launch_velocity_windows(ctx->stream, B, S, cc, sv, ev, meta, curv, dth, vel, flags, ctx->ufwd.ptr,
                                                  ctx->lstate.ptr, (int *)ctx->lcount.ptr));
         } else if (S <= vap::velocity_relax_max_samples(f64, vcap != nullptr)) {
-            void *ufwd = nullptr;
-            if (vap::velocity_relax_uses_windows(f64, S, vcap != nullptr || acc.fwd != nullptr)) {
-                VAP_TRY(ctx->ensure(ctx->ufwd, (size_t)B * S * (f64 ? 8 : 4)));
-                ufwd = ctx->ufwd.ptr;
-            }
-            HIP_TRY(vap::launch_velocity_relax(ctx->stream, f64, io64, B, S, cc, sv, ev, meta, curv, dth, vcap, acc, vel, flags, ufwd));
+            HIP_TRY(vap::launch_velocity_relax(ctx->stream, f64, io64, B, S, cc, sv, ev, meta, curv, dth, vcap, acc, vel, flags));
         } else {
             // long rows: two-level relaxation (host-synchronised super-rounds)
             VAP_TRY(ctx->ensure(ctx->ufwd, (size_t)B * S * (f64 ? 8 : 4)));

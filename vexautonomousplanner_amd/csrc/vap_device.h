@@ -668,10 +668,24 @@ __device__ __forceinline__ void idle_coef(R &rho, R &gq, R &A, R &cap)
 
 // Velocity from its square, the last operation of every velocity kernel (MPG:316 returns v, the kernels
 // carry u = v^2).  fp32: the hardware square root (v_sqrt_f32, 1 ulp) instead of the correctly rounded
-// sequence — one instruction instead of ten, 40 times per thread; all kernels use this one function, so
-// they stay bit-identical to each other.
+// sequence — one instruction instead of ten, 40 times per thread; all kernels use this one function (either
+// precision), so they stay bit-identical to each other.
 __device__ __forceinline__ float vel_sqrt(float u) { return __builtin_amdgcn_sqrtf(u); }
-__device__ __forceinline__ double vel_sqrt(double u) { return sqrt(u); }
+// fp64: the hardware estimate of 1/sqrt(u) (v_rsq_f64), one coupled Newton step on (sqrt, 1/(2 sqrt)) and a final
+// residual correction — eight instructions, within an ulp of the correctly rounded root (the library sqrt is ~22
+// instructions with scaling for denormals, which a squared velocity never is).  u = 0 (a zero start / end velocity)
+// gives 0.
+__device__ __forceinline__ double vel_sqrt(double u)
+{
+    const double y = __builtin_amdgcn_rsq(u);
+    double s = u * y, h = 0.5 * y;
+    const double r = fma(-h, s, 0.5);
+    s = fma(s, r, s);
+    h = fma(h, r, h);
+    const double d = fma(-s, s, u);
+    s = fma(d, h, s);
+    return u > 0.0 ? s : 0.0;
+}
 
 __device__ __forceinline__ float med3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
 __device__ __forceinline__ double med3(double a, double lo, double hi) { return fmin(fmax(a, lo), hi); }

@@ -74,10 +74,7 @@ int velocity_relax_acc_max_samples(bool f64);
 // vcap: optional [B][S] per-sample initial velocities (NULL = plain paths)
 hipError_t launch_velocity_relax(hipStream_t st, bool r64, bool io64, int B, int S, const double c[6], double sv, double ev,
                                  const double *meta, const void *curv, const void *dth, const void *vcap,
-                                 const AccRowsV &acc, void *vel, uint32_t *flags, void *ufwd = nullptr);
-// true when launch_velocity_relax would walk the row in windows: it then needs ufwd, a [B][S] scratch row of the
-// arithmetic type for the forward sweep's squared velocities
-bool velocity_relax_uses_windows(bool r64, int S, bool limits);
+                                 const AccRowsV &acc, void *vel, uint32_t *flags);
 // rows longer than velocity_relax_max_samples(): two-level relaxation, synchronises the stream once per super-round
 size_t velocity_long_state_bytes(bool f64, int B, int S);
 size_t velocity_long_counter_bytes(bool f64, int B, int S);

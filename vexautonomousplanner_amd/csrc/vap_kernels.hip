@@ -315,6 +315,7 @@ __global__ __launch_bounds__(256) void k_lut(int W, const double *__restrict__ s
 // broadcasts), the scanner wave adds, all threads store distances and slopes (256-byte rows).
 // Same expressions in the same order as k_lut: the tables are bit-identical.
 constexpr int kLutManyPaths = 64, kLutManyTile = 32, kLutManyThreads = 256;
+constexpr int kLutManyMinPaths = 32768;   // batches from here on (and W <= 9) take the lane-per-path table kernel
 __global__ __launch_bounds__(kLutManyThreads) void k_lut_many(int B, int W, const double *__restrict__ segments,
                                                                double *__restrict__ lut, double *__restrict__ slopes,
                                                                double *__restrict__ meta, uint32_t *__restrict__ flags,
@@ -1397,438 +1398,6 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
 }
 
 // ------------------------------------------------------------------------------------------------
-// K5d: k_velocity_relax for plain fp64 rows of ~10^4 samples (config 3 / 4 in the default mode) with
-// PER-WAVEFRONT phases.  In K5b the two sweeps are workgroup-wide phases, and each is as long as its ramp:
-// out of the start the forward sweep climbs ~63 chunks without touching a cap (one chain, walked by one lane of
-// wave 0 at the step's dependent-issue latency), into the stop the backward sweep does the same in the last wave —
-// one after the other, with the rest of the CU idle (one path per CU: the coefficients fill the register file).
-// Here a wavefront whose forward chunks have settled commits them and starts its backward sweep on its own, so the
-// backward ramp is walked while wave 0 still climbs the forward one:
-//   * both input rows stay in LDS for the whole kernel (2 x 10^4 x 8 B = the CU's 160 KB; sample i of chunk c, slot s
-//     sits at s*NC1 + c with NC1 odd: a lane's reads are conflict-free), so any wave can derive either sweep's
-//     coefficients at any time, and the curvature row is read from HBM once instead of twice;
-//   * a wave in forward mode whose lanes have no work left, and whose lower neighbour wave has none either (the one
-//     wave behind a climbing ramp waits: the ramp usually ends in it), commits its forward values with the incoming
-//     states it has, remembers lane 0's incoming state (s_ffin) and lane 63's outgoing one (s_fout, republished every
-//     round), derives the backward coefficients and relaxes backwards; forward-mode waves publish "no state yet" for
-//     the backward hand-off and the wave below then starts from its own seed, as every chunk does;
-//   * if the forward state entering a backward-mode wave later differs from the one it committed with, the wave goes
-//     back: forward coefficients again, forward seeds, forward mode (counted in the statistics; rare);
-//   * the workgroup ends when every wave is in backward mode and none had work for a whole round: each wave then
-//     committed with the final state of the wave below it (wave 0's is the given start), i.e. the forward values are
-//     the sequential sweep's, and the backward fixed point is the sequential sweep's as in K5b — bit for bit.
-// One workgroup barrier per round in either mode, so waves in different modes stay in step.
-// MEASURED (config 3, default mode): bit-identical to the sequential sweep, no wave ever sent back, 13.3 rounds — and
-// 242 k cycles per path against K5b's 153 k.  A coefficient phase costs a wave ~13 k cycles (4 fp64 reciprocals per
-// sample, latency-bound when one wave runs it alone), the waves settle one after the other as boundary states ripple
-// upwards, so their phases land in DIFFERENT rounds, and with one barrier per round every one of them holds up all
-// eight waves: ~7 x 13 k cycles that K5b pays once, in parallel.  Letting only the top waves go early removes the
-// stagger but then the lower waves' backward ripple costs what it did in K5b.  Kept behind VAP_RELAX_OVL=1.
-// ------------------------------------------------------------------------------------------------
-template <typename IO>
-__global__ __launch_bounds__(512, 2) void k_velocity_ovl(int S, int NC1, VelConsts<double> c, double start_u, double end_u,
-                                                          const double *__restrict__ meta,
-                                                          const double *__restrict__ curv,
-                                                          const double *__restrict__ dtheta,
-                                                          IO *__restrict__ vel, uint32_t *__restrict__ flags,
-                                                          long long *__restrict__ stats)
-{
-    using R = double;
-    constexpr int L = 20, MAXW = 8, kInner = 8;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    R *rowK = reinterpret_cast<R *>(smem_raw);
-    R *rowD = rowK + (size_t)NC1 * L;
-    __shared__ BoundaryState<R> s_fb[2][MAXW + 2];   // forward: the state leaving wave w sits at [w + 1]
-    __shared__ BoundaryState<R> s_bb[2][MAXW + 2];   // backward: the state leaving wave w (downwards) sits at [w]
-    __shared__ BoundaryState<R> s_ffin[MAXW + 2];    // backward-mode wave: the forward state it committed with
-    __shared__ BoundaryState<R> s_fout[MAXW + 2];    // ... and its forward outgoing state
-    __shared__ BoundaryState<R> s_pend[MAXW + 2];    // the forward state that sent a wave back to its forward sweep
-    __shared__ int s_quiet[2][MAXW + 2];
-    __shared__ int s_any[3];
-    __shared__ int s_dup, s_back;
-    const long long t_start = stats ? __builtin_amdgcn_s_memtime() : 0;
-    const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
-    const int wv = tid >> 6, lane = tid & 63;
-    const double *m = meta + (size_t)b * kMetaStride;
-    const R twodd = (R)2 * (R)m[2];
-    const int N = (int)m[3];
-    const size_t row = (size_t)b * S;
-    const R *K = curv + row, *DT = dtheta + row;
-    FastConsts<R> fc = make_fast(c, twodd);
-    // (the step constants in scalar registers: the coefficient phases run with all 200 array registers live)
-    fc.vmax = uniform_pinned(fc.vmax); fc.amaxp = uniform_pinned(fc.amaxp); fc.adecp = uniform_pinned(fc.adecp);
-    fc.h = uniform_pinned(fc.h); fc.gk = uniform_pinned(fc.gk); fc.aangp = uniform_pinned(fc.aangp);
-    const R hugeS = uniform_pinned(Huge<R>::v);
-    const int lo = tid * L;
-    R q[L], g[L], A[L], cp[L], am[L];
-    if (tid == 0) { s_any[0] = 0; s_any[1] = 0; s_any[2] = 0; s_dup = 0; s_back = 0; }
-    if (tid < 2 * (MAXW + 2)) {
-        s_bb[tid / (MAXW + 2)][tid % (MAXW + 2)] = BoundaryState<R>{(R)-1, (R)-1};
-        s_fb[tid / (MAXW + 2)][tid % (MAXW + 2)] = BoundaryState<R>{(R)-1, (R)-1};
-    }
-
-    // ---------------- both rows into LDS, transposed: sample i -> (i % L) * NC1 + i / L
-    const int cells = NC1 * L;
-    {
-        constexpr int ITER = L / 2 + 1;
-        const bool aligned = (S & 1) == 0;
-        const double2 *K2 = reinterpret_cast<const double2 *>(K), *D2 = reinterpret_cast<const double2 *>(DT);
-        double2 vk[ITER], vd[ITER];
-#pragma unroll
-        for (int it = 0; it < ITER; it++) {
-            const int p = tid + it * T, i = 2 * p;
-            if (aligned && i + 1 < S) {
-                vk[it] = K2[p];
-                vd[it] = D2[p];
-            } else {
-                vk[it].x = i < S ? K[i] : (R)0;
-                vk[it].y = i + 1 < S ? K[i + 1] : (R)0;
-                vd[it].x = i < S ? DT[i] : (R)0;
-                vd[it].y = i + 1 < S ? DT[i + 1] : (R)0;
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < ITER; it++) {
-            const int i = 2 * (tid + it * T);
-            if (i < cells) {   // L is even: i and i + 1 share a chunk
-                const int ch = i / L, sl = i - ch * L;
-                rowK[sl * NC1 + ch] = vk[it].x;
-                rowK[(sl + 1) * NC1 + ch] = vk[it].y;
-                rowD[sl * NC1 + ch] = vd[it].x;
-                rowD[(sl + 1) * NC1 + ch] = vd[it].y;
-            }
-        }
-    }
-    __syncthreads();
-    // sample lo + k of a row, -2 <= k <= L + 1.  Unconditional loads from clamped addresses (a conditional one becomes a
-    // branch around every ds_read): where the row has no such sample the value is whatever the clamped cell holds, and
-    // every such slot is masked by a select below (valid / idle_coef, the (j >= 2) and (j + 2 <= N - 1) selects).
-    const int c0 = tid < NC1 ? tid : NC1 - 1;
-    const int cm = c0 > 0 ? c0 - 1 : 0, cq = c0 + 1 < NC1 ? c0 + 1 : NC1 - 1;
-    // (cc: the chunk index through opaque() at every use site — the coefficient phases run inside the round loop and
-    // depend on nothing it changes, so the compiler would hoist all of them, 400 registers' worth, in front of it)
-    auto rd = [&](const R *rw, int k, int cc) __attribute__((always_inline)) -> R {
-        if (k < 0) return rw[(L + k) * NC1 + cc + (cm - c0)];
-        if (k < L) return rw[k * NC1 + cc];
-        return rw[(k - L) * NC1 + cc + (cq - c0)];
-    };
-    constexpr int BK = 4;
-
-    // forward coefficients (the step (j-1 -> j) into owned sample j uses k[j-1], dth[j-1], and k[j-2] for rho)
-    auto derive_fwd = [&]() __attribute__((always_inline)) -> bool {
-        bool dup = false;
-        const int cc = opaque(c0);
-        const int lo_ = opaque(lo);   // (as cc: the per-sample predicates would otherwise be hoisted, 40 mask pairs)
-        R kp = (R)fabs(rd(rowK, -2, cc));
-        R kc = (R)fabs(rd(rowK, -1, cc));
-#pragma unroll
-        for (int s0 = 0; s0 < L; s0 += BK) {
-            __builtin_amdgcn_sched_barrier(0);   // one batch after the other: everything here is independent of the next
-            R kn[BK];
-#pragma unroll
-            for (int i = 0; i < BK; i++) kn[i] = (R)fabs(rd(rowK, s0 + i, cc));
-#pragma unroll
-            for (int i = 0; i < BK; i++) {
-                const int s = s0 + i, j = lo_ + s;
-                const bool valid = j >= 1 && j <= N - 1;
-                fast_derive_k(fc, kc, (j >= 2) ? kp : (R)0, fc.amaxp, q[s], g[s], A[s], cp[s]);   // g[s] = k^2 for now
-                if (!valid) idle_coef(q[s], g[s], A[s], cp[s]);
-                q[s] = opaque(q[s]);
-                kp = kc;
-                kc = kn[i];
-            }
-        }
-#pragma unroll
-        for (int s0 = 0; s0 < L; s0 += BK) {
-            __builtin_amdgcn_sched_barrier(0);
-            R dn[BK];
-#pragma unroll
-            for (int i = 0; i < BK; i++) dn[i] = rd(rowD, s0 + i - 1, cc);
-#pragma unroll
-            for (int i = 0; i < BK; i++) {
-                const int s = s0 + i, j = lo_ + s;
-                const bool valid = j >= 1 && j <= N - 1;
-                const R gq = fast_gq(fast_gg(fc, dn[i], hugeS), g[s], hugeS);
-                R amv, gv;
-                fast_scale(fc.amaxp, valid ? gq : (R)0, A[s], amv, gv);
-                g[s] = opaque(gv);
-                am[s] = amv;
-                dup |= g[s] < (R)0;
-            }
-        }
-        return dup;
-    };
-    // backward coefficients (the step (j+1 -> j) into owned sample j uses k[j+1], dth[j], and k[j+2] for rho); cp[]
-    // holds the committed forward values on entry and min(cap, forward value) on exit
-    constexpr int BKB = 2;
-    auto derive_bwd = [&]() __attribute__((always_inline)) {
-        const int cc = opaque(c0);
-        const int lo_ = opaque(lo);
-        R kc = (R)fabs(rd(rowK, 1, cc));
-#pragma unroll
-        for (int s0 = 0; s0 < L; s0 += BKB) {
-            __builtin_amdgcn_sched_barrier(0);
-            R kn[BKB], dn[BKB];
-#pragma unroll
-            for (int i = 0; i < BKB; i++) {
-                kn[i] = (R)fabs(rd(rowK, s0 + i + 2, cc));
-                dn[i] = rd(rowD, s0 + i, cc);
-            }
-#pragma unroll
-            for (int i = 0; i < BKB; i++) {
-                const int s = s0 + i, j = lo_ + s;
-                const bool valid = j <= N - 2;
-                R qq;
-                const R ufwd_s = cp[s];
-                fast_derive_k(fc, kc, (j + 2 <= N - 1) ? kn[i] : (R)0, fc.adecp, q[s], qq, A[s], cp[s]);
-                g[s] = fast_gq(fast_gg(fc, dn[i], hugeS), qq, hugeS);
-                if (!valid) { idle_coef(q[s], g[s], A[s], cp[s]); cp[s] = end_u; }
-                else cp[s] = vmin(cp[s], ufwd_s);
-                R amv, gv;
-                fast_scale(fc.amaxp, g[s], A[s], amv, gv);
-                g[s] = gv;
-                am[s] = amv;
-                q[s] = opaque(q[s]);
-                kc = kn[i];
-            }
-        }
-    };
-
-    // zero heading differences (the backward step's sign-aware variant): the marker the forward coefficients carry,
-    // found ahead of them so that the coefficient phases below have no workgroup-wide part
-    {
-        bool dup = false;
-        const int cc = opaque(c0);
-        R kc = (R)fabs(rd(rowK, -1, cc));
-#pragma unroll
-        for (int s = 0; s < L; s++) {
-            const int j = lo + s;
-            const bool valid = j >= 1 && j <= N - 1;
-            const R gg = fast_gg(fc, rd(rowD, s - 1, cc), hugeS);
-            dup |= valid && !(kc * kc < (R)1e-12) && gg >= hugeS;
-            kc = (R)fabs(rd(rowK, s, cc));
-        }
-        if (dup) s_dup = 1;
-    }
-    const bool fwd_active = lo <= N - 1;           // the chunk holds at least one real sample
-    const int last_chunk = (N - 1) / L;            // chunk that owns the fixed end sample
-    const bool bwd_active = tid <= last_chunk;
-    R in_u = (R)0, in_w = (R)0, out_u = (R)0, out_w = (R)0;
-    bool resume = false;
-    bool need = false;
-    int mode = 0;                                  // 0 forward, 1 backward: uniform over a wavefront
-    int rounds = 0, f_cur = 0, f_nxt = 1, f_prv = 2;
-    __syncthreads();
-    const bool any_dup = s_dup != 0;
-    const long long t_loop0 = stats ? __builtin_amdgcn_s_memtime() : 0;
-    const int guard = 2 * T + 8;
-    long long acc_inner = 0, acc_wait = 0, acc_switch = 0;
-    bool finished = false;
-
-    // An epoch = this wave's coefficients for its current sweep (straight-line code at the top: the arrays are
-    // defined here and nowhere else, so nothing but cp[] — the committed forward values — is carried around the
-    // loop), then rounds until the workgroup is done or the wave changes its sweep.  Waves sit in different epochs;
-    // each executes one s_barrier per round wherever it is.
-    while (!finished) {
-        const long long te0 = stats ? __builtin_amdgcn_s_memtime() : 0;
-        if (mode == 0) {
-            (void)derive_fwd();
-            if (tid == 0) { in_u = start_u; in_w = (R)0; }
-            else { in_u = cp[0]; in_w = in_u; }
-            if (resume && lane == 0 && tid > 0) { const BoundaryState<R> pd = s_pend[wv]; in_u = pd.u; in_w = pd.w; }
-            need = fwd_active;
-        } else {
-            derive_bwd();
-            if (tid >= last_chunk) { in_u = end_u; in_w = (R)0; }
-            else { in_u = cp[L - 1]; in_w = in_u; }
-            need = bwd_active;
-        }
-        out_u = in_u;
-        out_w = in_w;
-        if (stats) acc_switch += __builtin_amdgcn_s_memtime() - te0;
-        while (true) {
-            bool settled = true;    // the wave ended this round's evaluations with no lane waiting
-            const long long tr0 = stats ? __builtin_amdgcn_s_memtime() : 0;
-            if (mode == 0) {
-#pragma unroll 1
-                for (int k = 0; k < kInner; k++) {
-                    if (need) {
-                        R uu = in_u, wp = in_w;
-#pragma unroll
-                        for (int s = 0; s < L; s++) {
-                            if (s == 0 && tid == 0) continue;   // sample 0 is the given start velocity (MPG:189)
-                            uu = step_fwd(am[s], q[s], g[s], A[s], cp[s], uu, wp);
-                        }
-                        out_u = uu;
-                        out_w = wp;
-                    }
-                    const R nu = wave_shift_up(out_u), nw = wave_shift_up(out_w);
-                    need = false;
-                    if (lane > 0 && fwd_active) {
-                        need = !(same_bits(nu, in_u) && same_bits(nw, in_w));
-                        in_u = nu;
-                        in_w = nw;
-                    }
-                    settled = __ballot(need) == 0;
-                    if (settled) break;
-                }
-            } else {
-#pragma unroll 1
-                for (int k = 0; k < kInner; k++) {
-                    if (need) {
-                        R uu = in_u, wp = in_w;
-                        if (any_dup) {
-#pragma unroll
-                            for (int s = L - 1; s >= 0; s--) uu = bwd_step<true, true>(am[s], q[s], g[s], A[s], cp[s], uu, wp, (R)0);
-                        } else {
-#pragma unroll
-                            for (int s = L - 1; s >= 0; s--) uu = bwd_step<false, true>(am[s], q[s], g[s], A[s], cp[s], uu, wp, (R)0);
-                        }
-                        out_u = uu;
-                        out_w = wp;
-                    }
-                    const R nu = wave_shift_down(out_u), nw = wave_shift_down(out_w);
-                    need = false;
-                    if (lane < 63 && tid < last_chunk) {
-                        need = !(same_bits(nu, in_u) && same_bits(nw, in_w));
-                        in_u = nu;
-                        in_w = nw;
-                    }
-                    settled = __ballot(need) == 0;
-                    if (settled) break;
-                }
-            }
-            const int pb = rounds & 1;
-            const long long tr1 = stats ? __builtin_amdgcn_s_memtime() : 0;
-            if (mode == 0) {
-                if (lane == 63) s_fb[pb][wv + 1] = BoundaryState<R>{out_u, out_w};
-                if (lane == 0) s_bb[pb][wv] = BoundaryState<R>{(R)-1, (R)-1};   // no backward state yet
-            } else {
-                if (lane == 63) s_fb[pb][wv + 1] = s_fout[wv];
-                if (lane == 0) s_bb[pb][wv] = BoundaryState<R>{out_u, out_w};
-            }
-            if (lane == 0) s_quiet[pb][wv] = (mode == 1 || settled) ? 1 : 0;
-            if (tid == 0) s_any[f_nxt] = 0;
-            __syncthreads();
-            const long long tr2 = stats ? __builtin_amdgcn_s_memtime() : 0;
-            acc_inner += tr1 - tr0;
-            acc_wait += tr2 - tr1;
-            const int changed_last = s_any[f_prv];
-            if (rounds > 0 && changed_last == 0) { finished = true; break; }   // every wave in backward mode, none had work
-            if (rounds > 2 * guard) {
-                if (tid == 0 && flags) atomicOr(&flags[b], VAP_FLAG_NOCONVERGE_BIT);
-                finished = true;
-                break;
-            }
-            const BoundaryState<R> fin = s_fb[pb][wv];   // forward state entering this wave
-            bool change = false;
-            if (mode == 0) {
-                if (lane == 0 && tid > 0 && fwd_active) {
-                    need = !(same_bits(fin.u, in_u) && same_bits(fin.w, in_w));
-                    in_u = fin.u;
-                    in_w = fin.w;
-                }
-                const bool below_quiet = wv == 0 || s_quiet[pb][wv - 1] != 0;
-                const bool forced = rounds > guard;
-                if ((__ballot(need) == 0 && settled && below_quiet) || forced) {
-                    if (forced && tid == 0 && flags) atomicOr(&flags[b], VAP_FLAG_NOCONVERGE_BIT);
-                    // forward commit with the incoming states the lanes hold; the next epoch is this wave's backward sweep
-                    R uu = in_u, wp = in_w;
-#pragma unroll
-                    for (int s = 0; s < L; s++) {
-                        if (s == 0 && tid == 0) { cp[0] = start_u; continue; }
-                        uu = step_fwd(am[s], q[s], g[s], A[s], cp[s], uu, wp);
-                        cp[s] = uu;
-                    }
-                    if (lane == 0) s_ffin[wv] = BoundaryState<R>{in_u, in_w};
-                    if (lane == 63) s_fout[wv] = BoundaryState<R>{uu, wp};
-                    mode = 1;
-                    change = true;
-                }
-            } else {
-                const BoundaryState<R> used = s_ffin[wv];
-                const bool moved = lane == 0 && tid > 0 && fwd_active && !(same_bits(fin.u, used.u) && same_bits(fin.w, used.w));
-                if (__ballot(moved) != 0) {
-                    // the forward state this wave committed with has changed: back to the forward sweep
-                    if (lane == 0 && stats) atomicAdd(&s_back, 1);
-                    if (lane == 0) s_pend[wv] = fin;
-                    resume = true;
-                    mode = 0;
-                    change = true;
-                } else {
-                    const BoundaryState<R> nb = s_bb[pb][wv + 1];
-                    if (lane == 63 && tid < last_chunk) {
-                        const R bu = nb.u < (R)0 ? cp[L - 1] : nb.u;     // the wave above has no backward state yet: the seed
-                        const R bw = nb.u < (R)0 ? cp[L - 1] : nb.w;
-                        need = !(same_bits(bu, in_u) && same_bits(bw, in_w));
-                        in_u = bu;
-                        in_w = bw;
-                    }
-                }
-            }
-            if (need || mode == 0 || change) s_any[f_cur] = 1;
-            { const int t = f_prv; f_prv = f_cur; f_cur = f_nxt; f_nxt = t; }
-            rounds++;
-            if (change) break;
-        }
-    }
-    const long long t_loop1 = stats ? __builtin_amdgcn_s_memtime() : 0;
-    // backward commit (every wave is in backward mode here)
-    if (bwd_active && mode == 1) {
-        R uu = in_u, wp = in_w;
-        if (any_dup) {
-#pragma unroll
-            for (int s = L - 1; s >= 0; s--) cp[s] = uu = bwd_step<true, true>(am[s], q[s], g[s], A[s], cp[s], uu, wp, (R)0);
-        } else {
-#pragma unroll
-            for (int s = L - 1; s >= 0; s--) cp[s] = uu = bwd_step<false, true>(am[s], q[s], g[s], A[s], cp[s], uu, wp, (R)0);
-        }
-    }
-    // velocities leave through LDS (the rows are dead) in K5b's padded layout, 16 bytes per lane to HBM
-    IO *ostage = reinterpret_cast<IO *>(smem_raw);
-    const int cbase = tid * (L + 1);
-#pragma unroll
-    for (int s = 0; s < L; s++) {
-        const int j = lo + s;
-        ostage[cbase + s] = j < N ? (IO)vel_sqrt(cp[s]) : (IO)0;
-    }
-    __syncthreads();
-    IO *V = vel + row;
-    const int TL = T * L;
-    {
-        constexpr int VW = 16 / sizeof(IO);
-        const int n = S < TL ? S : TL;
-        if ((S % VW) == 0) {
-            using VT = typename std::conditional<sizeof(IO) == 4, float4, double2>::type;
-            VT *dst = reinterpret_cast<VT *>(V);
-            for (int i = tid; i < n / VW; i += T) {
-                VT v;
-                IO *e = reinterpret_cast<IO *>(&v);
-                const int p0 = stage_pos<IO, L>(i * VW);
-#pragma unroll
-                for (int k = 0; k < VW; k++) e[k] = ostage[p0 + k];   // L % VW == 0: the VW elements share a chunk
-                dst[i] = v;
-            }
-            for (int i = (n / VW) * VW + tid; i < n; i += T) V[i] = ostage[stage_pos<IO, L>(i)];
-        } else {
-            for (int i = tid; i < n; i += T) V[i] = ostage[stage_pos<IO, L>(i)];
-        }
-    }
-    for (int j = TL + tid; j < S; j += T) V[j] = (IO)0;
-    if (stats && tid == 0) {
-        long long *st = stats + (size_t)b * 8;
-        st[0] = rounds;
-        st[1] = s_back;
-        st[2] = t_loop0 - t_start;                       // load + forward coefficients
-        st[3] = t_loop1 - t_loop0;                       // rounds (both sweeps, mode changes included)
-        st[4] = acc_inner;
-        st[6] = acc_wait;
-        st[7] = acc_switch;
-        st[5] = __builtin_amdgcn_s_memtime() - t_loop1;  // commit + store
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // K5c: rows longer than the register-resident kernel covers (config 2: one path, 10^6 samples).
 // Same relaxation, two levels: a row is cut into super-chunks of SC = MAXT*L samples, one workgroup
 // each, which relax internally exactly like K5b for a given incoming interface state; the interface
@@ -2103,431 +1672,6 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_long(int S, int nsc, in
 }
 
 // ------------------------------------------------------------------------------------------------
-// K5d: the same relaxation, one workgroup per path walking the row in WINDOWS of T*L samples — forward
-// through the windows in order, then backward in reverse order.  A window's incoming state is final when
-// its turn comes (it is the previous window's outgoing state), so every window is relaxed exactly once and
-// the result equals the sequential sweep bit for bit, like K5b's.  What the windows buy is residency: a
-// thread holds L samples' coefficients instead of S/T, so an fp64 row of 10 000 samples needs 256 threads
-// x 20 samples (two paths per CU, each with its own critical chain in flight) instead of 512 x 20 (one).
-// Forward squared velocities wait in an HBM scratch row (ufwd, arithmetic type) for the backward sweep.
-// ------------------------------------------------------------------------------------------------
-// what a forward window hands to the next one: the recurrence state after its last sample and the inputs of the
-// next window's first step that lie before that window (|k| of its last two samples, |dtheta| of its last one)
-template <typename R>
-struct WindowCarry {
-    R u, w, k1, k2, d1;
-};
-
-template <typename R, int T>
-struct WinShared {
-    BoundaryState<R> bs[2][T / 64 + 2];   // states crossing a wavefront boundary, by round parity
-    int any[3];                           // "some chunk's incoming state changed", rotating slots
-    int dup;
-    WindowCarry<R> carry[2];              // by window parity: a window reads one while filling the other
-};
-
-// Forward sweep of window sc (samples [base, base + T*L)): the step (j-1 -> j) into owned sample j uses k[j-1],
-// dth[j-1] (and k[j-2] for rho).  Same phases as k_velocity_relax, with the previous chunk of thread 0 coming
-// from the carry.
-template <typename R, int L, int T>
-__device__ __forceinline__ void fwd_window(R *__restrict__ stage, WinShared<R, T> &sh, int S, int N, int base, size_t row,
-                                           const FastConsts<R> &fc, R start_u, const R *__restrict__ K,
-                                           const R *__restrict__ DT, R *__restrict__ ufwd, uint32_t *__restrict__ flags,
-                                           int b, int tid_in, int &rounds_out)
-{
-    // (the thread index is hidden from loop-invariant code motion: hoisted out of the window loop, the per-thread
-    // addresses of every phase of both sweeps would be live — and spilled — throughout)
-    const int tid = opaque(tid_in);
-    constexpr int SC = T * L;
-    constexpr int VW = 16 / (int)sizeof(R);
-    constexpr int BK = (L % 8 == 0) ? 8 : ((L % 5 == 0) ? 5 : 4);
-    const int lo = tid * L, jb = base + lo;
-    const bool aligned = (S % VW) == 0;
-    const int cbase = tid * (L + 1);
-    auto cpos = [&](int k) { return k < 0 ? cbase + k - 1 : (k < L ? cbase + k : cbase + k + 1); };
-    // the carry of the previous window (published by the barrier that ended it) is read where it is needed, by
-    // thread 0 only; this window's goes into the other slot as soon as its parts are known
-    const WindowCarry<R> &cin = sh.carry[(base / SC + 1) & 1];
-    WindowCarry<R> &cout = sh.carry[(base / SC) & 1];
-    if (tid == 0) { sh.any[0] = 0; sh.any[1] = 0; sh.any[2] = 0; }
-    int n_in = N - base;
-    n_in = n_in < 0 ? 0 : (n_in > SC ? SC : n_in);
-    // commit mode, as the fp64 instantiations of k_velocity_relax: no array of squared velocities; the rounds move
-    // boundary states only and one commit evaluation writes the result over cp[]
-    R q[L], g[L], A[L], cp[L];
-    constexpr bool PSA = ScaledStep<R>::value;   // the scaled fp64 step keeps its `am` per slot (fast_scale)
-    R am[PSA ? L : 1];
-    stage_load<R, L>(stage, K + base, n_in, SC, aligned, tid, T);
-    __syncthreads();
-    {
-        R kp = tid > 0 ? (R)fabs(stage[cpos(-2)]) : (base > 0 ? cin.k2 : (R)0);
-        R kc = tid > 0 ? (R)fabs(stage[cpos(-1)]) : (base > 0 ? cin.k1 : (R)0);
-#pragma unroll
-        for (int s0 = 0; s0 < L; s0 += BK) {
-            R kn[BK];
-#pragma unroll
-            for (int i = 0; i < BK; i++) kn[i] = (R)fabs(stage[cpos(s0 + i)]);
-#pragma unroll
-            for (int i = 0; i < BK; i++) {
-                const int s = s0 + i, j = jb + s;
-                const bool valid = j >= 1 && j <= N - 1;
-                fast_derive_k(fc, kc, (j >= 2) ? kp : (R)0, fc.amaxp, q[s], g[s], A[s], cp[s]);   // g[s] = k^2 for now
-                if (!valid) idle_coef(q[s], g[s], A[s], cp[s]);
-                q[s] = opaque(q[s]);
-                kp = kc;
-                kc = kn[i];
-            }
-        }
-        if (tid == T - 1) { cout.k1 = kc; cout.k2 = kp; }   // |k| of the window's last sample and of the one before it
-    }
-    __syncthreads();
-    stage_load<R, L>(stage, DT + base, n_in, SC, aligned, tid, T);
-    __syncthreads();
-    bool dup = false;
-#pragma unroll
-    for (int s0 = 0; s0 < L; s0 += BK) {
-        R dn[BK];
-#pragma unroll
-        for (int i = 0; i < BK; i++) {
-            const int k = s0 + i - 1;
-            dn[i] = (k < 0 && tid == 0) ? (base > 0 ? cin.d1 : (R)1) : stage[cpos(k)];
-        }
-#pragma unroll
-        for (int i = 0; i < BK; i++) {
-            const int s = s0 + i, j = jb + s;
-            const bool valid = j >= 1 && j <= N - 1;
-            const R gq = fast_gq(fast_gg(fc, dn[i]), g[s]);
-            R amv, gv;
-            fast_scale(fc.amaxp, valid ? gq : (R)0, A[s], amv, gv);
-            g[s] = opaque(gv);
-            if constexpr (PSA) am[s] = amv;
-            dup |= g[s] < (R)0;
-        }
-    }
-    if (tid == T - 1) cout.d1 = stage[cpos(L - 1)];
-    if (dup) sh.dup = 1;   // (read by the backward sweep, many barriers later)
-    R in_u, in_w;
-    if (tid == 0) { in_u = base > 0 ? cin.u : start_u; in_w = base > 0 ? cin.w : (R)0; }
-    else { in_u = cp[0]; in_w = in_u; }
-    const bool active = jb <= N - 1;       // the chunk holds at least one real sample
-    bool need = active;
-    R out_u = in_u, out_w = in_w;
-    int rounds = 0;
-    __syncthreads();
-    constexpr int kInner = 8;
-    const int wv = tid >> 6, lane = tid & 63;
-    int f_cur = 0, f_nxt = 1, f_prv = 2;
-    while (true) {
-#pragma unroll 1
-        for (int k = 0; k < kInner; k++) {
-            if (need) {
-                R uu = in_u, wp = in_w;
-#pragma unroll
-                for (int s = 0; s < L; s++) {
-                    if (s == 0 && jb == 0) continue;   // sample 0 is the given start velocity (MPG:189)
-                    uu = step_fwd(PSA ? am[PSA ? s : 0] : fc.amaxp, q[s], g[s], A[s], cp[s], uu, wp);
-                }
-                out_u = uu;
-                out_w = wp;
-            }
-            const R nu = wave_shift_up(out_u), nw = wave_shift_up(out_w);
-            need = false;
-            if (lane > 0 && active) {
-                need = !(same_bits(nu, in_u) && same_bits(nw, in_w));
-                in_u = nu;
-                in_w = nw;
-            }
-            if (__ballot(need) == 0) break;
-        }
-        const int pb = rounds & 1;
-        if (lane == 63) sh.bs[pb][wv + 1] = BoundaryState<R>{out_u, out_w};
-        if (tid == 0) sh.any[f_nxt] = 0;
-        __syncthreads();
-        const int changed_last = sh.any[f_prv];
-        const BoundaryState<R> nb = sh.bs[pb][wv];
-        if (rounds > 0 && changed_last == 0) break;   // nobody had work left last round
-        if (lane == 0 && tid > 0 && active) {
-            need = !(same_bits(nb.u, in_u) && same_bits(nb.w, in_w));
-            in_u = nb.u;
-            in_w = nb.w;
-        }
-        if (need) sh.any[f_cur] = 1;
-        { const int t = f_prv; f_prv = f_cur; f_cur = f_nxt; f_nxt = t; }
-        rounds++;
-        if (rounds > 2 * T + 8) {
-            if (tid == 0 && flags) atomicOr(&flags[b], VAP_FLAG_NOCONVERGE_BIT);
-            break;
-        }
-    }
-    rounds_out += rounds;
-    if (tid == T - 1) { cout.u = out_u; cout.w = out_w; }
-    {   // commit: the converged incoming states are final
-        R uu = in_u, wp = in_w;
-#pragma unroll
-        for (int s = 0; s < L; s++) {
-            if (s == 0 && jb == 0) { cp[0] = start_u; continue; }
-            uu = step_fwd(PSA ? am[PSA ? s : 0] : fc.amaxp, q[s], g[s], A[s], cp[s], uu, wp);
-            cp[s] = uu;
-        }
-    }
-    // the squared velocities wait in the scratch row for the backward sweep
-    __syncthreads();
-#pragma unroll
-    for (int s = 0; s < L; s++) stage[cpos(s)] = cp[s];
-    __syncthreads();
-    {
-        R *dst = ufwd + row + base;
-        int n = S - base;
-        n = n > SC ? SC : n;
-        if (aligned && (L % VW) == 0) {
-            using VT = typename std::conditional<sizeof(R) == 4, float4, double2>::type;
-            VT *dst4 = reinterpret_cast<VT *>(dst);
-            for (int i = tid; i < n / VW; i += T) {
-                VT v;
-                R *e = reinterpret_cast<R *>(&v);
-                const int p0 = stage_pos<R, L>(i * VW);
-#pragma unroll
-                for (int k = 0; k < VW; k++) e[k] = stage[p0 + k];
-                dst4[i] = v;
-            }
-            for (int i = (n / VW) * VW + tid; i < n; i += T) dst[i] = stage[stage_pos<R, L>(i)];
-        } else {
-            for (int i = tid; i < n; i += T) dst[i] = stage[stage_pos<R, L>(i)];
-        }
-    }
-    __syncthreads();   // the stage and the shared words belong to the next window from here on
-}
-
-// Backward sweep of window sc: the step (j+1 -> j) into owned sample j uses k[j+1], dth[j] (and k[j+2] for rho);
-// slots at or past the fixed end sample N-1 are idle slots holding end_u.
-template <typename R, typename IO, int L, int T>
-__device__ __forceinline__ void bwd_window(unsigned char *__restrict__ smem_raw, WinShared<R, T> &sh, int S, int N, int base,
-                                           bool last_window, size_t row, const FastConsts<R> &fc, R end_u,
-                                           const R *__restrict__ K, const R *__restrict__ DT, const R *__restrict__ ufwd,
-                                           IO *__restrict__ vel, bool any_dup, uint32_t *__restrict__ flags, int b, int tid_in,
-                                           int &rounds_out)
-{
-    const int tid = opaque(tid_in);
-    R *stage = reinterpret_cast<R *>(smem_raw);
-    constexpr int SC = T * L;
-    constexpr int VW = 16 / (int)sizeof(R);
-    constexpr int BK = (L % 8 == 0) ? 8 : ((L % 5 == 0) ? 5 : 4);
-    const int lo = tid * L, jb = base + lo;
-    const bool aligned = (S % VW) == 0;
-    const int cbase = tid * (L + 1);
-    auto cpos = [&](int k) { return k < 0 ? cbase + k - 1 : (k < L ? cbase + k : cbase + k + 1); };
-    const WindowCarry<R> &cin = sh.carry[(base / SC + 1) & 1];
-    WindowCarry<R> &cout = sh.carry[(base / SC) & 1];
-    if (tid == 0) { sh.any[0] = 0; sh.any[1] = 0; sh.any[2] = 0; }
-    int n_in = N - base;
-    n_in = n_in < 0 ? 0 : (n_in > SC ? SC : n_in);
-    // commit mode: no array of squared velocities; the forward values are folded into the caps
-    R q[L], g[L], A[L], cp[L];
-    constexpr bool PSA = ScaledStep<R>::value;
-    R am[PSA ? L : 1];
-    {
-        int n = N - base;
-        n = n < 0 ? 0 : (n > SC + 2 ? SC + 2 : n);
-        stage_load<R, L>(stage, K + base, n, SC + 2, aligned, tid, T);
-    }
-    __syncthreads();
-    {
-        R kc = (R)fabs(stage[cpos(1)]);
-#pragma unroll
-        for (int s0 = 0; s0 < L; s0 += BK) {
-            R kn[BK];
-#pragma unroll
-            for (int i = 0; i < BK; i++) kn[i] = (R)fabs(stage[cpos(s0 + i + 2)]);
-#pragma unroll
-            for (int i = 0; i < BK; i++) {
-                const int s = s0 + i, j = jb + s;
-                fast_derive_k(fc, kc, (j + 2 <= N - 1) ? kn[i] : (R)0, fc.adecp, q[s], g[s], A[s], cp[s]);   // g[s] = k^2 for now
-                q[s] = opaque(q[s]);
-                kc = kn[i];
-            }
-        }
-    }
-    __syncthreads();
-    stage_load<R, L>(stage, DT + base, n_in, SC, aligned, tid, T);
-    __syncthreads();
-#pragma unroll
-    for (int s0 = 0; s0 < L; s0 += BK) {
-        R dn[BK];
-#pragma unroll
-        for (int i = 0; i < BK; i++) dn[i] = stage[cpos(s0 + i)];
-#pragma unroll
-        for (int i = 0; i < BK; i++) {
-            const int s = s0 + i, j = jb + s;
-            const bool valid = j <= N - 2;
-            R gq = fast_gq(fast_gg(fc, dn[i]), g[s]);
-            if (!valid) idle_coef(q[s], gq, A[s], cp[s]);
-            R amv, gv;
-            fast_scale(fc.amaxp, gq, A[s], amv, gv);
-            g[s] = opaque(gv);
-            if constexpr (PSA) am[s] = amv;
-        }
-    }
-    __syncthreads();
-    stage_load<R, L>(stage, ufwd + row + base, n_in, SC, aligned, tid, T);
-    __syncthreads();
-#pragma unroll
-    for (int s = 0; s < L; s++) {
-        const R uf = stage[cpos(s)];           // forward squared velocity of the sample
-        cp[s] = (jb + s <= N - 2) ? vmin(cp[s], uf) : end_u;
-    }
-    // chunk holding the fixed end sample (only the path's last window has it)
-    const int last_chunk = last_window ? (N - 1 - base) / L : T;
-    R in_u, in_w;
-    if (tid >= last_chunk) { in_u = end_u; in_w = (R)0; }
-    else if (tid == T - 1) { in_u = cin.u; in_w = cin.w; }     // the window above handed its first chunk's state down
-    else { in_u = cp[L - 1]; in_w = in_u; }
-    const bool active = tid <= last_chunk;
-    const bool has_nb = tid < last_chunk && tid < T - 1;       // takes its incoming state from the next chunk
-    bool need = active;
-    R out_u = in_u, out_w = in_w;
-    int rounds = 0;
-    __syncthreads();
-    constexpr int kInner = 8;
-    const int wv = tid >> 6, lane = tid & 63;
-    int f_cur = 0, f_nxt = 1, f_prv = 2;
-    while (true) {
-#pragma unroll 1
-        for (int k = 0; k < kInner; k++) {
-            if (need) {
-                R uu = in_u, wp = in_w;
-                if (any_dup) {
-#pragma unroll
-                    for (int s = L - 1; s >= 0; s--) uu = bwd_step<true, true>(PSA ? am[PSA ? s : 0] : fc.amaxp, q[s], g[s], A[s], cp[s], uu, wp, (R)0);
-                } else {
-#pragma unroll
-                    for (int s = L - 1; s >= 0; s--) uu = bwd_step<false, true>(PSA ? am[PSA ? s : 0] : fc.amaxp, q[s], g[s], A[s], cp[s], uu, wp, (R)0);
-                }
-                out_u = uu;
-                out_w = wp;
-            }
-            const R nu = wave_shift_down(out_u), nw = wave_shift_down(out_w);
-            need = false;
-            if (lane < 63 && has_nb) {
-                need = !(same_bits(nu, in_u) && same_bits(nw, in_w));
-                in_u = nu;
-                in_w = nw;
-            }
-            if (__ballot(need) == 0) break;
-        }
-        const int pb = rounds & 1;
-        if (lane == 0) sh.bs[pb][wv] = BoundaryState<R>{out_u, out_w};
-        if (tid == 0) sh.any[f_nxt] = 0;
-        __syncthreads();
-        const int changed_last = sh.any[f_prv];
-        const BoundaryState<R> nb = sh.bs[pb][wv + 1];
-        if (rounds > 0 && changed_last == 0) break;
-        if (lane == 63 && has_nb) {
-            need = !(same_bits(nb.u, in_u) && same_bits(nb.w, in_w));
-            in_u = nb.u;
-            in_w = nb.w;
-        }
-        if (need) sh.any[f_cur] = 1;
-        { const int t = f_prv; f_prv = f_cur; f_cur = f_nxt; f_nxt = t; }
-        rounds++;
-        if (rounds > 2 * T + 8) {
-            if (tid == 0 && flags) atomicOr(&flags[b], VAP_FLAG_NOCONVERGE_BIT);
-            break;
-        }
-    }
-    rounds_out += rounds;
-    // the backward step reads the forward value of the sample it overwrites: one commit evaluation with the final
-    // incoming state stores the backward velocities
-    if (active) {
-        R uu = in_u, wp = in_w;
-        if (any_dup) {
-#pragma unroll
-            for (int s = L - 1; s >= 0; s--) cp[s] = uu = bwd_step<true, true>(PSA ? am[PSA ? s : 0] : fc.amaxp, q[s], g[s], A[s], cp[s], uu, wp, (R)0);
-        } else {
-#pragma unroll
-            for (int s = L - 1; s >= 0; s--) cp[s] = uu = bwd_step<false, true>(PSA ? am[PSA ? s : 0] : fc.amaxp, q[s], g[s], A[s], cp[s], uu, wp, (R)0);
-        }
-        out_u = uu;
-        out_w = wp;
-    }
-    if (tid == 0) { cout.u = out_u; cout.w = out_w; }
-    // velocities leave through the stage (as IO elements) so the row is written with 16 bytes per lane
-    __syncthreads();
-    IO *ostage = reinterpret_cast<IO *>(smem_raw);
-    constexpr int OW = 16 / (int)sizeof(IO);
-#pragma unroll
-    for (int s = 0; s < L; s++) ostage[cpos(s)] = (jb + s) < N ? (IO)vel_sqrt(cp[s]) : (IO)0;
-    __syncthreads();
-    {
-        IO *dst = vel + row + base;
-        int n = S - base;
-        n = n > SC ? SC : n;
-        if ((S % OW) == 0 && (L % OW) == 0) {
-            using VT = typename std::conditional<sizeof(IO) == 4, float4, double2>::type;
-            VT *dst4 = reinterpret_cast<VT *>(dst);
-            for (int i = tid; i < n / OW; i += T) {
-                VT v;
-                IO *e = reinterpret_cast<IO *>(&v);
-                const int p0 = stage_pos<IO, L>(i * OW);
-#pragma unroll
-                for (int k = 0; k < OW; k++) e[k] = ostage[p0 + k];
-                dst4[i] = v;
-            }
-            for (int i = (n / OW) * OW + tid; i < n; i += T) dst[i] = ostage[stage_pos<IO, L>(i)];
-        } else {
-            for (int i = tid; i < n; i += T) dst[i] = ostage[stage_pos<IO, L>(i)];
-        }
-    }
-    __syncthreads();
-}
-
-// NW = number of windows the row capacity needs (S <= NW*T*L), unrolled: inside a run-time loop the compiler
-// hoists every per-thread address of every phase out of it and spills them.
-template <typename R, typename IO, int L, int T, int MINW, int NW>
-__global__ __launch_bounds__(T, MINW) void k_velocity_win(int S, VelConsts<R> c, R start_u, R end_u,
-                                                          const double *__restrict__ meta, const R *__restrict__ curv,
-                                                          const R *__restrict__ dtheta, R *__restrict__ ufwd,
-                                                          IO *__restrict__ vel, uint32_t *__restrict__ flags,
-                                                          long long *__restrict__ stats)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];   // (T*L + T + 16) elements of R
-    __shared__ WinShared<R, T> sh;
-    const long long t0 = stats ? __builtin_amdgcn_s_memtime() : 0;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const double *m = meta + (size_t)b * kMetaStride;
-    const R twodd = (R)2 * (R)m[2];
-    const int N = (int)m[3];
-    constexpr int SC = T * L;
-    const int last_sc = N > 0 ? (N - 1) / SC : 0;
-    const size_t row = (size_t)b * S;
-    const R *K = curv + row, *DT = dtheta + row;
-    const FastConsts<R> fc = make_fast(c, twodd);
-    if (tid == 0) sh.dup = 0;
-    __syncthreads();
-    int rounds_f = 0, rounds_b = 0;
-#pragma unroll
-    for (int sc = 0; sc < NW; sc++)
-        if (sc <= last_sc)
-            fwd_window<R, L, T>(reinterpret_cast<R *>(smem_raw), sh, S, N, sc * SC, row, fc, start_u, K, DT, ufwd, flags, b, tid, rounds_f);
-    const long long t1 = stats ? __builtin_amdgcn_s_memtime() : 0;
-    const bool any_dup = sh.dup != 0;   // (the last window ended with a barrier)
-#pragma unroll
-    for (int sc = NW - 1; sc >= 0; sc--)
-        if (sc <= last_sc)
-            bwd_window<R, IO, L, T>(smem_raw, sh, S, N, sc * SC, sc == last_sc, row, fc, end_u, K, DT, ufwd, vel, any_dup, flags, b, tid,
-                                    rounds_b);
-    for (int j = (last_sc + 1) * SC + tid; j < S; j += T) vel[row + j] = (IO)0;
-    if (stats && tid == 0) {
-        long long *st = stats + (size_t)b * 8;
-        st[0] = rounds_f;
-        st[1] = rounds_b;
-        st[2] = 0;
-        st[3] = t1 - t0;
-        st[4] = __builtin_amdgcn_s_memtime() - t1;
-        st[5] = 0;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // Segment blocks -> monomial coefficients (scratch used by k_sample).
 // ------------------------------------------------------------------------------------------------
 __global__ void k_power(int n_seg, const double *__restrict__ segments, double *__restrict__ power)
@@ -2618,10 +1762,8 @@ hipError_t launch_lut(hipStream_t st, int B, int W, const double *seg, double *l
     static const bool want_stats = getenv("VAP_LUT_STATS") != nullptr;
     long long *stats = nullptr;
     if (want_stats) (void)hipMalloc(&stats, (size_t)B * 4 * sizeof(long long));
-    static const char *many_cfg = getenv("VAP_LUT_MANY");   // developer knob: 0 = never, 1 = always
-    const int many = many_cfg ? atoi(many_cfg) : -1;
     // (the 64 paths' segment rows are staged in LDS: 6 KB per segment column, so short paths only)
-    if (!want_stats && !rt.sptab && W <= 9 && (many == 1 || (many != 0 && B >= 32768))) {
+    if (!want_stats && !rt.sptab && W <= 9 && B >= kLutManyMinPaths) {
         // very many paths: 64 per workgroup, the sequential sums of 64 paths in the lanes of one wavefront
         hipLaunchKernelGGL(k_lut_many, dim3((B + kLutManyPaths - 1) / kLutManyPaths), dim3(kLutManyThreads),
                            sizeof(double) * kLutManyPaths * (W - 1) * 12, st, B, W, seg, lut, slopes, meta, flags, grid);
@@ -2788,93 +1930,10 @@ static void launch_relax_t(hipStream_t st, int B, int S, const double c[6], doub
     }
 }
 
-template <typename IO>
-static void launch_ovl_t(hipStream_t st, int B, int S, int NC1, const double c[6], double sv, double ev, const double *meta,
-                         const void *curv, const void *dth, void *vel, uint32_t *flags)
-{
-    constexpr int L = 20;
-    const int nch = (S + L - 1) / L;
-    const int T = (nch + 63) / 64 * 64;
-    const size_t lds = (size_t)2 * NC1 * L * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_velocity_ovl<IO>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
-        attr_set = true;
-    }
-    static const bool want_stats = getenv("VAP_RELAX_STATS") != nullptr;
-    long long *stats = nullptr;
-    if (want_stats) (void)hipMalloc(&stats, (size_t)B * 8 * sizeof(long long));
-    hipLaunchKernelGGL((k_velocity_ovl<IO>), dim3(B), dim3(T), lds, st, S, NC1, make_consts<double>(c), sv * sv, ev * ev, meta,
-                       (const double *)curv, (const double *)dth, (IO *)vel, flags, stats);
-    if (stats) {
-        std::vector<long long> h((size_t)B * 8);
-        (void)hipStreamSynchronize(st);
-        (void)hipMemcpy(h.data(), stats, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
-        (void)hipFree(stats);
-        double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        long long mx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int b = 0; b < B; b++)
-            for (int k = 0; k < 8; k++) {
-                sum[k] += (double)h[(size_t)b * 8 + k];
-                if (h[(size_t)b * 8 + k] > mx[k]) mx[k] = h[(size_t)b * 8 + k];
-            }
-        fprintf(stderr, "[ovl T=%d] rounds mean %.1f max %lld | waves sent back mean %.2f max %lld | ticks mean: load %.0f rounds %.0f commit %.0f | max: %lld %lld %lld | wave 0: evaluations %.0f barrier %.0f hand-off + mode changes %.0f\n",
-                T, sum[0] / B, mx[0], sum[1] / B, mx[1], sum[2] / B, sum[3] / B, sum[5] / B, mx[2], mx[3], mx[5], sum[4] / B, sum[6] / B, sum[7] / B);
-    }
-}
-
-template <typename R, typename IO, int L, int T, int MINW, int NW>
-static void launch_win_t(hipStream_t st, int B, int S, const double c[6], double sv, double ev, const double *meta,
-                         const void *curv, const void *dth, void *ufwd, void *vel, uint32_t *flags)
-{
-    const R s = (R)sv, e = (R)ev;
-    static const bool want_stats = getenv("VAP_RELAX_STATS") != nullptr;
-    long long *stats = nullptr;
-    if (want_stats) (void)hipMalloc(&stats, (size_t)B * 8 * sizeof(long long));
-    const size_t lds = sizeof(R) * ((size_t)T * L + T + 16);
-    hipLaunchKernelGGL((k_velocity_win<R, IO, L, T, MINW, NW>), dim3(B), dim3(T), lds, st, S, make_consts<R>(c), s * s, e * e, meta,
-                       (const R *)curv, (const R *)dth, (R *)ufwd, (IO *)vel, flags, stats);
-    if (stats) {
-        std::vector<long long> h((size_t)B * 8);
-        (void)hipStreamSynchronize(st);
-        (void)hipMemcpy(h.data(), stats, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
-        (void)hipFree(stats);
-        double sum[6] = {0, 0, 0, 0, 0, 0};
-        long long mx[6] = {0, 0, 0, 0, 0, 0};
-        for (int b = 0; b < B; b++)
-            for (int k = 0; k < 6; k++) {
-                sum[k] += (double)h[(size_t)b * 8 + k];
-                if (h[(size_t)b * 8 + k] > mx[k]) mx[k] = h[(size_t)b * 8 + k];
-            }
-        fprintf(stderr, "[win L=%d T=%d] workgroup rounds fwd mean %.1f max %lld | bwd mean %.1f max %lld | ticks mean: fwd %.0f bwd %.0f | max: %lld %lld\n",
-                L, T, sum[0] / B, mx[0], sum[1] / B, mx[1], sum[3] / B, sum[4] / B, mx[3], mx[4]);
-    }
-}
-
-// rows the windowed kernel takes instead of the whole-row one (plain rows only): the fp64 recurrence beyond 4096
-// samples, where the whole-row kernel needs 512 threads x 256 registers — one path per CU
-bool velocity_relax_uses_windows(bool r64, int S, bool limits)
-{
-    static const char *cfg = getenv("VAP_RELAX_WIN");   // developer knob: 0 = never, 1 = also the fp32 recurrence
-    const int force = cfg ? atoi(cfg) : -1;
-    if (limits || force <= 0) return false;   // (default: the whole-row kernel; windows measured no faster)
-    if (r64) return S > 512 * 8 && S <= 2 * 256 * 20;
-    return S > 256 * 16 && S <= 4 * 256 * 20;
-}
-
 hipError_t launch_velocity_relax(hipStream_t st, bool r64, bool io64, int B, int S, const double c[6], double sv, double ev,
                                  const double *meta, const void *curv, const void *dth, const void *vcap,
-                                 const AccRowsV &acc, void *vel, uint32_t *flags, void *ufwd)
+                                 const AccRowsV &acc, void *vel, uint32_t *flags)
 {
-    if (velocity_relax_uses_windows(r64, S, vcap != nullptr || acc.fwd != nullptr) && ufwd) {
-        static const char *lcfg = getenv("VAP_WIN_L");   // developer knob (tuning only): 16 or 20
-        const int wl = lcfg ? atoi(lcfg) : 20;
-        (void)wl;
-        if (r64 && io64) launch_win_t<double, double, 20, 256, 2, 2>(st, B, S, c, sv, ev, meta, curv, dth, ufwd, vel, flags);
-        else if (r64) launch_win_t<double, float, 20, 256, 2, 2>(st, B, S, c, sv, ev, meta, curv, dth, ufwd, vel, flags);
-        else launch_win_t<float, float, 20, 256, 4, 4>(st, B, S, c, sv, ev, meta, curv, dth, ufwd, vel, flags);
-        return hipGetLastError();
-    }
     if (acc.fwd) {
         // per-sample max_acceleration: one more register array per thread, so shorter chunks
         // (velocity_relax_acc_max_samples() is the limit the caller checks)
@@ -2893,24 +1952,10 @@ hipError_t launch_velocity_relax(hipStream_t st, bool r64, bool io64, int B, int
 #undef VAP_RELAX_ACC
         return hipGetLastError();
     }
-    // plain fp64 rows of 4097 .. 10 000 samples: developer knob VAP_RELAX_OVL=1 selects the kernel with per-wavefront
-    // phases (K5d; bit-identical, measured 2x SLOWER than K5b at config 3 — see its header and DESIGN.md §5)
-    if (r64 && !vcap && S > 512 * 8) {
-        static const char *ovl = getenv("VAP_RELAX_OVL");
-        constexpr int L = 20;
-        const int nch = (S + L - 1) / L, NC1 = nch | 1;
-        const size_t lds = (size_t)2 * NC1 * L * sizeof(double);
-        if (ovl && atoi(ovl) == 1 && lds + 1536 <= 160 * 1024) {
-            if (io64) launch_ovl_t<double>(st, B, S, NC1, c, sv, ev, meta, curv, dth, vel, flags);
-            else launch_ovl_t<float>(st, B, S, NC1, c, sv, ev, meta, curv, dth, vel, flags);
-            return hipGetLastError();
-        }
-    }
 #define VAP_RELAX(R_, IO_, L_, MAXT_, W_) launch_relax_t<R_, IO_, L_, MAXT_, W_>(st, B, S, c, sv, ev, meta, curv, dth, vcap, acc, vel, flags)
     // chunk length: the longest instantiated L whose thread count still covers the row — fewer, longer
     // chunks mean fewer rounds (rounds ~ longest unclamped run / L) and fewer waves to synchronise
-    static const char *w16 = getenv("VAP_RELAX_W16");   // developer knob: 0 = no single-wavefront variant
-    const bool one_wave = !(w16 && atoi(w16) == 0) && S > 64 * 4 && S <= 64 * 16;
+    const bool one_wave = S > 64 * 4 && S <= 64 * 16;
     if (r64 && io64) {
         if (S <= 64 * 4) VAP_RELAX(double, double, 4, 256, 4);
         else if (one_wave) VAP_RELAX(double, double, 16, 64, 2);   // one wavefront per path: no workgroup barrier at all
@@ -2925,14 +1970,8 @@ hipError_t launch_velocity_relax(hipStream_t st, bool r64, bool io64, int B, int
         else VAP_RELAX(double, float, 20, 512, 2);
         return hipGetLastError();
     }
-    // developer knob (tuning only): VAP_RELAX_CFG=<L>, one of the instantiated chunk lengths
-    static const char *cfg = getenv("VAP_RELAX_CFG");
-    int L = cfg ? atoi(cfg) : 0;
-    if (L == 0) L = S <= 64 * 4 ? 4 : (S <= 256 * 16 ? 16 : 40);
-    if (L == 4 && S <= 1024 * 4) VAP_RELAX(float, float, 4, 1024, 8);
-    else if (L == 10 && S <= 1024 * 10) VAP_RELAX(float, float, 10, 1024, 4);
-    else if (L == 16 && S <= 512 * 16) VAP_RELAX(float, float, 16, 512, 4);
-    else if (L == 20 && S <= 512 * 20) VAP_RELAX(float, float, 20, 512, 4);
+    if (S <= 64 * 4) VAP_RELAX(float, float, 4, 1024, 8);
+    else if (S <= 256 * 16) VAP_RELAX(float, float, 16, 512, 4);
     else VAP_RELAX(float, float, 40, 512, 2);
 #undef VAP_RELAX
     return hipGetLastError();
@@ -3014,11 +2053,9 @@ hipError_t launch_velocity_long(hipStream_t st, bool f64, bool io64, int B, int 
 {
     // super-chunk = 512, 128 or 64 threads x 16 samples (fp64): few long rows (config 2: one) are cut finer so that the
     // chip has more workgroups to run and a super-round is shorter
-    static const char *cfg64 = getenv("VAP_LONG_T64");   // developer knob (tuning only): 64, 128 or 512
-    const int forced64 = cfg64 ? atoi(cfg64) : 0;
     if (f64) {
         const long blocks512 = (long)B * ((S + 512 * 16 - 1) / (512 * 16));
-        const int t64 = forced64 ? forced64 : (blocks512 < 256 ? 64 : (blocks512 < 1024 ? 128 : 512));
+        const int t64 = blocks512 < 256 ? 64 : (blocks512 < 1024 ? 128 : 512);
 #define VAP_LONG64(IO_, T_) velocity_long_t<double, IO_, 16, T_, 2>(st, B, S, c, sv, ev, meta, curv, dth, vel, flags, ufwd, state, counters)
         if (io64) return t64 == 64 ? VAP_LONG64(double, 64) : (t64 == 128 ? VAP_LONG64(double, 128) : VAP_LONG64(double, 512));
         return t64 == 64 ? VAP_LONG64(float, 64) : (t64 == 128 ? VAP_LONG64(float, 128) : VAP_LONG64(float, 512));
@@ -3026,10 +2063,8 @@ hipError_t launch_velocity_long(hipStream_t st, bool f64, bool io64, int B, int 
     }
     // super-chunk = 256 or 64 threads x 40 samples: few long rows (config 2: one) are cut finer so that the
     // chip has more workgroups to run and a super-round is shorter
-    static const char *cfg = getenv("VAP_LONG_T");   // developer knob (tuning only): 64 or 256
-    const int forced = cfg ? atoi(cfg) : 0;
     const long blocks256 = (long)B * ((S + 256 * 40 - 1) / (256 * 40));
-    if (forced == 64 || (forced != 256 && blocks256 < 512))
+    if (blocks256 < 512)
         return velocity_long_t<float, float, 40, 64, 2>(st, B, S, c, sv, ev, meta, curv, dth, vel, flags, ufwd, state, counters);
     return velocity_long_t<float, float, 40, 256, 2>(st, B, S, c, sv, ev, meta, curv, dth, vel, flags, ufwd, state, counters);
 }

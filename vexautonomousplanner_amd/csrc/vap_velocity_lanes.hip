@@ -37,7 +37,16 @@ constexpr int kLanesProducers = kLanesThreads / 64 - 1;   // wave 0 is the chain
 constexpr int kRecBytes = 48;
 constexpr int kTileRecords = 1024;                        // (path, sample) slots per tile = 16 producer batches of 64
 constexpr int kTileBatches = kTileRecords / 64;
+// Batches of a tile by producer wave: producer pw takes batches pw, pw + 7, pw + 14 — three for the first two waves, two
+// for the others.  (Waves of a workgroup go to the CU's four SIMDs in turn, so wave 4 shares SIMD 0 with the chain wave
+// and has that SIMD's vector pipe mostly to itself; giving it four batches and the others two was measured: it then sets
+// the step time, at ~950 cycles per batch against ~675 for a SIMD shared by two producers.)
 constexpr int kBatchesPerProducer = (kTileBatches + kLanesProducers - 1) / kLanesProducers;
+__device__ __forceinline__ int batch_of(int wv, int i)   // tile batch i-th of wave wv, or -1
+{
+    const int q = wv - 1 + i * kLanesProducers;
+    return q < kTileBatches ? q : -1;
+}
 
 template <int P>
 struct LanesGeo {
@@ -65,156 +74,139 @@ struct PathConsts {   // per path (its own sample spacing), in LDS
     int N;
 };
 
+// What a producer lane keeps in registers about its slot of batch i for a whole sweep: which path and which sample of
+// a tile it serves is the same in every tile, so the path's constants, its row and the slot's LDS offsets are formed once.
+struct SlotCtx {
+    FastConsts<double> fc;
+    double twodd, adecp_b;
+    size_t row;          // b*S of the path (of the last path for lanes past the batch: their loads stay inside the buffers)
+    int N;               // samples of the path (0: no such path)
+    int s;               // sample within a tile
+    int p;               // path within the group
+    int rec_off;         // byte offset of the slot's record in a record tile
+    int out_off;         // index of the slot's result in a result tile
+    bool live;           // the batch exists for this producer and the path exists
+};
+
 template <typename IO, int P, bool VCAP, bool ACC>
 struct Lanes {
     using G = LanesGeo<P>;
     static constexpr int TS = G::TS;
 
-    int B, S, blk;
+    int S;
     const double *K, *DT;
     const IO *VC;
     AccRows<IO> acc;
     IO *V;
     double *UF;
-    double vmax, h, end_u;
-    const PathConsts *pc;   // LDS
+    double end_u;
     unsigned char *rec;     // LDS: two record tiles
     double *out;            // LDS: two result tiles
-    int *path_dup;          // LDS [P]: the path has a sample with a zero heading difference (forward sweep's finding)
     int *tile_dup;          // LDS [2]: the backward record tile (by parity) holds such a sample
 
-    __device__ __forceinline__ static void slot_of(int q, int lane, int &p, int &s)
+    // Row loads are unconditional (sample indices clamped into the row; the values of slots that hold no step are
+    // discarded by put_*): straight-line loads keep the compiler's vmcnt accounting exact.
+    __device__ __forceinline__ size_t at(const SlotCtx &c, int j) const
     {
-        const int f = q * 64 + lane;
-        p = f / TS;
-        s = f % TS;
-    }
-    __device__ __forceinline__ FastConsts<double> consts_of(const PathConsts &c) const
-    {
-        FastConsts<double> f;
-        f.vmax = vmax;
-        f.amaxp = c.amaxp;
-        f.adecp = c.adecp;
-        f.h = h;
-        f.gk = c.gk;
-        f.aangp = c.aangp;
-        return f;
+        const int jj = j < 0 ? 0 : (j < S ? j : S - 1);
+        return c.row + jj;
     }
 
     // ---- forward: the step (j-1 -> j) into slot j uses k[j-1], dth[j-1] (and k[j-2] for rho); slot 0 and the slots
     // past the end hold the state (u' = u)
-    // Row loads are unconditional (indices clamped into the buffers, the values of slots that hold no step are
-    // discarded by put_*): straight-line loads keep the compiler's vmcnt accounting exact.
-    __device__ __forceinline__ size_t clamped(int b, int j) const
+    __device__ __forceinline__ void load_fwd(const SlotCtx &c, int tile, SlotIn<IO> &in) const
     {
-        const int bb = b < B ? b : B - 1;
-        const int jj = j < 0 ? 0 : (j < S ? j : S - 1);
-        return (size_t)bb * S + jj;
-    }
-    __device__ __forceinline__ void load_fwd(int tile, int q, int lane, SlotIn<IO> &in) const
-    {
-        int p, s;
-        slot_of(q, lane, p, s);
-        const int j = tile * TS + s, b = blk * P + p;
-        const size_t i1 = clamped(b, j - 1);
+        const int j = tile * TS + c.s;
+        const size_t i1 = at(c, j - 1);
         in.k0 = K[i1];
-        in.k1 = K[clamped(b, j - 2)];
+        in.k1 = K[at(c, j - 2)];
         in.dth = DT[i1];
         if constexpr (ACC) in.acc = acc.fwd[i1];
-        if constexpr (VCAP) in.vc = VC[clamped(b, j)];
+        if constexpr (VCAP) in.vc = VC[at(c, j)];
     }
-    __device__ __forceinline__ void put_fwd(int tile, int q, int lane, const SlotIn<IO> &in, unsigned char *rt) const
+    __device__ __forceinline__ void put_fwd(const SlotCtx &c, int tile, const SlotIn<IO> &in, unsigned char *rt, bool &saw_dup) const
     {
-        int p, s;
-        slot_of(q, lane, p, s);
-        const int j = tile * TS + s, b = blk * P + p;
-        const PathConsts c = pc[p];
-        const bool valid = b < B && j >= 1 && j <= c.N - 1;
-        const FastConsts<double> fc = consts_of(c);
+        const int j = tile * TS + c.s;
+        const bool valid = j >= 1 && j <= c.N - 1;
         const double kc = fabs(in.k0), kp = j >= 2 ? fabs(in.k1) : 0.0;
-        double base = fc.amaxp;
-        if constexpr (ACC) base = valid ? c.twodd * (double)in.acc : fc.amaxp;   // MPG:194-196
+        double base = c.fc.amaxp;
+        if constexpr (ACC) base = valid ? c.twodd * (double)in.acc : c.fc.amaxp;   // MPG:194-196
         double rho, q2, A, cap;
-        fast_derive_k(fc, kc, kp, base, rho, q2, A, cap);
-        if constexpr (ACC) A = fast_cap_A(fc, kc, A);
-        const double gq = fast_gq(fast_gg(fc, in.dth), q2);
+        fast_derive_k(c.fc, kc, kp, base, rho, q2, A, cap);
+        if constexpr (ACC) A = fast_cap_A(c.fc, kc, A);
+        const double gq = fast_gq(fast_gg(c.fc, in.dth), q2);
         double am, g;
-        fast_scale(ACC ? base : fc.amaxp, gq, A, am, g);
+        fast_scale(ACC ? base : c.fc.amaxp, gq, A, am, g);
         if constexpr (VCAP) {   // MPG:121,127,153,172: the sample's own initial velocity also bounds the step into it
             const double vc = (double)in.vc;
             if (valid && j <= c.N - 2) cap = vmin(cap, vc * vc);
         }
-        if (valid && g < 0.0) path_dup[p] = 1;
-        if (!valid) { rho = 0.0; g = 0.0; am = 0.0; A = 0.0; cap = Huge<double>::v; }
-        unsigned char *r = rt + s * G::stride + p * kRecBytes;
+        saw_dup |= valid && g < 0.0;
+        // a slot that holds no step (sample 0, past the end, no such path): A = 0 and an infinite cap keep the state,
+        // whatever the other coefficients are (they are finite: the loads were clamped into the rows)
+        A = valid ? A : 0.0;
+        cap = valid ? cap : Huge<double>::v;
+        unsigned char *r = rt + c.rec_off;
         *reinterpret_cast<double2 *>(r) = make_double2(rho, g);
         *reinterpret_cast<double2 *>(r + 16) = make_double2(am, A);
         *reinterpret_cast<double *>(r + 32) = cap;
     }
-    __device__ __forceinline__ void flush_fwd(int tile, int q, int lane, const double *ot) const
+    __device__ __forceinline__ void flush_fwd(const SlotCtx &c, int tile, const double *ot) const
     {
-        int p, s;
-        slot_of(q, lane, p, s);
-        const int j = tile * TS + s, b = blk * P + p;
-        if (b < B && j < pc[p].N) UF[(size_t)b * S + j] = ot[p * G::out_row + s];
+        const int j = tile * TS + c.s;
+        if (j < c.N) UF[c.row + j] = ot[c.out_off];
     }
 
     // ---- backward: the step (j+1 -> j) into slot j uses k[j+1], dth[j] (and k[j+2] for rho) and the forward value of
     // the sample, folded into the cap; slots at or past the end sample hold end_u (MPG:252-253)
-    __device__ __forceinline__ void load_bwd(int tile, int q, int lane, SlotIn<IO> &in) const
+    __device__ __forceinline__ void load_bwd(const SlotCtx &c, int tile, SlotIn<IO> &in) const
     {
-        int p, s;
-        slot_of(q, lane, p, s);
-        const int j = tile * TS + s, b = blk * P + p;
-        const size_t i0 = clamped(b, j), i1 = clamped(b, j + 1);
+        const int j = tile * TS + c.s;
+        const size_t i0 = at(c, j), i1 = at(c, j + 1);
         in.k0 = K[i1];
-        in.k1 = K[clamped(b, j + 2)];
+        in.k1 = K[at(c, j + 2)];
         in.dth = DT[i0];
         in.uf = UF[i0];
         if constexpr (ACC) in.acc = acc.bwd[i1];
     }
-    __device__ __forceinline__ void put_bwd(int tile, int q, int lane, const SlotIn<IO> &in, unsigned char *rt, int parity) const
+    __device__ __forceinline__ void put_bwd(const SlotCtx &c, int tile, const SlotIn<IO> &in, unsigned char *rt, int parity, bool path_is_dup) const
     {
-        int p, s;
-        slot_of(q, lane, p, s);
-        const int j = tile * TS + s, b = blk * P + p;
-        const PathConsts c = pc[p];
-        const bool valid = b < B && j <= c.N - 2;
-        const FastConsts<double> fc = consts_of(c);
+        const int j = tile * TS + c.s;
+        const bool valid = j <= c.N - 2;
         const double kc = fabs(in.k0), kn = (j + 2 <= c.N - 1) ? fabs(in.k1) : 0.0;
         double rho, q2, A, cap;
-        fast_derive_k(fc, kc, kn, ACC ? c.adecp_b : fc.adecp, rho, q2, A, cap);
-        const double g0 = fast_gq(fast_gg(fc, in.dth), q2);
-        double am_in = fc.amaxp;
+        fast_derive_k(c.fc, kc, kn, ACC ? c.adecp_b : c.fc.adecp, rho, q2, A, cap);
+        const double g0 = fast_gq(fast_gg(c.fc, in.dth), q2);
+        double am_in = c.fc.amaxp;
         if constexpr (ACC) {
             // the clamp comes from the sweep's max_dec, the wheel limit from the max_acc the sweep has at j+1
             // (MPG:256-257); a straight sample, or one with a zero heading difference, has max_dec alone
-            A = fast_cap_A(fc, kc, A);
+            A = fast_cap_A(c.fc, kc, A);
             am_in = (!(kc < 1e-6) && !(g0 < 0.0)) ? c.twodd * (double)in.acc : A;
         }
         cap = vmin(cap, in.uf);
         double am, g;
         fast_scale(am_in, g0, A, am, g);
-        if (!valid) { rho = 0.0; g = 0.0; am = 0.0; A = 0.0; cap = end_u; }
+        A = valid ? A : 0.0;          // (as in the forward sweep; the slots at or past the end sample hold end_u)
+        cap = valid ? cap : end_u;
+        g = valid ? g : 0.0;
         // A zero heading difference (g < 0) needs the sign-aware step (MPG:52-59): the chain takes it for the whole
         // tile (on every other sample it equals the plain step bit for bit).  k_velocity_seq decides per PATH, from the
         // forward sweep's coefficients; the two findings agree (the same dtheta, the same curvature on both sides of
         // it) — should they ever not, the sample keeps the plain step, as there.
         if (g < 0.0) {
-            if (path_dup[p]) tile_dup[parity] = 1;
+            if (path_is_dup) tile_dup[parity] = 1;
             else g = -g;
         }
-        unsigned char *r = rt + s * G::stride + p * kRecBytes;
+        unsigned char *r = rt + c.rec_off;
         *reinterpret_cast<double2 *>(r) = make_double2(rho, g);
         *reinterpret_cast<double2 *>(r + 16) = make_double2(am, A);
         *reinterpret_cast<double *>(r + 32) = cap;
     }
-    __device__ __forceinline__ void flush_bwd(int tile, int q, int lane, const double *ot) const
+    __device__ __forceinline__ void flush_bwd(const SlotCtx &c, int tile, const double *ot) const
     {
-        int p, s;
-        slot_of(q, lane, p, s);
-        const int j = tile * TS + s, b = blk * P + p;
-        if (b < B && j < S) V[(size_t)b * S + j] = j < pc[p].N ? (IO)vel_sqrt(ot[p * G::out_row + s]) : (IO)0;
+        const int j = tile * TS + c.s;
+        if (c.N > 0 && j < S) V[c.row + j] = j < c.N ? (IO)vel_sqrt(ot[c.out_off]) : (IO)0;
     }
 
     // One pipeline step of a producer wave.  `rows` holds the rows of tile `t_put`, loaded during the previous step:
@@ -222,12 +214,21 @@ struct Lanes {
     // next step's t_put) into the same registers — they fly while this step derives its records, moves the results of
     // tile `t_flush` out and waits at the barrier — then do that work.  Tiles outside [0, NT) are skipped (fill, drain).
     template <bool BWD>
-    __device__ __forceinline__ void producer_step(int pw, int lane, int NT, int t_load, int t_put, int t_flush, int parity,
-                                                  SlotIn<IO> (&rows)[kBatchesPerProducer]) const
+    __device__ __forceinline__ void producer_step(const SlotCtx (&ctx)[kBatchesPerProducer], bool four, int NT, int t_load, int t_put,
+                                                  int t_flush, int parity, SlotIn<IO> (&rows)[kBatchesPerProducer],
+                                                  bool (&saw_dup)[kBatchesPerProducer]) const
     {
-        SlotIn<IO> cur[kBatchesPerProducer];
+        if (four) producer_step_n<BWD, kBatchesPerProducer>(ctx, NT, t_load, t_put, t_flush, parity, rows, saw_dup);
+        else producer_step_n<BWD, kBatchesPerProducer - 1>(ctx, NT, t_load, t_put, t_flush, parity, rows, saw_dup);
+    }
+    template <bool BWD, int NB>
+    __device__ __forceinline__ void producer_step_n(const SlotCtx (&ctx)[kBatchesPerProducer], int NT, int t_load, int t_put, int t_flush,
+                                                    int parity, SlotIn<IO> (&rows)[kBatchesPerProducer],
+                                                    bool (&saw_dup)[kBatchesPerProducer]) const
+    {
+        SlotIn<IO> cur[NB];
 #pragma unroll
-        for (int i = 0; i < kBatchesPerProducer; i++) {
+        for (int i = 0; i < NB; i++) {
             cur[i].k0 = opaque(rows[i].k0);
             cur[i].k1 = opaque(rows[i].k1);
             cur[i].dth = opaque(rows[i].dth);
@@ -236,38 +237,27 @@ struct Lanes {
             if constexpr (VCAP && !BWD) cur[i].vc = opaque(rows[i].vc);
         }
         __builtin_amdgcn_sched_barrier(0);
-        {
-            // (unconditional: a tile index outside the row loads clamped, unused values)
+        // (unconditional: a tile index outside the row loads clamped, unused values)
 #pragma unroll
-            for (int i = 0; i < kBatchesPerProducer; i++) {
-                const int q = pw + i * kLanesProducers;
-                if (q < kTileBatches) {
-                    if constexpr (BWD) load_bwd(t_load, q, lane, rows[i]);
-                    else load_fwd(t_load, q, lane, rows[i]);
-                }
-            }
+        for (int i = 0; i < NB; i++) {
+            if constexpr (BWD) load_bwd(ctx[i], t_load, rows[i]);
+            else load_fwd(ctx[i], t_load, rows[i]);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (t_put >= 0 && t_put < NT) {
             unsigned char *rt = rec + (size_t)parity * G::rec_bytes;
 #pragma unroll
-            for (int i = 0; i < kBatchesPerProducer; i++) {
-                const int q = pw + i * kLanesProducers;
-                if (q < kTileBatches) {
-                    if constexpr (BWD) put_bwd(t_put, q, lane, cur[i], rt, parity);
-                    else put_fwd(t_put, q, lane, cur[i], rt);
-                }
+            for (int i = 0; i < NB; i++) {
+                if constexpr (BWD) put_bwd(ctx[i], t_put, cur[i], rt, parity, saw_dup[i]);
+                else put_fwd(ctx[i], t_put, cur[i], rt, saw_dup[i]);
             }
         }
         if (t_flush >= 0 && t_flush < NT) {
             const double *ot = out + (size_t)parity * (G::out_bytes / 8);   // the tile two steps back shares this step's parity
 #pragma unroll
-            for (int i = 0; i < kBatchesPerProducer; i++) {
-                const int q = pw + i * kLanesProducers;
-                if (q < kTileBatches) {
-                    if constexpr (BWD) flush_bwd(t_flush, q, lane, ot);
-                    else flush_fwd(t_flush, q, lane, ot);
-                }
+            for (int i = 0; i < NB; i++) {
+                if constexpr (BWD) flush_bwd(ctx[i], t_flush, ot);
+                else flush_fwd(ctx[i], t_flush, ot);
             }
         }
     }
@@ -322,20 +312,20 @@ __global__ __launch_bounds__(kLanesThreads, 2) void k_velocity_lanes(int B, int 
     const int NT = (s_nmax + TS - 1) / TS;
 
     Lanes<IO, P, VCAP, ACC> L;
-    L.B = B; L.S = S; L.blk = blockIdx.x;
+    L.S = S;
     L.K = curv; L.DT = dtheta; L.VC = vcap; L.acc = acc; L.V = vel;
     if constexpr (std::is_same<IO, double>::value) L.UF = reinterpret_cast<double *>(vel);   // fp64 rows: in place
     else L.UF = ufwd;
-    L.vmax = c.vmax; L.h = c.tw / 2.0; L.end_u = end_u;
-    L.pc = s_pc;
+    L.end_u = end_u;
     L.rec = smem_raw;
     L.out = reinterpret_cast<double *>(smem_raw + 2 * (size_t)G::rec_bytes);
-    L.path_dup = s_pdup;
     L.tile_dup = s_tdup;
 
     if (wv == 0) {
         // ---------------- the chain wave
-        __builtin_amdgcn_s_setprio(2);
+        // chain-bound groups (16 paths): the chain wave goes first on its SIMD; larger groups are producer-bound, and the
+        // producer wave that shares the SIMD needs the issue slots more than the chain does
+        if constexpr (P == 16) __builtin_amdgcn_s_setprio(2);
         const uint32_t rec0 = (uint32_t)(uintptr_t)(L.rec + lane * kRecBytes);
         const uint32_t out0 = (uint32_t)(uintptr_t)(L.out + lane * G::out_row);
         double u = start_u, up = 0.0;
@@ -381,7 +371,7 @@ __global__ __launch_bounds__(kLanesThreads, 2) void k_velocity_lanes(int B, int 
             lds_barrier();
         }
         if (stats && lane == 0) {
-            long long *st = stats + (size_t)blockIdx.x * 8;
+            long long *st = stats + (size_t)blockIdx.x * 16;
             st[0] = NT;
             st[1] = t_chain;                                   // cycles inside the forward chain loops
             st[2] = t_fwd_all;                                 // the forward sweep as the chain wave saw it
@@ -394,28 +384,63 @@ __global__ __launch_bounds__(kLanesThreads, 2) void k_velocity_lanes(int B, int 
 
     // ---------------- the producer waves
     const int pw = wv - 1;
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);    // (wave-uniform: the batch tests below are scalar branches)
+    SlotCtx ctx[kBatchesPerProducer];
+#pragma unroll
+    for (int i = 0; i < kBatchesPerProducer; i++) {
+        const int q = batch_of(wvu, i);                    // this wave's i-th batch of a tile
+        const int f = (q >= 0 ? q : 0) * 64 + lane;
+        SlotCtx &x = ctx[i];
+        x.p = f / TS;
+        x.s = f % TS;
+        const int b = blockIdx.x * P + x.p;
+        const PathConsts pc = s_pc[x.p];
+        x.live = q >= 0;
+        x.N = x.live ? pc.N : 0;
+        x.row = (size_t)(b < B ? b : B - 1) * S;
+        x.twodd = pc.twodd;
+        x.adecp_b = pc.adecp_b;
+        x.fc.vmax = c.vmax;
+        x.fc.amaxp = pc.amaxp;
+        x.fc.adecp = pc.adecp;
+        x.fc.h = c.tw / 2.0;
+        x.fc.gk = pc.gk;
+        x.fc.aangp = pc.aangp;
+        x.rec_off = x.s * G::stride + x.p * kRecBytes;
+        x.out_off = x.p * G::out_row + x.s;
+    }
+    const bool four = batch_of(wvu, kBatchesPerProducer - 1) >= 0;   // (this wave has the full count of batches)
+    bool saw_dup[kBatchesPerProducer] = {};
     long long t_busy = 0;
     auto sweep = [&](auto bwd_tag) {
         constexpr bool BWD = decltype(bwd_tag)::value;
         // pipeline tile #n -> row tile (clamped outside [0, NT): those loads are never used)
         auto rt = [NT](int n) { return BWD ? NT - 1 - n : n; };
         SlotIn<IO> rows[kBatchesPerProducer] = {};
-        L.template producer_step<BWD>(pw, lane, NT, rt(0), -1, -1, 0, rows);
+        L.template producer_step<BWD>(ctx, four, NT, rt(0), -1, -1, 0, rows, saw_dup);
         for (int it = 0; it <= NT + 1; it++) {
             const long long t0 = stats ? __builtin_amdgcn_s_memtime() : 0;
-            L.template producer_step<BWD>(pw, lane, NT, rt(it + 1), it < NT ? rt(it) : -1, (it >= 2 && it - 2 < NT) ? rt(it - 2) : -1,
-                                          it & 1, rows);
+            L.template producer_step<BWD>(ctx, four, NT, rt(it + 1), it < NT ? rt(it) : -1, (it >= 2 && it - 2 < NT) ? rt(it - 2) : -1,
+                                          it & 1, rows, saw_dup);
             if (stats) t_busy += __builtin_amdgcn_s_memtime() - t0;
             lds_barrier();
         }
     };
+    // forward: a lane notes whether any of its slots had a zero heading difference; the paths' flags are raised once, at
+    // the turn, and read back per slot for the backward sweep (k_velocity_seq's per-path decision)
     sweep(std::false_type());
-    if (stats && tid == 64) stats[(size_t)blockIdx.x * 8 + 5] = t_busy;   // producer 0 (three batches per tile), forward
+#pragma unroll
+    for (int i = 0; i < kBatchesPerProducer; i++)
+        if (ctx[i].live && saw_dup[i]) s_pdup[ctx[i].p] = 1;
+    if (stats && tid == 64) stats[(size_t)blockIdx.x * 16 + 5] = t_busy;   // producer 0 (three batches per tile), forward
     // the turn: every forward value this workgroup stored has reached memory before any wave of it reads one back
     __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0) expcnt(0) lgkmcnt(0)
     __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kBatchesPerProducer; i++) saw_dup[i] = s_pdup[ctx[i].p] != 0;
     sweep(std::true_type());
-    if (stats && tid == 64) stats[(size_t)blockIdx.x * 8 + 7] = t_busy;   // ... both sweeps
+    if (stats && tid == 64) stats[(size_t)blockIdx.x * 16 + 7] = t_busy;   // ... both sweeps
+    if (stats && lane == 0) stats[(size_t)blockIdx.x * 16 + 8 + pw] = t_busy;   // every producer, both sweeps
     // rows longer than the longest path of the group: zeros past the last tile
     for (int p = 0; p < P; p++) {
         const int b = blockIdx.x * P + p;
@@ -441,8 +466,8 @@ hipError_t launch_lanes_p(hipStream_t st, int B, int S, const double c[6], doubl
     static const bool want_stats = getenv("VAP_LANES_STATS") != nullptr;
     long long *stats = nullptr;
     if (want_stats) {
-        (void)hipMalloc(&stats, (size_t)grid.x * 8 * sizeof(long long));
-        (void)hipMemsetAsync(stats, 0, (size_t)grid.x * 8 * sizeof(long long), st);
+        (void)hipMalloc(&stats, (size_t)grid.x * 16 * sizeof(long long));
+        (void)hipMemsetAsync(stats, 0, (size_t)grid.x * 16 * sizeof(long long), st);
     }
 #define VAP_LANES_LAUNCH(VCAP_, ACC_)                                                                                       \
     do {                                                                                                                    \
@@ -457,15 +482,16 @@ hipError_t launch_lanes_p(hipStream_t st, int B, int S, const double c[6], doubl
     else VAP_LANES_LAUNCH(false, false);
 #undef VAP_LANES_LAUNCH
     if (stats) {
-        std::vector<long long> h((size_t)grid.x * 8);
+        std::vector<long long> h((size_t)grid.x * 16);
         (void)hipStreamSynchronize(st);
         (void)hipMemcpy(h.data(), stats, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
         (void)hipFree(stats);
-        double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        double sum[16] = {0};
         for (unsigned w = 0; w < grid.x; w++)
-            for (int k = 0; k < 8; k++) sum[k] += (double)h[(size_t)w * 8 + k] / grid.x;
+            for (int k = 0; k < 16; k++) sum[k] += (double)h[(size_t)w * 16 + k] / grid.x;
         fprintf(stderr, "[lanes P=%d, %u workgroups] tiles %.0f | mean ticks: forward chain loops %.0f of sweep %.0f | backward chain loops %.0f | both sweeps %.0f | producer 0 busy forward %.0f, both %.0f | per step: chain %.1f, sweep %.1f | backward tiles with a zero heading difference %.2f\n",
                 P, grid.x, sum[0], sum[1], sum[2], sum[3], sum[4], sum[5], sum[7], sum[1] / (sum[0] * G::TS), sum[2] / (sum[0] * G::TS), sum[6]);
+        fprintf(stderr, "        producers busy, both sweeps: %.0f %.0f %.0f %.0f %.0f %.0f %.0f\n", sum[8], sum[9], sum[10], sum[11], sum[12], sum[13], sum[14]);
     }
     return hipGetLastError();
 }
