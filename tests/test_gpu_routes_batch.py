@@ -166,7 +166,7 @@ def full_profile(torch, gen, route, cons, copies=2):
     return (out["rows"][0, :T].cpu().numpy(), [int(v) for v in out["nodes_map"][0, :nn]], [int(v) for v in out["actions_map"][0, :na]])
 
 
-@pytest.mark.parametrize("dtype,tol", [("f64", 1e-8), ("f32", 2e-5)])
+@pytest.mark.parametrize("dtype,tol", [("f64", 1e-8), ("f32", 1e-5)])
 @pytest.mark.parametrize("name", ["feat_reverse", "feat_turn", "feat_mixed", "feat_split2", "feat_wait", "feat_action", "feat_tangent"])
 def test_batched_route_full_motion_profile_matches_reference_golden(torch_mod, name, dtype, tol):
     """generate_motion_profile of the real reference — rows, nodes_map, actions_map — for routes with reverse nodes
@@ -183,12 +183,7 @@ def test_batched_route_full_motion_profile_matches_reference_golden(torch_mod, n
     for col, key in ((0, "times"), (1, "positions"), (2, "linear_vels"), (3, "accelerations"), (4, "headings"), (5, "angular_vels")):
         ref = g["profile_" + key]
         e = np.abs(rows[:, col] - ref) / np.maximum(np.abs(ref), 1.0)
-        if dtype == "f32" and key in ("headings", "angular_vels"):
-            # fp32 velocity rows move a row's position by ~1e-7 relative: now and then across a boundary of the
-            # reference's 1000-per-node property table, i.e. to the neighbouring entry (a step of ~1e-3 in heading)
-            assert np.mean(e > tol) <= 0.01 and e.max() <= 5e-3, (key, e.max(), np.mean(e > tol))
-        else:
-            assert e.max() <= tol, (key, e.max())
+        assert e.max() <= tol, (key, e.max())
     assert np.max(np.abs(rows[:, 6:8] - g["profile_coords"])) <= tol
 
 
@@ -323,3 +318,59 @@ def test_large_batch_of_split_routes_matches_oracle_on_a_sample(torch_mod, dtype
             got = r[k][b].cpu().numpy().astype(np.float64)
             err = np.max(np.abs(got - ref[k]) / np.maximum(np.abs(ref[k]), floor))
             assert err <= (tol if k == "velocity" or dtype == "f32" else 1e-9), (int(b), k, err)
+
+
+def test_widest_route_and_refusals(torch_mod):
+    """The route fit keeps 13 doubles and an int per node in LDS: routes of up to 1500 nodes run (held to the oracle on
+    a 1500-node route with a reverse and a turn node), wider ones are refused with VAP_ERR_UNSUPPORTED instead of a raw
+    launch failure; node_tangent without node_magnitudes and a non-finite node_turn are refused on the host."""
+    from oracle import oracle
+    from vexautonomousplanner_amd import _lib
+    from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
+    torch = torch_mod
+    gen = make_gen("f64")
+    W = 1500
+    wp = make_waypoints(1, W, 4242).astype(np.float64)
+    rev = np.zeros((1, W), dtype=bool)
+    turn = np.zeros((1, W))
+    rev[0, 700] = True
+    turn[0, 1200] = 35.0
+    r = gen.profile_routes(torch.tensor(wp, dtype=gen.tdtype, device=gen.device), node_reverse=rev, node_turn=turn,
+                           constraints=DEFAULT_CONSTRAINTS, samples=20000)
+    torch.cuda.synchronize()
+    assert int(r["flags"].abs().max().item()) == 0 and int(r["spline_counts"][0].item()) == 3
+    nodes = dict(is_reverse=rev[0].astype(float), turn=turn[0], stop=np.zeros(W), wait_time=np.zeros(W), max_velocity=np.zeros(W),
+                 max_acceleration=np.zeros(W), tangent=np.full((W, 2), np.nan), magnitudes=np.zeros((W, 2)))
+    op = oracle.OraclePath(wp[0], nodes=nodes)
+    op.rebuild_tables()
+    assert abs(float(r["meta"][0, 1].item()) - op.total_arc_length()) <= 1e-9 * op.total_arc_length()
+    wide = torch.tensor(make_waypoints(1, 1501, 7).astype(np.float64), dtype=gen.tdtype, device=gen.device)
+    with pytest.raises(_lib.VapError) as ei:
+        gen.profile_routes(wide, constraints=DEFAULT_CONSTRAINTS, samples=4000)
+    assert ei.value.status == _lib.VAP_ERR_UNSUPPORTED
+    small = torch.tensor(make_waypoints(2, 6, 8).astype(np.float64), dtype=gen.tdtype, device=gen.device)
+    with pytest.raises(ValueError):
+        gen.profile_routes(small, node_tangent=np.full((2, 6, 2), np.nan), samples=500)
+    bad_turn = np.zeros((2, 6))
+    bad_turn[1, 2] = np.nan
+    with pytest.raises(ValueError):
+        gen.profile_routes(small, node_turn=bad_turn, samples=500)
+
+
+def test_follow_up_calls_refuse_a_superseded_result(torch_mod):
+    """apply_node_limits / time_profile read rows the context kept from the profile call that made `result`: a result
+    that a later profile call of the same shape has superseded is refused instead of silently mixing two batches."""
+    from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
+    torch = torch_mod
+    gen = make_gen("f32")
+    a = torch.tensor(make_waypoints(3, 6, 1).astype(np.float32), device=gen.device)
+    b = torch.tensor(make_waypoints(3, 6, 2).astype(np.float32), device=gen.device)
+    ra = gen.profile(a, DEFAULT_CONSTRAINTS, samples=600)
+    rb = gen.profile(b, DEFAULT_CONSTRAINTS, samples=600)
+    with pytest.raises(ValueError):
+        gen.apply_node_limits(ra, DEFAULT_CONSTRAINTS, node_max_velocity=np.full((3, 6), 2.0))
+    with pytest.raises(ValueError):
+        gen.time_profile(ra, DEFAULT_CONSTRAINTS)
+    gen.apply_node_limits(rb, DEFAULT_CONSTRAINTS, node_max_velocity=np.full((3, 6), 2.0))
+    gen.time_profile(rb, DEFAULT_CONSTRAINTS)
+    torch.cuda.synchronize()

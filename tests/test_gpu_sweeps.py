@@ -78,8 +78,10 @@ def test_config3_sweep_rate_of_paths_outside_the_bound(torch_mod, config3_sweep,
     geo = 1e-9 if dtype == "f64" else 1e-5
     assert worst["curvature"] <= geo and worst["heading"] <= geo and worst["x"] <= geo and worst["y"] <= geo
     if dtype == "f32r32":
-        # the all-fp32 recurrence: recorded, and bounded so that it cannot get worse unnoticed
-        assert frac <= 0.03 and worst["velocity"] <= 5e-4
+        # the all-fp32 recurrence: recorded, and bounded so that it cannot get worse unnoticed — and from below, so
+        # that the sweep is known to still bite (a sweep on which even this mode passes everywhere would prove nothing
+        # about the default mode)
+        assert 0.005 <= frac <= 0.03 and worst["velocity"] <= 5e-4
     else:
         assert frac == 0.0, f"{int(frac * SWEEP_PATHS)} paths above {bound:g} (worst {worst['velocity']:.2e})"
         if dtype == "f32":
@@ -234,3 +236,24 @@ def test_full_size_batch_is_deterministic_and_order_independent(torch_mod, dtype
     for k in first:
         assert torch.equal(first[k][perm], shuffled[k]), k
     assert int(first["flags"].abs().max().item()) == 0
+
+
+def test_tolerance_sweep(torch_mod):
+    """BASELINE config 5, "fp64 vs fp32 tolerance sweep" (bench.py --tolerance-sweep), as a gate: 16 384 config-5-shaped
+    paths (8 waypoints x 1024 samples) in the two fp32-row modes against this library's fp64 run of the same batch.
+    Default mode: no path above 1e-5.  All-fp32 recurrence: some are — the sweep keeps biting."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
+    torch = torch_mod
+    B, W, S = 16384, 8, 1024
+    wp = torch.tensor(make_waypoints(B, W, 5, dtype=np.float32), dtype=torch.float32, device="cuda:0")
+    sweep = bench.tolerance_sweep(0, wp, list(DEFAULT_CONSTRAINTS), S)
+    default = sweep["modes"]["f32 rows, f64 recurrence (default)"]
+    f32rec = sweep["modes"]["f32 rows, f32 recurrence"]
+    print(sweep)
+    assert default["paths"] == B and f32rec["paths"] == B
+    assert default["paths_above_1e-5"] == 0 and default["worst"] <= 2e-6
+    assert f32rec["paths_above_1e-5"] > 0 and f32rec["worst"] > 1e-5

@@ -22,6 +22,12 @@ def _torch_dtype(dtype):
     raise ValueError(f"unsupported dtype {dtype!r}")
 
 
+class ProfileResult(dict):
+    """What profile() / profile_routes() return: a dict of tensors, stamped with the generation of the context rows it
+    belongs to (apply_node_limits / time_profile read rows the context kept from that very call)."""
+    generation = None
+
+
 class BatchedTrajectoryGenerator:
     """rebuild_tables + forward_backward_pass (SM:582-594, MPG:70-316) for B independent
     plain-node paths per call, outputs resident in HBM as (B, S) tensors."""
@@ -83,7 +89,7 @@ class BatchedTrajectoryGenerator:
             ddv = float(dd)
             S = int(capacity) if capacity is not None else int(np.ceil(64.0 / ddv)) + 2
         c = _lib.make_constraints(constraints)
-        res = {} if out is None else out
+        res = ProfileResult() if out is None else (out if isinstance(out, ProfileResult) else ProfileResult(out))
         for f in FIELDS:
             if f in want or f == "velocity":
                 t = res.get(f)
@@ -107,7 +113,20 @@ class BatchedTrajectoryGenerator:
                                        C.c_void_p(res["flags"].data_ptr()))
         _lib.check(st, "vap_profile_batch")
         self._last_shape = (B, W, S)
+        self._stamp(res)
         return res
+
+    def _stamp(self, res):
+        """The context keeps rows of the batch it sampled last (tables, fp64 curvature / heading-difference rows, the
+        fp64 velocities): a result dict is tied to them by a generation number, and the follow-up calls refuse a result
+        that another profile()/profile_routes() call of this generator has superseded."""
+        self._generation = getattr(self, "_generation", 0) + 1
+        res.generation = self._generation
+
+    def _check_current(self, result, what):
+        if getattr(result, "generation", None) != getattr(self, "_generation", None):
+            raise ValueError(f"{what} needs the result of this generator's LAST profile()/profile_routes() call: the context "
+                             "rows it reads belong to a later batch")
 
     def profile_routes(self, waypoints, node_reverse=None, node_turn=None, node_tangent=None, node_magnitudes=None,
                        constraints=DEFAULT_CONSTRAINTS, samples=None, dd=None, start_vel=START_VEL, end_vel=END_VEL,
@@ -125,8 +144,12 @@ class BatchedTrajectoryGenerator:
             raise ValueError(f"waypoints must be a (B,W,2) {self.tdtype} tensor on {self.device}")
         wp = wp.contiguous()
         B, W, _ = wp.shape
+        if node_tangent is not None and node_magnitudes is None:
+            raise ValueError("node_tangent needs node_magnitudes ((B, W, 2): incoming, outgoing) for the nodes that have a tangent")
         rev = np.zeros((B, W), dtype=np.int32) if node_reverse is None else np.asarray(node_reverse).astype(bool).astype(np.int32).reshape(B, W)
         turn = np.zeros((B, W)) if node_turn is None else np.asarray(node_turn, dtype=np.float64).reshape(B, W)
+        if not np.all(np.isfinite(turn)):
+            raise ValueError("node_turn must be finite (degrees; 0 = no turn)")
         split = ((rev != 0) | (turn != 0))[:, 1:W - 1] if W > 2 else np.zeros((B, 0), dtype=bool)
         max_splines = int(1 + (split.sum(axis=1).max() if split.size else 0))
         dev = self.device
@@ -142,7 +165,7 @@ class BatchedTrajectoryGenerator:
             ddv = float(dd)
             S = int(capacity) if capacity is not None else int(np.ceil(64.0 / ddv)) + 2
         c = _lib.make_constraints(constraints)
-        res = {} if out is None else out
+        res = ProfileResult() if out is None else (out if isinstance(out, ProfileResult) else ProfileResult(out))
         for f in FIELDS:
             if f in want or f == "velocity":
                 t = res.get(f)
@@ -163,6 +186,7 @@ class BatchedTrajectoryGenerator:
                                         ptr(res["spline_counts"]))
         _lib.check(st, "vap_profile_routes")
         self._last_shape = (B, W, S)
+        self._stamp(res)
         return res
 
     def time_profile(self, result, constraints=DEFAULT_CONSTRAINTS, dt=0.01, capacity_rows=None, out=None, node_reverse=None):
@@ -184,6 +208,7 @@ class BatchedTrajectoryGenerator:
         last = getattr(self, "_last_shape", None)
         if last is None or (last[0], last[2]) != (B, S):
             raise ValueError("time_profile needs the result of this generator's last profile() call")
+        self._check_current(result, "time_profile")
         W = last[1]
         if capacity_rows is None:
             capacity_rows = 4096
@@ -227,6 +252,7 @@ class BatchedTrajectoryGenerator:
         last = getattr(self, "_last_shape", None)
         if last is None or (last[0], last[2]) != (B, S):
             raise ValueError("apply_node_limits needs the result of this generator's last profile() call")
+        self._check_current(result, "apply_node_limits")
         W = last[1]
         as2d = lambda a: np.zeros((B, W)) if a is None else np.asarray(a, dtype=np.float64).reshape(B, W)
         mv, ma = as2d(node_max_velocity), as2d(node_max_acceleration)

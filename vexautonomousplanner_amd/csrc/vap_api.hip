@@ -66,6 +66,14 @@ int run_velocity(vap_ctx *ctx, bool f64, bool io64, int B, int S, const double c
                  const void *curv, const void *dth, const void *vcap, const vap::AccRowsV &acc, void *vel, uint32_t *flags)
 {
     int mode = ctx->velocity_kernel;
+    ctx->vhi_for = nullptr;
+    const bool want_hi = f64 && !io64;   // fp32 rows behind the fp64 recurrence: the velocities stay on the context in fp64
+    auto keep_hi = [&](const void *rows) {
+        ctx->vhi_ptr = rows;
+        ctx->vhi_for = vel;
+        ctx->vhi_B = B;
+        ctx->vhi_S = S;
+    };
     // per-sample initial velocities: the register-resident relaxation kernel takes them, the two-level one for
     // long rows and the wave-per-path variant do not (the sequential sweep does)
     const int relax_limit = acc.fwd ? vap::velocity_relax_acc_max_samples(f64) : vap::velocity_relax_max_samples(f64, vcap != nullptr);
@@ -81,6 +89,7 @@ int run_velocity(vap_ctx *ctx, bool f64, bool io64, int B, int S, const double c
         }
         const int group = mode == VAP_VELOCITY_LANES ? 0 : (mode == VAP_VELOCITY_LANES_16 ? 16 : (mode == VAP_VELOCITY_LANES_32 ? 32 : 64));
         HIP_TRY(vap::launch_velocity_lanes(ctx->stream, io64, B, S, cc, sv, ev, meta, curv, dth, vcap, acc, vel, ufwd, group));
+        if (want_hi) keep_hi(ufwd);
         return VAP_OK;
     }
     if (mode == VAP_VELOCITY_AUTO)
@@ -105,14 +114,27 @@ int run_velocity(vap_ctx *ctx, bool f64, bool io64, int B, int S, const double c
             HIP_TRY(vap::launch_velocity_windows(ctx->stream, B, S, cc, sv, ev, meta, curv, dth, vel, flags, ctx->ufwd.ptr,
                                                  ctx->lstate.ptr, (int *)ctx->lcount.ptr));
         } else if (S <= vap::velocity_relax_max_samples(f64, vcap != nullptr)) {
-            HIP_TRY(vap::launch_velocity_relax(ctx->stream, f64, io64, B, S, cc, sv, ev, meta, curv, dth, vcap, acc, vel, flags));
+            void *vhi = nullptr;
+            if (want_hi) {
+                VAP_TRY(ctx->ensure(ctx->ufwd, (size_t)B * S * 8));
+                vhi = ctx->ufwd.ptr;
+            }
+            HIP_TRY(vap::launch_velocity_relax(ctx->stream, f64, io64, B, S, cc, sv, ev, meta, curv, dth, vcap, acc, vel, flags, vhi));
+            if (want_hi) keep_hi(vhi);
         } else {
-            // long rows: two-level relaxation (host-synchronised super-rounds)
+            // long rows: two-level relaxation (host-synchronised super-rounds); its scratch row holds the forward
+            // values until the last super-round, so the fp64 velocities get a row of their own
             VAP_TRY(ctx->ensure(ctx->ufwd, (size_t)B * S * (f64 ? 8 : 4)));
             VAP_TRY(ctx->ensure(ctx->lstate, vap::velocity_long_state_bytes(f64, B, S)));
             VAP_TRY(ctx->ensure(ctx->lcount, vap::velocity_long_counter_bytes(f64, B, S)));
+            void *vhi = nullptr;
+            if (want_hi) {
+                VAP_TRY(ctx->ensure(ctx->vhi, (size_t)B * S * 8));
+                vhi = ctx->vhi.ptr;
+            }
             HIP_TRY(vap::launch_velocity_long(ctx->stream, f64, io64, B, S, cc, sv, ev, meta, curv, dth, vel, flags,
-                                              ctx->ufwd.ptr, ctx->lstate.ptr, (int *)ctx->lcount.ptr));
+                                              ctx->ufwd.ptr, ctx->lstate.ptr, (int *)ctx->lcount.ptr, vhi));
+            if (want_hi) keep_hi(vhi);
         }
     } else {
         void *usq = nullptr;
@@ -122,8 +144,23 @@ int run_velocity(vap_ctx *ctx, bool f64, bool io64, int B, int S, const double c
         }
         HIP_TRY(vap::launch_velocity_seq(ctx->stream, f64, io64, mode == VAP_VELOCITY_SEQ_FAST, B, S, cc, sv, ev, meta, curv,
                                          dth, vcap, acc, vel, usq));
+        if (want_hi) keep_hi(usq);
     }
     return VAP_OK;
+}
+
+// The velocity row a time-domain entry point integrates: the caller's, or — fp32 rows whose velocity pass ran the
+// fp64 recurrence in this context — the fp64 velocities that pass left behind (MPG:566-584 integrates positions
+// from the row; an fp32 row moves a position by ~1e-7 relative, now and then across a boundary of the reference's
+// step lookup, SM:550-580).
+const void *time_domain_velocity(vap_ctx *ctx, vap_dtype dt, int B, int S, const void *d_velocity, bool &is64)
+{
+    is64 = dt == VAP_F64;
+    if (dt == VAP_F32 && ctx->vhi_for == d_velocity && ctx->vhi_ptr && ctx->vhi_B == B && ctx->vhi_S == S) {
+        is64 = true;
+        return ctx->vhi_ptr;
+    }
+    return d_velocity;
 }
 
 }  // namespace
@@ -186,7 +223,7 @@ int vap_ctx_destroy(vap_ctx *ctx)
     if (!ctx) return VAP_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    VapBuffer *bufs[] = {&ctx->sptab, &ctx->nspl, &ctx->k64, &ctx->dth64, &ctx->ufwd, &ctx->lstate, &ctx->lcount, &ctx->seg, &ctx->power, &ctx->lut, &ctx->slopes, &ctx->aux, &ctx->runs, &ctx->meta, &ctx->dth, &ctx->flags, &ctx->small_in,
+    VapBuffer *bufs[] = {&ctx->sptab, &ctx->nspl, &ctx->k64, &ctx->dth64, &ctx->ufwd, &ctx->vhi, &ctx->lstate, &ctx->lcount, &ctx->seg, &ctx->power, &ctx->lut, &ctx->slopes, &ctx->aux, &ctx->runs, &ctx->meta, &ctx->dth, &ctx->flags, &ctx->small_in,
                       &ctx->small_out, &ctx->small_seg, &ctx->small_lut};
     for (VapBuffer *b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
@@ -458,6 +495,9 @@ int vap_profile_routes(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double d
     VAP_TRY(check_shape(B, W, S));
     if (!d_waypoints || !c || !d_velocity) return vap_fail(VAP_ERR_INVALID, "null buffer");
     if (max_splines < 1 || max_splines > W - 1) return vap_fail(VAP_ERR_INVALID, "max_splines must be in [1, W-1] (got %d)", max_splines);
+    if (W > vap::kMaxRouteWaypoints)   // the route fit keeps 13 doubles and an int per node in LDS (160 KB per CU)
+        return vap_fail(VAP_ERR_UNSUPPORTED, "batched routes: W=%d exceeds %d nodes (plain paths go to %d through vap_profile_batch)", W,
+                        vap::kMaxRouteWaypoints, vap::kMaxWaypoints);
     if (d_node_tangent && !d_node_magnitudes) return vap_fail(VAP_ERR_INVALID, "node tangents come with their magnitudes");
     const bool f64 = dt == VAP_F64;
     const int NS = max_splines;
@@ -624,7 +664,9 @@ int vap_time_profile(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, const doub
         d_segments = (const double *)ctx->seg.ptr;
         d_lut = (const double *)ctx->lut.ptr;
     }
-    HIP_TRY(vap::launch_time_profile(ctx->stream, dt == VAP_F64, B, W, S, d_segments, d_lut, d_meta, d_velocity, c->max_acc,
+    bool v64;
+    const void *vrow = time_domain_velocity(ctx, dt, B, S, d_velocity, v64);
+    HIP_TRY(vap::launch_time_profile(ctx->stream, v64, B, W, S, d_segments, d_lut, d_meta, vrow, c->max_acc,
                                      c->max_dec, time_step, capacity_rows, d_rows, d_counts, d_nodes_map, d_flags));
     return VAP_OK;
 }
@@ -676,8 +718,10 @@ int vap_time_profile_routes(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, con
         rt.nspl = (const int *)ctx->nspl.ptr;
         rt.NS = ctx->route_NS;
     }
-    HIP_TRY(vap::launch_time_profile(ctx->stream, dt == VAP_F64, B, W, S, (const double *)ctx->seg.ptr, (const double *)ctx->lut.ptr,
-                                     d_meta, d_velocity, c->max_acc, c->max_dec, time_step, capacity_rows, d_rows, d_counts,
+    bool v64;
+    const void *vrow = time_domain_velocity(ctx, dt, B, S, d_velocity, v64);
+    HIP_TRY(vap::launch_time_profile(ctx->stream, v64, B, W, S, (const double *)ctx->seg.ptr, (const double *)ctx->lut.ptr,
+                                     d_meta, vrow, c->max_acc, c->max_dec, time_step, capacity_rows, d_rows, d_counts,
                                      d_nodes_map, d_flags, rt, d_node_reverse));
     return VAP_OK;
 }

@@ -17,6 +17,7 @@ constexpr int kCoefBlockDoubles = 36;                      // doubles per segmen
 constexpr int kGridRunBlockDoubles = 3 * 100;            // distance-grid runs per path: 100 entries of {k0, s0, D} (vap_device.h)
 constexpr int kLdsCoefSegments = 112;                     // segments whose coefficient blocks are staged in LDS
 constexpr int kMaxWaypoints = 2048;              // k_fit LDS: 7*W doubles
+constexpr int kMaxRouteWaypoints = 1500;         // k_fit_routes LDS: 13*W doubles + W ints (108 B per node of 160 KB)
 
 // Routes cut into several splines by reverse / turn nodes (vap_routes_batch.hip): the per-route spline table
 //   sptab [B][NS][4] = {parameters[-1], distance offset, parameter offset, first node}, nspl [B] = splines per route
@@ -65,7 +66,9 @@ struct AccRowsV {
     const void *dec = nullptr;   // [B]    dtype: max_dec of the backward sweep
 };
 // Velocity kernels: r64 = arithmetic (and the curvature / dtheta rows) in fp64; io64 = the caller's rows (vcap,
-// acc, vel) are fp64.  r64 && !io64 is the fp64 recurrence behind fp32 outputs.
+// acc, vel) are fp64.  r64 && !io64 is the fp64 recurrence behind fp32 outputs; every kernel then also leaves the
+// velocities in fp64 ([B][S], what the time-domain resample integrates): launch_velocity_seq in `usq`,
+// launch_velocity_lanes in `ufwd` (both rows are scratch the sweeps are done with), the others in `vhi`.
 hipError_t launch_velocity_seq(hipStream_t st, bool r64, bool io64, bool fast, int B, int S, const double c[6], double sv,
                                double ev, const double *meta, const void *curv, const void *dth, const void *vcap,
                                const AccRowsV &acc, void *vel, void *usq);
@@ -74,13 +77,13 @@ int velocity_relax_acc_max_samples(bool f64);
 // vcap: optional [B][S] per-sample initial velocities (NULL = plain paths)
 hipError_t launch_velocity_relax(hipStream_t st, bool r64, bool io64, int B, int S, const double c[6], double sv, double ev,
                                  const double *meta, const void *curv, const void *dth, const void *vcap,
-                                 const AccRowsV &acc, void *vel, uint32_t *flags);
+                                 const AccRowsV &acc, void *vel, uint32_t *flags, void *vhi = nullptr);
 // rows longer than velocity_relax_max_samples(): two-level relaxation, synchronises the stream once per super-round
 size_t velocity_long_state_bytes(bool f64, int B, int S);
 size_t velocity_long_counter_bytes(bool f64, int B, int S);
 hipError_t launch_velocity_long(hipStream_t st, bool f64, bool io64, int B, int S, const double c[6], double sv, double ev,
                                 const double *meta, const void *curv, const void *dth, void *vel, uint32_t *flags,
-                                void *ufwd, void *state, int *counters);
+                                void *ufwd, void *state, int *counters, void *vhi = nullptr);
 // K5w (vap_velocity_lanes.hip), fp64 recurrence only: lane per path, `group` paths per workgroup (0 = by batch size).
 // ufwd: [B][S] doubles of scratch for the forward sweep's squared velocities (unused when io64: the rows are used in place)
 int velocity_lanes_group(int B);

@@ -816,11 +816,22 @@ __global__ __launch_bounds__(64) void k_velocity_seq(int B, int S, VelConsts<R> 
             const SampleLimits<R> L = sample_limits(c, (R)fabs(K[i]), cur_acc, cur_dec);
             up = backward_step(c, L, cur_acc, twodd, u, wprev, DT[i - 1], V[i - 1]);
         }
-        vel[row + i] = (IO)vel_sqrt(u);
+        // (R != IO: V[i] — the scratch row, the forward value of sample i — is dead from here on and receives the
+        // velocity in the arithmetic type: the fp64 row the time-domain resample integrates behind fp32 rows)
+        const R vv = vel_sqrt(u);
+        vel[row + i] = (IO)vv;
+        if constexpr (!std::is_same<R, IO>::value) V[i] = vv;
         u = up;
     }
-    vel[row] = (IO)vel_sqrt(u);
-    for (int i = N; i < S; i++) vel[row + i] = (IO)0;
+    {
+        const R vv = vel_sqrt(u);
+        vel[row] = (IO)vv;
+        if constexpr (!std::is_same<R, IO>::value) V[0] = vv;
+    }
+    for (int i = N; i < S; i++) {
+        vel[row + i] = (IO)0;
+        if constexpr (!std::is_same<R, IO>::value) V[i] = (R)0;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -986,7 +997,7 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
                                                                const R *__restrict__ dtheta,
                                                                const IO *__restrict__ vcap, AccRows<IO> acc,
                                                                IO *__restrict__ vel, uint32_t *__restrict__ flags,
-                                                               long long *__restrict__ stats)
+                                                               long long *__restrict__ stats, R *__restrict__ vhi)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     R *stage = reinterpret_cast<R *>(smem_raw);   // (T*L + T + 2) elements
@@ -1386,6 +1397,18 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
         }
     }
     for (int j = TL + tid; j < S; j += T) V[j] = (IO)0;
+    if constexpr (!std::is_same<R, IO>::value) {
+        // the velocities in the arithmetic type as well (vhi: [B][S], what the time-domain resample integrates behind
+        // fp32 rows); straight from the registers — this kernel serves the small batches
+        if (vhi) {
+#pragma unroll
+            for (int s = 0; s < L; s++) {
+                const int j = lo + s;
+                if (j < S) vhi[row + j] = j < N ? vel_sqrt(CM ? cp[s] : u[CM ? 0 : s]) : (R)0;
+            }
+            for (int j = TL + tid; j < S; j += T) vhi[row + j] = (R)0;
+        }
+    }
     if (stats && tid == 0) {
         long long *st = stats + (size_t)b * 8;
         st[0] = fwd_rounds;
@@ -1433,7 +1456,8 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_long(int S, int nsc, in
                                                               IO *__restrict__ vel, R *__restrict__ bnd,
                                                               R *__restrict__ used, R *__restrict__ outst,
                                                               const int *__restrict__ dupflag,
-                                                              int *__restrict__ changed, uint32_t *__restrict__ flags)
+                                                              int *__restrict__ changed, uint32_t *__restrict__ flags,
+                                                              R *__restrict__ vhi)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     R *stage = reinterpret_cast<R *>(smem_raw);
@@ -1662,6 +1686,17 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_long(int S, int nsc, in
         for (int i = tid; i < n; i += T) dst[i] = ostage[stage_pos<IO, L>(i)];
         if (sc == last_sc)
             for (int j = (last_sc + 1) * SC + tid; j < S; j += T) vel[row + j] = (IO)0;
+        if constexpr (!std::is_same<R, IO>::value) {
+            if (vhi) {   // the velocities in the arithmetic type as well (the time-domain resample behind fp32 rows)
+#pragma unroll
+                for (int s = 0; s < L; s++) {
+                    const int j = base + lo + s;
+                    if (j < S) vhi[row + j] = j < N ? vel_sqrt(u[s]) : (R)0;
+                }
+                if (sc == last_sc)
+                    for (int j = (last_sc + 1) * SC + tid; j < S; j += T) vhi[row + j] = (R)0;
+            }
+        }
     } else {
 #pragma unroll
         for (int s = 0; s < L; s++) stage[stage_pos<R, L>(lo + s)] = u[s];
@@ -1890,7 +1925,7 @@ int velocity_relax_acc_max_samples(bool f64) { return f64 ? 512 * 8 : 512 * 20; 
 template <typename R, typename IO, int L, int MAXT, int MINW, bool ACC = false>
 static void launch_relax_t(hipStream_t st, int B, int S, const double c[6], double sv, double ev,
                            const double *meta, const void *curv, const void *dth, const void *vcap, const AccRowsV &accv,
-                           void *vel, uint32_t *flags)
+                           void *vel, uint32_t *flags, void *vhi)
 {
     AccRows<IO> acc;
     acc.fwd = (const IO *)accv.fwd;
@@ -1906,13 +1941,13 @@ static void launch_relax_t(hipStream_t st, int B, int S, const double c[6], doub
     const size_t lds = sizeof(R) * ((size_t)T * L + T + 8);
     if constexpr (ACC)
         hipLaunchKernelGGL((k_velocity_relax<R, IO, L, MAXT, MINW, true, true>), dim3(B), dim3(T), lds, st, S, make_consts<R>(c), s * s,
-                           e * e, meta, (const R *)curv, (const R *)dth, (const IO *)vcap, acc, (IO *)vel, flags, stats);
+                           e * e, meta, (const R *)curv, (const R *)dth, (const IO *)vcap, acc, (IO *)vel, flags, stats, (R *)vhi);
     else if (vcap)
         hipLaunchKernelGGL((k_velocity_relax<R, IO, L, MAXT, MINW, true, false>), dim3(B), dim3(T), lds, st, S, make_consts<R>(c), s * s,
-                           e * e, meta, (const R *)curv, (const R *)dth, (const IO *)vcap, acc, (IO *)vel, flags, stats);
+                           e * e, meta, (const R *)curv, (const R *)dth, (const IO *)vcap, acc, (IO *)vel, flags, stats, (R *)vhi);
     else
         hipLaunchKernelGGL((k_velocity_relax<R, IO, L, MAXT, MINW, false, false>), dim3(B), dim3(T), lds, st, S, make_consts<R>(c), s * s,
-                           e * e, meta, (const R *)curv, (const R *)dth, (const IO *)nullptr, acc, (IO *)vel, flags, stats);
+                           e * e, meta, (const R *)curv, (const R *)dth, (const IO *)nullptr, acc, (IO *)vel, flags, stats, (R *)vhi);
     if (stats) {
         std::vector<long long> h((size_t)B * 8);
         (void)hipStreamSynchronize(st);
@@ -1932,12 +1967,12 @@ static void launch_relax_t(hipStream_t st, int B, int S, const double c[6], doub
 
 hipError_t launch_velocity_relax(hipStream_t st, bool r64, bool io64, int B, int S, const double c[6], double sv, double ev,
                                  const double *meta, const void *curv, const void *dth, const void *vcap,
-                                 const AccRowsV &acc, void *vel, uint32_t *flags)
+                                 const AccRowsV &acc, void *vel, uint32_t *flags, void *vhi)
 {
     if (acc.fwd) {
         // per-sample max_acceleration: one more register array per thread, so shorter chunks
         // (velocity_relax_acc_max_samples() is the limit the caller checks)
-#define VAP_RELAX_ACC(R_, IO_, L_, MAXT_, W_) launch_relax_t<R_, IO_, L_, MAXT_, W_, true>(st, B, S, c, sv, ev, meta, curv, dth, vcap, acc, vel, flags)
+#define VAP_RELAX_ACC(R_, IO_, L_, MAXT_, W_) launch_relax_t<R_, IO_, L_, MAXT_, W_, true>(st, B, S, c, sv, ev, meta, curv, dth, vcap, acc, vel, flags, vhi)
         if (r64 && io64) {
             if (S <= 64 * 4) VAP_RELAX_ACC(double, double, 4, 256, 4);
             else VAP_RELAX_ACC(double, double, 8, 512, 4);
@@ -1952,7 +1987,7 @@ hipError_t launch_velocity_relax(hipStream_t st, bool r64, bool io64, int B, int
 #undef VAP_RELAX_ACC
         return hipGetLastError();
     }
-#define VAP_RELAX(R_, IO_, L_, MAXT_, W_) launch_relax_t<R_, IO_, L_, MAXT_, W_>(st, B, S, c, sv, ev, meta, curv, dth, vcap, acc, vel, flags)
+#define VAP_RELAX(R_, IO_, L_, MAXT_, W_) launch_relax_t<R_, IO_, L_, MAXT_, W_>(st, B, S, c, sv, ev, meta, curv, dth, vcap, acc, vel, flags, vhi)
     // chunk length: the longest instantiated L whose thread count still covers the row — fewer, longer
     // chunks mean fewer rounds (rounds ~ longest unclamped run / L) and fewer waves to synchronise
     const bool one_wave = S > 64 * 4 && S <= 64 * 16;
@@ -1980,7 +2015,7 @@ hipError_t launch_velocity_relax(hipStream_t st, bool r64, bool io64, int B, int
 template <typename R, typename IO, int L, int MAXT, int MINW>
 static hipError_t velocity_long_t(hipStream_t st, int B, int S, const double c[6], double sv, double ev,
                                   const double *meta, const void *curv, const void *dth, void *vel, uint32_t *flags,
-                                  void *ufwd, void *state, int *counters)
+                                  void *ufwd, void *state, int *counters, void *vhi)
 {
     constexpr int SC = MAXT * L;
     const int nsc = (S + SC - 1) / SC;
@@ -2016,11 +2051,11 @@ static hipError_t velocity_long_t(hipStream_t st, int B, int S, const double c[6
                 if (dir == 0)
                     hipLaunchKernelGGL((k_velocity_long<R, IO, L, MAXT, MINW, false>), dim3(nsc, B), dim3(MAXT), lds, st, S, nsc,
                                        round, -1, make_consts<R>(c), s * s, e * e, meta, (const R *)curv, (const R *)dth,
-                                       (R *)ufwd, (IO *)vel, bnd, used, outst, dup, ch, flags);
+                                       (R *)ufwd, (IO *)vel, bnd, used, outst, dup, ch, flags, (R *)vhi);
                 else
                     hipLaunchKernelGGL((k_velocity_long<R, IO, L, MAXT, MINW, true>), dim3(nsc, B), dim3(MAXT), lds, st, S, nsc,
                                        round, -1, make_consts<R>(c), s * s, e * e, meta, (const R *)curv, (const R *)dth,
-                                       (R *)ufwd, (IO *)vel, bnd, used, outst, dup, ch, flags);
+                                       (R *)ufwd, (IO *)vel, bnd, used, outst, dup, ch, flags, (R *)vhi);
                 if ((err = hipGetLastError()) != hipSuccess) return err;
             }
             int h = 0;
@@ -2049,14 +2084,14 @@ size_t velocity_long_counter_bytes(bool f64, int B, int S)
 
 hipError_t launch_velocity_long(hipStream_t st, bool f64, bool io64, int B, int S, const double c[6], double sv, double ev,
                                 const double *meta, const void *curv, const void *dth, void *vel, uint32_t *flags,
-                                void *ufwd, void *state, int *counters)
+                                void *ufwd, void *state, int *counters, void *vhi)
 {
     // super-chunk = 512, 128 or 64 threads x 16 samples (fp64): few long rows (config 2: one) are cut finer so that the
     // chip has more workgroups to run and a super-round is shorter
     if (f64) {
         const long blocks512 = (long)B * ((S + 512 * 16 - 1) / (512 * 16));
         const int t64 = blocks512 < 256 ? 64 : (blocks512 < 1024 ? 128 : 512);
-#define VAP_LONG64(IO_, T_) velocity_long_t<double, IO_, 16, T_, 2>(st, B, S, c, sv, ev, meta, curv, dth, vel, flags, ufwd, state, counters)
+#define VAP_LONG64(IO_, T_) velocity_long_t<double, IO_, 16, T_, 2>(st, B, S, c, sv, ev, meta, curv, dth, vel, flags, ufwd, state, counters, vhi)
         if (io64) return t64 == 64 ? VAP_LONG64(double, 64) : (t64 == 128 ? VAP_LONG64(double, 128) : VAP_LONG64(double, 512));
         return t64 == 64 ? VAP_LONG64(float, 64) : (t64 == 128 ? VAP_LONG64(float, 128) : VAP_LONG64(float, 512));
 #undef VAP_LONG64
@@ -2065,8 +2100,8 @@ hipError_t launch_velocity_long(hipStream_t st, bool f64, bool io64, int B, int 
     // chip has more workgroups to run and a super-round is shorter
     const long blocks256 = (long)B * ((S + 256 * 40 - 1) / (256 * 40));
     if (blocks256 < 512)
-        return velocity_long_t<float, float, 40, 64, 2>(st, B, S, c, sv, ev, meta, curv, dth, vel, flags, ufwd, state, counters);
-    return velocity_long_t<float, float, 40, 256, 2>(st, B, S, c, sv, ev, meta, curv, dth, vel, flags, ufwd, state, counters);
+        return velocity_long_t<float, float, 40, 64, 2>(st, B, S, c, sv, ev, meta, curv, dth, vel, flags, ufwd, state, counters, nullptr);
+    return velocity_long_t<float, float, 40, 256, 2>(st, B, S, c, sv, ev, meta, curv, dth, vel, flags, ufwd, state, counters, nullptr);
 }
 
 // K5b': many paths, fp32: one wave per path walks the row in windows of 64*L samples, one launch per
@@ -2099,11 +2134,11 @@ hipError_t launch_velocity_windows(hipStream_t st, int B, int S, const double c[
     for (int sc = 0; sc < nsc; sc++)
         hipLaunchKernelGGL((k_velocity_long<R, R, L, T, 2, false>), dim3(1, B), dim3(T), lds, st, S, nsc, 0, sc,
                            make_consts<R>(c), s * s, e * e, meta, (const R *)curv, (const R *)dth, (R *)ufwd, (R *)vel, bnd,
-                           used, outst, dup, changed, flags);
+                           used, outst, dup, changed, flags, (R *)nullptr);
     for (int sc = nsc - 1; sc >= 0; sc--)
         hipLaunchKernelGGL((k_velocity_long<R, R, L, T, 2, true>), dim3(1, B), dim3(T), lds, st, S, nsc, 0, sc,
                            make_consts<R>(c), s * s, e * e, meta, (const R *)curv, (const R *)dth, (R *)ufwd, (R *)vel, bnd,
-                           used, outst, dup, changed, flags);
+                           used, outst, dup, changed, flags, (R *)nullptr);
     return hipGetLastError();
 }
 

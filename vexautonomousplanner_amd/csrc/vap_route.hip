@@ -759,24 +759,38 @@ int vap_route_set_table_sizes(vap_route *rt, int lut_samples, int samples_per_no
         return vap_fail(VAP_ERR_INVALID, "table sizes out of range");
     VAP_TRY(vap_set_device(rt->ctx));
     hipStream_t st = rt->ctx->stream;
-    rt->d.spn = samples_per_node;
-    rt->N = 0;   // a cached distance-domain result belongs to the old tables
-    if (lut_samples == rt->d.lut_n) return VAP_OK;
+    if (lut_samples == rt->d.lut_n) {
+        rt->d.spn = samples_per_node;
+        rt->N = 0;   // a cached distance-domain result belongs to the old tables
+        return VAP_OK;
+    }
+    // Build the new arc-length table beside the old one and commit (sizes, pointers, the invalidated cache) only when
+    // every step has succeeded: a failed rebuild leaves the route as it was.
     HIP_TRY(hipStreamSynchronize(st));
     void *nb = nullptr;
     const size_t per = (size_t)(rt->W - 1) * lut_samples;
     HIP_TRY(hipMalloc(&nb, sizeof(double) * 2 * per));
+    auto trial = rt->d;
+    trial.spn = samples_per_node;
+    trial.lut = (double *)nb;
+    trial.lut_mag = (double *)nb + per;
+    trial.lut_n = lut_samples;
+    hipLaunchKernelGGL(vap::k_route_lut, dim3(rt->n_splines), dim3(256), 0, st, trial);
+    hipLaunchKernelGGL(vap::k_route_offsets, dim3(1), dim3(1), 0, st, trial);
+    double info[8];
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(info, trial.info, sizeof(info), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        hipLaunchKernelGGL(vap::k_route_offsets, dim3(1), dim3(1), 0, st, rt->d);   // (the device-side total belongs to the old table again)
+        (void)hipStreamSynchronize(st);
+        (void)hipFree(nb);
+        return vap_fail(VAP_ERR_HIP, "rebuilding the arc-length table failed: %s (the route keeps its tables)", hipGetErrorString(e));
+    }
     if (rt->lut_blob) (void)hipFree(rt->lut_blob);
     rt->lut_blob = nb;
-    rt->d.lut = (double *)nb;
-    rt->d.lut_mag = (double *)nb + per;
-    rt->d.lut_n = lut_samples;
-    hipLaunchKernelGGL(vap::k_route_lut, dim3(rt->n_splines), dim3(256), 0, st, rt->d);
-    hipLaunchKernelGGL(vap::k_route_offsets, dim3(1), dim3(1), 0, st, rt->d);
-    HIP_TRY(hipGetLastError());
-    double info[8];
-    HIP_TRY(hipMemcpyAsync(info, rt->d.info, sizeof(info), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    rt->d = trial;
+    rt->N = 0;   // a cached distance-domain result belongs to the old tables
     rt->total = info[1];
     return VAP_OK;
 }

@@ -206,7 +206,14 @@ struct Lanes {
     __device__ __forceinline__ void flush_bwd(const SlotCtx &c, int tile, const double *ot) const
     {
         const int j = tile * TS + c.s;
-        if (c.N > 0 && j < S) V[c.row + j] = j < c.N ? (IO)vel_sqrt(ot[c.out_off]) : (IO)0;
+        if (c.N > 0 && j < S) {
+            const double v = j < c.N ? vel_sqrt(ot[c.out_off]) : 0.0;
+            V[c.row + j] = (IO)v;
+            // fp32 rows: the scratch row that carried the forward sweep's squared velocities leaves with the fp64
+            // velocities (what the time-domain resample integrates, MPG:566-584: an fp32 row moves a position by 1e-7
+            // relative, now and then across a boundary of the reference's step lookup)
+            if constexpr (!std::is_same<IO, double>::value) UF[c.row + j] = v;
+        }
     }
 
     // One pipeline step of a producer wave.  `rows` holds the rows of tile `t_put`, loaded during the previous step:

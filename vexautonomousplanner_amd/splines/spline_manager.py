@@ -126,7 +126,7 @@ class QuinticHermiteSplineManager:
         try:
             r.set_table_sizes(lut_samples=min_samples)
         except _lib.VapError as e:
-            if e.status == _lib.VAP_ERR_INVALID:
+            if e.status == _lib.VAP_ERR_INVALID and int(min_samples) < 2:   # (other invalid sizes keep their own message)
                 raise IndexError("index 1 is out of bounds for axis 0 with size %d" % max(int(min_samples), 0))  # SM:444
             raise
         self.lookup_table = PathLookupTable(distances=r.lut_distances, parameters=r.lut_parameters,
