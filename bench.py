@@ -133,7 +133,12 @@ def profiled_traffic(stage, workload, dtype, paths, recurrence):
     corrections applied) — only while that profile was taken on this workload and mode AND on these kernel sources
     (it records their hash); otherwise (None, reason): a stale figure is not quoted."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    import re
+
+    def round_of(path):     # r02_traffic.json < r10_traffic.json: by number, not by text
+        m = re.match(r"r(\d+)", os.path.basename(path))
+        return int(m.group(1)) if m else -1
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), key=round_of)
     if not files:
         return None, "no PMC profile committed"
     prof = json.load(open(files[-1]))
@@ -147,6 +152,17 @@ def profiled_traffic(stage, workload, dtype, paths, recurrence):
     kern = {"sample": "k_sample", "velocity": "k_velocity", "fit": "k_fit", "lut": "k_lut"}[stage]
     vals = [v["hbm_bytes"] for k, v in prof["kernels"].items() if kern in k]
     return (sum(vals), name) if vals else (None, f"{name} has no {kern} entry")
+
+
+def profiled_pipeline_traffic(workload, dtype, paths, recurrence):
+    """HBM bytes per step over all of the step's kernels, from the same committed profile (None when stale)."""
+    t, note = 0.0, None
+    for stage in ("fit", "lut", "sample", "velocity"):
+        v, note = profiled_traffic(stage, workload, dtype, paths, recurrence)
+        if v is None:
+            return None
+        t += v
+    return t
 
 
 def launch_ranks(n):
@@ -362,7 +378,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "kernel_ms": dom_ms, "algorithmic_bytes_per_point": stage_bytes[dom]},
+            "kernel_source_sha": kernel_source_sha(),
             "pipeline": {"bytes_per_point": bytes_per_point,
+                         "traffic": profiled_pipeline_traffic(args.workload, args.dtype, B, args.recurrence),
                          "achieved_GBs": bytes_per_point * B * S / (acc["total"] * 1e-3) / 1e9,
                          "frac_of_hbm_peak": bytes_per_point * B * S / (acc["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "stage_ms": {k: round(v, 4) for k, v in acc.items()}},

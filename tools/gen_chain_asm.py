@@ -13,9 +13,12 @@ Why assembly, and why this shape (measured with tools/ubench_chain_lds.hip on MI
   * b128 reads need sub-register pairs, which inline-asm operands cannot name, so the banks are fixed registers
     (clobbers); the compiler keeps everything else out of them.
 
-Record layout (48 bytes, lane = path): +0 rho, +8 g, +16 am, +24 A, +32 cap.  Step stride = P*48+16 bytes (STRIDE,
-an "i" operand bound to an assembler symbol so one text serves every P).  Results: one double per step at
-oaddr + 8*slot.  Forward tiles consume slots 0..TS-1, backward tiles TS-1..0.
+Record layout: the records of two consecutive slots (2m, 2m+1) of one path form an 80-byte PAIR (lane = path, lane
+stride 80): +0 rho0, +8 g0, +16 am0, +24 A0, +32 rho1, +40 g1, +48 am1, +56 A1, +64 cap0, +72 cap1 — five b128 reads
+per two steps (2.5 per step instead of 3 with one 48-byte record per slot: an LDS read costs the chain ~6.6 cycles).
+Pair stride = P*80+64 bytes (STRIDE, an "i" operand bound to an assembler symbol so one text serves every P; the +64
+keeps the producers' stores conflict-free).  Results: one double per step at oaddr + 8*slot.  Forward tiles consume
+slots 0..TS-1, backward tiles TS-1..0.
 
     python3 tools/gen_chain_asm.py            # rewrites the header in place
 """
@@ -32,7 +35,8 @@ TILES = (16, 32, 64)
 def rec(bank, k):
     b = BANK[bank] + 8 * k
     return dict(rho=f"v[{b}:{b+1}]", g=f"v[{b+2}:{b+3}]", am=f"v[{b+4}:{b+5}]", A=f"v[{b+6}:{b+7}]",
-                lo=f"v[{b}:{b+3}]", hi=f"v[{b+4}:{b+7}]", cap=f"v[{BANK[bank]+8*NB+2*k}:{BANK[bank]+8*NB+2*k+1}]")
+                lo=f"v[{b}:{b+3}]", hi=f"v[{b+4}:{b+7}]", cap=f"v[{BANK[bank]+8*NB+2*k}:{BANK[bank]+8*NB+2*k+1}]",
+                cap2=f"v[{BANK[bank]+8*NB+2*k}:{BANK[bank]+8*NB+2*k+3}]")
 
 
 def res(k):
@@ -41,13 +45,16 @@ def res(k):
 
 
 def loads(bank, first_slot):
+    assert first_slot % 2 == 0 and NB % 2 == 0
     out = []
-    for k in range(NB):
-        r = rec(bank, k)
-        off = f"{first_slot + k}*vap_stride_%="
-        out.append(f"ds_read_b128 {r['lo']}, %[addr] offset:{off}")
-        out.append(f"ds_read_b128 {r['hi']}, %[addr] offset:{off}+16")
-        out.append(f"ds_read_b64 {r['cap']}, %[addr] offset:{off}+32")
+    for k in range(0, NB, 2):
+        r0, r1 = rec(bank, k), rec(bank, k + 1)
+        off = f"{(first_slot + k) // 2}*vap_stride_%="
+        out.append(f"ds_read_b128 {r0['lo']}, %[addr] offset:{off}")
+        out.append(f"ds_read_b128 {r0['hi']}, %[addr] offset:{off}+16")
+        out.append(f"ds_read_b128 {r1['lo']}, %[addr] offset:{off}+32")
+        out.append(f"ds_read_b128 {r1['hi']}, %[addr] offset:{off}+48")
+        out.append(f"ds_read_b128 {r0['cap2']}, %[addr] offset:{off}+64")
     return out
 
 
@@ -122,10 +129,11 @@ __device__ __forceinline__ void {name}(uint32_t addr, uint32_t oaddr, double &u,
 HEADER = f"""// vap_chain_asm.h — GENERATED by tools/gen_chain_asm.py (edit the generator, not this file).
 //
 // The chain wave's tile loops of k_velocity_lanes ("a wavefront of paths": lane = path), fully unrolled gfx950
-// assembly.  chain_fwd_<TS> walks slots 0..TS-1 of a tile of LDS records, chain_bwd_<TS> walks TS-1..0; a record is
-// {{rho, g | am, A | cap}} (48 bytes, lane stride 48, step stride STRIDE bytes); one double per slot goes to
-// oaddr + 8*slot.  u / up are the last two squared velocities (MPG:188-311 in the scaled four-instruction form of
-// vap_device.h step4, bit for bit).  Registers v{BANK[0]}..v{LAST} are the two record banks and the result pairs.
+// assembly.  chain_fwd_<TS> walks slots 0..TS-1 of a tile of LDS records, chain_bwd_<TS> walks TS-1..0; the records of
+// slots 2m, 2m+1 are one 80-byte pair {{rho0, g0 | am0, A0 | rho1, g1 | am1, A1 | cap0, cap1}} (lane stride 80, pair stride
+// STRIDE bytes); one double per slot goes to oaddr + 8*slot.  u / up are the last two squared velocities (MPG:188-311
+// in the scaled four-instruction form of vap_device.h step4, bit for bit).  Registers v{BANK[0]}..v{LAST} are the two
+// record banks and the result pairs.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -9,7 +9,7 @@ f = glob.glob(sys.argv[1] + "/*/*counter_collection.csv")[0]
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.Counter()
 for r in csv.DictReader(open(f)):
-    k = r["Kernel_Name"][:44]
+    k = r["Kernel_Name"].replace("(anonymous namespace)::", "")[:52]
     acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
     if r["Counter_Name"] == "SQ_WAVES":
         cnt[k] += 1
@@ -20,4 +20,4 @@ for k in acc:
     a = acc[k]
     w = a["SQ_WAVES"] / n
     rest = " ".join(f"{c[3:]} {a[c] / n / w:.0f}" for c in sorted(a) if c != "SQ_WAVES")
-    print(f"{k:44s} x{n} waves {w:.0f} | per wave: {rest}")
+    print(f"{k:52s} x{n} waves {w:.0f} | per wave: {rest}")

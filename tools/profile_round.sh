@@ -5,6 +5,7 @@
 # 2. two separate PMC passes (FETCH_SIZE, WRITE_SIZE cannot share a pass on gfx950) -> profiles/<tag>_traffic.json,
 #    which records the bench mode and the hash of the kernel sources it was taken on (bench.py refuses a stale one)
 # 3. one SQ pass (instructions / busy cycles per wave) -> profiles/<tag>_sq_counters.txt
+# 4. the bench line itself, taken last -> profiles/<tag>_bench.json (its traffic entries quote the passes above)
 set -e
 tag=${1:-r02}
 shift || true
@@ -19,5 +20,8 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -- p
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-mode --parity-paths 0 $extra > $out/write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $out/sq -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-mode --parity-paths 0 $extra > $out/sq.log 2>&1 || true
 python3 $root/tools/profile_summary.py $tag
+# the bench line to commit: after the PMC passes, so that its roofline.traffic quotes this profile (cpu_baseline included)
+python3 $root/bench.py --steps 20 --warmup 3 $extra > $out/bench_final.log 2>&1
+python3 $root/tools/profile_summary.py $tag > /dev/null
 # gpurun merges only gpurun_out/ back: leave copies there for the caller to move into profiles/
 cp $root/profiles/${tag}_* $root/gpurun_out/profiles/

@@ -14,12 +14,14 @@ using namespace vap;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
-constexpr int kRec = 48;
+constexpr int kPair = 80;              // the records of two consecutive samples of a path (vap_chain_asm.h)
 constexpr int kProducers = 7;
 template <int P> struct Geo {
     static constexpr int TS = 1024 / P;
-    static constexpr int stride = P * kRec + 16;
-    static constexpr int tile_bytes = TS * stride;
+    static constexpr int stride = P * kPair + 64;          // bytes between consecutive sample pairs
+    static constexpr int tile_bytes = (TS / 2) * stride;
+    __host__ __device__ static constexpr int rec_off(int p, int s) { return (s >> 1) * stride + p * kPair + (s & 1) * 32; }
+    __host__ __device__ static constexpr int cap_off(int p, int s) { return (s >> 1) * stride + p * kPair + 64 + (s & 1) * 8; }
 };
 
 template <int P>
@@ -35,10 +37,10 @@ __device__ void fill_tile(unsigned char *rec, const double *kin, const double *d
         double rho, gq, A, cap, am, g;
         fast_derive(fc, kc, kp, din[p * 68 + s], fc.amaxp, rho, gq, A, cap);
         fast_scale(fc.amaxp, gq, A, am, g);
-        unsigned char *r = rec + s * STRIDE + p * kRec;
+        unsigned char *r = rec + Geo<P>::rec_off(p, s);
         *reinterpret_cast<double2 *>(r) = make_double2(rho, g);
         *reinterpret_cast<double2 *>(r + 16) = make_double2(am, A);
-        *reinterpret_cast<double *>(r + 32) = cap;
+        *reinterpret_cast<double *>(rec + Geo<P>::cap_off(p, s)) = cap;
     }
 }
 
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(64 * (kProducers + 1)) void k_bench(int tiles, int 
         double u = 1e-4, up = 0.0;
         const long long t0 = __builtin_amdgcn_s_memtime();
         if (lane < P) {
-            const uint32_t a = (uint32_t)(uintptr_t)(rec + lane * kRec), o = (uint32_t)(uintptr_t)(otile + lane * (TS + 2));
+            const uint32_t a = (uint32_t)(uintptr_t)(rec + lane * kPair), o = (uint32_t)(uintptr_t)(otile + lane * (TS + 2));
             for (int t = 0; t < tiles; t++) {
                 if (mode & 4) chain_bwd<STRIDE, TS>(a, o, u, up);
                 else chain_fwd<STRIDE, TS>(a, o, u, up);
@@ -80,10 +82,11 @@ __global__ __launch_bounds__(64 * (kProducers + 1)) void k_bench(int tiles, int 
             double rho, gq, A, cap, am, g;
             fast_derive(fc, kc, kp, dth, fc.amaxp, rho, gq, A, cap);
             fast_scale(fc.amaxp, gq, A, am, g);
-            unsigned char *r = scratch + (lane % TS) * STRIDE + (((wv - 1) * 2 + (it & 1)) % P) * kRec;
+            const int pp = ((wv - 1) * 2 + (it & 1)) % P, ss = lane % TS;
+            unsigned char *r = scratch + Geo<P>::rec_off(pp, ss);
             *reinterpret_cast<double2 *>(r) = make_double2(rho, g);
             *reinterpret_cast<double2 *>(r + 16) = make_double2(am, A);
-            *reinterpret_cast<double *>(r + 32) = cap;
+            *reinterpret_cast<double *>(scratch + Geo<P>::cap_off(pp, ss)) = cap;
             kp = kc;
             kc = opaque(kc + 1e-9 * cap);
             dth = opaque(dth + 1e-12 * g);
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(64) void k_check(const double *__restrict__ kin, co
     __syncthreads();
     int bad = 0;
     if (lane < P) {
-        const uint32_t a = (uint32_t)(uintptr_t)(rec + lane * kRec), o = (uint32_t)(uintptr_t)(otile + lane * (TS + 2));
+        const uint32_t a = (uint32_t)(uintptr_t)(rec + lane * kPair), o = (uint32_t)(uintptr_t)(otile + lane * (TS + 2));
         for (int dir = 0; dir < 2; dir++) {
             double u = 1e-4, up = 0.0, u2 = 1e-4, up2 = 0.0;
             for (int t = 0; t < 3; t++) {
@@ -115,9 +118,9 @@ __global__ __launch_bounds__(64) void k_check(const double *__restrict__ kin, co
                 else chain_fwd<STRIDE, TS>(a, o, u, up);
                 for (int i = 0; i < TS; i++) {
                     const int s = dir ? TS - 1 - i : i;
-                    const unsigned char *r = rec + s * STRIDE + lane * kRec;
+                    const unsigned char *r = rec + Geo<P>::rec_off(lane, s);
                     const double rho = *(const double *)r, g = *(const double *)(r + 8), am = *(const double *)(r + 16),
-                                 A = *(const double *)(r + 24), cap = *(const double *)(r + 32);
+                                 A = *(const double *)(r + 24), cap = *(const double *)(rec + Geo<P>::cap_off(lane, s));
                     const double nx = step4(am, rho, g, A, cap, u2, up2);
                     up2 = u2;
                     u2 = nx;

@@ -566,7 +566,16 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int 
             if (!dst || !writer) return;
             if (aligned && kbase + kSPT <= S) {
                 if constexpr (sizeof(OT) == 4) {
-                    *reinterpret_cast<float4 *>(dst + row + kbase) = make_float4(v[0], v[1], v[2], v[3]);
+                    if constexpr (HI) {
+                        // the caller's rows leave non-temporally: nothing on the device reads them again before the whole
+                        // batch has been written, and the fp64 side rows the velocity kernel is about to read keep the
+                        // cache (MALL) to themselves
+                        using f4 = float __attribute__((ext_vector_type(4)));
+                        f4 w = {v[0], v[1], v[2], v[3]};
+                        __builtin_nontemporal_store(w, reinterpret_cast<f4 *>(dst + row + kbase));
+                    } else {
+                        *reinterpret_cast<float4 *>(dst + row + kbase) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
                 } else {
                     *reinterpret_cast<double2 *>(dst + row + kbase) = make_double2(v[0], v[1]);
                     *reinterpret_cast<double2 *>(dst + row + kbase + 2) = make_double2(v[2], v[3]);

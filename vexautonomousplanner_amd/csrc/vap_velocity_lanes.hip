@@ -34,7 +34,7 @@ namespace {
 
 constexpr int kLanesThreads = 512;
 constexpr int kLanesProducers = kLanesThreads / 64 - 1;   // wave 0 is the chain wave
-constexpr int kRecBytes = 48;
+constexpr int kPairBytes = 80;                            // the records of two consecutive samples of a path (vap_chain_asm.h)
 constexpr int kTileRecords = 1024;                        // (path, sample) slots per tile = 16 producer batches of 64
 constexpr int kTileBatches = kTileRecords / 64;
 // Batches of a tile by producer wave: producer pw takes batches pw, pw + 7, pw + 14 — three for the first two waves, two
@@ -51,11 +51,16 @@ __device__ __forceinline__ int batch_of(int wv, int i)   // tile batch i-th of w
 template <int P>
 struct LanesGeo {
     static constexpr int TS = kTileRecords / P;            // samples per tile
-    static constexpr int stride = P * kRecBytes + 16;      // bytes between consecutive samples' records
-    static constexpr int rec_bytes = TS * stride;          // one record tile
+    static constexpr int stride = P * kPairBytes + 64;     // bytes between consecutive sample PAIRS' records (the +64: the
+                                                           // producers' 16-byte stores of eight consecutive samples then
+                                                           // fall into eight different bank groups)
+    static constexpr int rec_bytes = (TS / 2) * stride;    // one record tile
     static constexpr int out_row = TS + 2;                 // doubles per path in a result tile (padded: bank spread)
     static constexpr int out_bytes = P * out_row * 8;
     static constexpr size_t lds_bytes = 2 * (size_t)rec_bytes + 2 * (size_t)out_bytes;
+    // byte offsets of sample s of path p inside a record tile: its {rho, g | am, A} half-pair and its cap
+    __host__ __device__ static constexpr int rec_off(int p, int s) { return (s >> 1) * stride + p * kPairBytes + (s & 1) * 32; }
+    __host__ __device__ static constexpr int cap_off(int p, int s) { return (s >> 1) * stride + p * kPairBytes + 64 + (s & 1) * 8; }
 };
 
 // Workgroup barrier for LDS hand-offs only: this wave's LDS operations have completed (they complete in order), global
@@ -83,7 +88,7 @@ struct SlotCtx {
     int N;               // samples of the path (0: no such path)
     int s;               // sample within a tile
     int p;               // path within the group
-    int rec_off;         // byte offset of the slot's record in a record tile
+    int rec_off, cap_off;   // byte offsets of the slot's {rho, g | am, A} and of its cap in a record tile
     int out_off;         // index of the slot's result in a result tile
     bool live;           // the batch exists for this producer and the path exists
 };
@@ -149,7 +154,7 @@ struct Lanes {
         unsigned char *r = rt + c.rec_off;
         *reinterpret_cast<double2 *>(r) = make_double2(rho, g);
         *reinterpret_cast<double2 *>(r + 16) = make_double2(am, A);
-        *reinterpret_cast<double *>(r + 32) = cap;
+        *reinterpret_cast<double *>(rt + c.cap_off) = cap;
     }
     __device__ __forceinline__ void flush_fwd(const SlotCtx &c, int tile, const double *ot) const
     {
@@ -201,18 +206,18 @@ struct Lanes {
         unsigned char *r = rt + c.rec_off;
         *reinterpret_cast<double2 *>(r) = make_double2(rho, g);
         *reinterpret_cast<double2 *>(r + 16) = make_double2(am, A);
-        *reinterpret_cast<double *>(r + 32) = cap;
+        *reinterpret_cast<double *>(rt + c.cap_off) = cap;
     }
     __device__ __forceinline__ void flush_bwd(const SlotCtx &c, int tile, const double *ot) const
     {
         const int j = tile * TS + c.s;
         if (c.N > 0 && j < S) {
             const double v = j < c.N ? vel_sqrt(ot[c.out_off]) : 0.0;
-            V[c.row + j] = (IO)v;
+            __builtin_nontemporal_store((IO)v, &V[c.row + j]);   // (never read again by this kernel: keep it out of the caches)
             // fp32 rows: the scratch row that carried the forward sweep's squared velocities leaves with the fp64
             // velocities (what the time-domain resample integrates, MPG:566-584: an fp32 row moves a position by 1e-7
             // relative, now and then across a boundary of the reference's step lookup)
-            if constexpr (!std::is_same<IO, double>::value) UF[c.row + j] = v;
+            if constexpr (!std::is_same<IO, double>::value) __builtin_nontemporal_store(v, &UF[c.row + j]);
         }
     }
 
@@ -333,7 +338,7 @@ __global__ __launch_bounds__(kLanesThreads, 2) void k_velocity_lanes(int B, int 
         // chain-bound groups (16 paths): the chain wave goes first on its SIMD; larger groups are producer-bound, and the
         // producer wave that shares the SIMD needs the issue slots more than the chain does
         if constexpr (P == 16) __builtin_amdgcn_s_setprio(2);
-        const uint32_t rec0 = (uint32_t)(uintptr_t)(L.rec + lane * kRecBytes);
+        const uint32_t rec0 = (uint32_t)(uintptr_t)(L.rec + lane * kPairBytes);
         const uint32_t out0 = (uint32_t)(uintptr_t)(L.out + lane * G::out_row);
         double u = start_u, up = 0.0;
         long long t_chain = 0, t_all = stats ? __builtin_amdgcn_s_memtime() : 0;
@@ -361,12 +366,12 @@ __global__ __launch_bounds__(kLanesThreads, 2) void k_velocity_lanes(int B, int 
                     chain_bwd<G::stride, TS>(rec0 + par * G::rec_bytes, out0 + par * G::out_bytes, u, up);
                 } else {
                     // a path with a zero heading difference somewhere (dense grids): the sign-aware step, MPG:52-59
-                    const unsigned char *rt = L.rec + (size_t)par * G::rec_bytes + lane * kRecBytes;
+                    const unsigned char *rt = L.rec + (size_t)par * G::rec_bytes;
                     double *ot = L.out + (size_t)par * (G::out_bytes / 8) + lane * G::out_row;
                     for (int s = TS - 1; s >= 0; s--) {
-                        const double2 a = *reinterpret_cast<const double2 *>(rt + s * G::stride);
-                        const double2 b2 = *reinterpret_cast<const double2 *>(rt + s * G::stride + 16);
-                        const double cap = *reinterpret_cast<const double *>(rt + s * G::stride + 32);
+                        const double2 a = *reinterpret_cast<const double2 *>(rt + G::rec_off(lane, s));
+                        const double2 b2 = *reinterpret_cast<const double2 *>(rt + G::rec_off(lane, s) + 16);
+                        const double cap = *reinterpret_cast<const double *>(rt + G::cap_off(lane, s));
                         u = fast_backward_a<true, false>(b2.x, a.x, a.y, b2.y, cap, u, up, 0.0);
                         ot[s] = u;
                     }
@@ -413,7 +418,8 @@ __global__ __launch_bounds__(kLanesThreads, 2) void k_velocity_lanes(int B, int 
         x.fc.h = c.tw / 2.0;
         x.fc.gk = pc.gk;
         x.fc.aangp = pc.aangp;
-        x.rec_off = x.s * G::stride + x.p * kRecBytes;
+        x.rec_off = G::rec_off(x.p, x.s);
+        x.cap_off = G::cap_off(x.p, x.s);
         x.out_off = x.p * G::out_row + x.s;
     }
     const bool four = batch_of(wvu, kBatchesPerProducer - 1) >= 0;   // (this wave has the full count of batches)
