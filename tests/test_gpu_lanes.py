@@ -17,7 +17,7 @@ DTYPES = ["f32", "f64"]      # "f32" = fp32 rows, fp64 recurrence (the default m
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,W,S,seed", [(8, 32, 10000, 3), (33, 8, 1024, 5), (5, 5, 257, 10), (70, 8, 300, 11),
-                                        (3, 2, 64, 9), (2, 16, 7001, 13), (4, 4, 2, 14), (3, 4, 3, 15), (130, 5, 65, 16),
+                                        (3, 2, 64, 9), (2, 16, 7001, 13), (4, 4, 2, 14), (3, 4, 3, 15), (130, 5, 65, 16), (1, 8, 1000, 17),
                                         (2, 64, 30001, 41)])
 def test_lanes_rows_are_bit_identical_to_the_sequential_sweep(torch_mod, B, W, S, seed, dtype):
     from vexautonomousplanner_amd.synth import make_waypoints
