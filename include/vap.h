@@ -93,7 +93,7 @@ int vap_ctx_synchronize(vap_ctx *ctx);
  * lane walks a path, 16-64 paths per workgroup, coefficients streamed through LDS by producer waves — every
  * sample evaluated once per direction, bit-identical to SEQ_FAST, any row length; AUTO picks it for batches of
  * 2048 paths and more.  LANES_16 / _32 / _64 force its group size (tests). */
-enum { VAP_OPT_VELOCITY_KERNEL = 0, VAP_OPT_F32_RECURRENCE = 1 };
+enum { VAP_OPT_VELOCITY_KERNEL = 0, VAP_OPT_F32_RECURRENCE = 1, VAP_OPT_FUSED_SAMPLING = 2 };
 enum { VAP_VELOCITY_AUTO = 0, VAP_VELOCITY_SEQ_LITERAL = 1, VAP_VELOCITY_SEQ_FAST = 2, VAP_VELOCITY_RELAX = 3,
        VAP_VELOCITY_RELAX_BLOCK = 4 /* workgroup per path */, VAP_VELOCITY_RELAX_WAVE = 5 /* wave per path, fp32 */,
        VAP_VELOCITY_LANES = 6 /* lane per path, fp64 recurrence */, VAP_VELOCITY_LANES_16 = 7, VAP_VELOCITY_LANES_32 = 8,
@@ -106,6 +106,11 @@ enum { VAP_VELOCITY_AUTO = 0, VAP_VELOCITY_SEQ_LITERAL = 1, VAP_VELOCITY_SEQ_FAS
  *   VAP_RECURRENCE_F32: rows and recurrence in fp32 — faster, and within 1e-5 on ~98.6 % of config-3-shaped
  *     paths (worst sample 7e-5). */
 enum { VAP_RECURRENCE_F64 = 0, VAP_RECURRENCE_F32 = 1 };
+/* VAP_OPT_FUSED_SAMPLING (0 = off, the default; 1 = on): vap_profile_batch in the default VAP_F32 mode, when the
+ * velocity kernel is LANES (AUTO: batches of 2048 paths and more), samples the paths inside that kernel's forward sweep —
+ * the fp64 curvature / heading-difference rows then reach the recurrence without a round trip through HBM.  Same rows,
+ * bit for bit, as the separate sampling kernel (tests/test_gpu_fused.py); in its present form slower than the two
+ * kernels, hence off. */
 int vap_ctx_set_option(vap_ctx *ctx, int option, int value);
 /* Enable/disable per-stage hipEvent timing (replaces the reference's time.time() log lines,
  * SM:587-594, MPG:398-411).  Off by default. */

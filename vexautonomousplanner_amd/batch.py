@@ -32,11 +32,12 @@ class BatchedTrajectoryGenerator:
     """rebuild_tables + forward_backward_pass (SM:582-594, MPG:70-316) for B independent
     plain-node paths per call, outputs resident in HBM as (B, S) tensors."""
 
-    def __init__(self, device=0, dtype="f32", timing=False, velocity_kernel="auto", recurrence="f64"):
+    def __init__(self, device=0, dtype="f32", timing=False, velocity_kernel="auto", recurrence="f64", fused_sampling=False):
         """dtype "f32" | "f64": type of inputs and outputs.  recurrence (dtype "f32" only): "f64" (default) carries
         the velocity recurrence and its curvature / heading-difference rows in fp64 behind the fp32 outputs — the
         mode that holds 1e-5 against the reference on every path; "f32" is the all-fp32 recurrence (faster,
-        ~1.4 % of config-3-shaped paths have a sample above 1e-5)."""
+        ~1.4 % of config-3-shaped paths have a sample above 1e-5).  fused_sampling (VAP_OPT_FUSED_SAMPLING): the
+        default mode then samples large batches inside the velocity kernel (same rows; measured slower so far: off)."""
         if not torch.cuda.is_available():
             raise RuntimeError("no HIP device visible: vexautonomousplanner_amd has no CPU path")
         self.device = torch.device("cuda", device)
@@ -47,6 +48,7 @@ class BatchedTrajectoryGenerator:
         self._L = _lib.lib()
         self.set_velocity_kernel(velocity_kernel)
         self.set_recurrence(recurrence)
+        self.ctx.set_option(_lib.OPT_FUSED_SAMPLING, 1 if fused_sampling else 0)
 
     def set_recurrence(self, which):
         """"f64" | "f32" (VAP_OPT_F32_RECURRENCE; only matters for dtype "f32")."""

@@ -314,8 +314,14 @@ __global__ __launch_bounds__(256) void k_lut(int W, const double *__restrict__ s
 // magnitudes and trapezoid increments (lanes = consecutive entries of a path, so segment rows are read as
 // broadcasts), the scanner wave adds, all threads store distances and slopes (256-byte rows).
 // Same expressions in the same order as k_lut: the tables are bit-identical.
-constexpr int kLutManyPaths = 64, kLutManyTile = 32, kLutManyThreads = 256;
-constexpr int kLutManyMinPaths = 32768;   // batches from here on (and W <= 9) take the lane-per-path table kernel
+// Two group sizes: 64 paths per workgroup for very many short paths (W <= 9: config 5), 8 for large batches of paths of up
+// to 64 waypoints (config 4's share: 1000 entries of 8 paths are one entry per thread and tile, the eight chains run in
+// eight lanes).
+constexpr int kLutManyTile = 32;
+constexpr int kLutManyMinPaths = 32768;   // P = 64: batches from here on (and W <= 9)
+constexpr int kLutGroupMinPaths = 8192;   // P = 8: batches from here on (and W <= 64); measured at 4096 x 32: 59 us against
+                                          // k_lut's 57 (two workgroups per CU are too few to hide the barriers), at 8192: 75 against 93
+template <int kLutManyPaths, int kLutManyThreads>
 __global__ __launch_bounds__(kLutManyThreads) void k_lut_many(int B, int W, const double *__restrict__ segments,
                                                                double *__restrict__ lut, double *__restrict__ slopes,
                                                                double *__restrict__ meta, uint32_t *__restrict__ flags,
@@ -1809,8 +1815,13 @@ hipError_t launch_lut(hipStream_t st, int B, int W, const double *seg, double *l
     // (the 64 paths' segment rows are staged in LDS: 6 KB per segment column, so short paths only)
     if (!want_stats && !rt.sptab && W <= 9 && B >= kLutManyMinPaths) {
         // very many paths: 64 per workgroup, the sequential sums of 64 paths in the lanes of one wavefront
-        hipLaunchKernelGGL(k_lut_many, dim3((B + kLutManyPaths - 1) / kLutManyPaths), dim3(kLutManyThreads),
-                           sizeof(double) * kLutManyPaths * (W - 1) * 12, st, B, W, seg, lut, slopes, meta, flags, grid);
+        hipLaunchKernelGGL((k_lut_many<64, 256>), dim3((B + 63) / 64), dim3(256), sizeof(double) * 64 * (W - 1) * 12, st, B, W, seg, lut,
+                           slopes, meta, flags, grid);
+        return hipGetLastError();
+    }
+    if (!want_stats && !rt.sptab && W <= 64 && B >= kLutGroupMinPaths) {
+        hipLaunchKernelGGL((k_lut_many<8, 256>), dim3((B + 7) / 8), dim3(256), sizeof(double) * 8 * (W - 1) * 12, st, B, W, seg, lut,
+                           slopes, meta, flags, grid);
         return hipGetLastError();
     }
     // 128 threads: the sequential sum keeps one lane busy, so residency (16 workgroups per CU) is what hides it

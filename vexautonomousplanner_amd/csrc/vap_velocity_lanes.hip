@@ -22,6 +22,7 @@
 #include "vap_chain_asm.h"
 #include "vap_device.h"
 #include "vap_kernels.h"
+#include "vap_sample_lane.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -72,6 +73,14 @@ template <typename IO>
 struct SlotIn {
     double k0, k1, dth, uf;
     IO acc, vc;
+};
+
+// FUSED: the sampling of K3+K4 runs inside the forward producers (vap_sample_lane.h): what that needs
+struct FusedArgs {
+    const double *power = nullptr, *lut = nullptr, *aux = nullptr, *runs = nullptr;   // coefficient blocks, tables, grid constants, grid runs
+    float *ox = nullptr, *oy = nullptr, *oh = nullptr, *ok = nullptr;                 // the caller's rows (any may be NULL)
+    double *k64 = nullptr, *dth64 = nullptr;                                          // fp64 side rows (written forward, read backward)
+    int W = 0;
 };
 
 struct PathConsts {   // per path (its own sample spacing), in LDS
@@ -280,20 +289,24 @@ struct Lanes {
 //            tile #(it+1); the chain walks tile #(it-1) out of buffer (it-1)&1 into result buffer (it-1)&1; producers move
 //            tile #(it-2)'s results out of result buffer it&1.
 // (tile #n of the backward sweep is tile NT-1-n of the row.)
-template <typename IO, int P, bool VCAP, bool ACC>
+template <typename IO, int P, bool VCAP, bool ACC, bool FUSED>
 __global__ __launch_bounds__(kLanesThreads, 2) void k_velocity_lanes(int B, int S, VelConsts<double> c, double start_u, double end_u,
                                                                      const double *__restrict__ meta,
                                                                      const double *__restrict__ curv,
                                                                      const double *__restrict__ dtheta,
                                                                      const IO *__restrict__ vcap, AccRows<IO> acc,
                                                                      IO *__restrict__ vel, double *__restrict__ ufwd,
-                                                                     long long *__restrict__ stats)
+                                                                     long long *__restrict__ stats, FusedArgs fz)
 {
     using G = LanesGeo<P>;
     constexpr int TS = G::TS;
+    static_assert(!FUSED || (TS == 64 && std::is_same<IO, float>::value && !VCAP && !ACC),
+                  "fused sampling: a wavefront = 64 consecutive samples of one path, fp32 rows, plain paths");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ PathConsts s_pc[P];
     __shared__ int s_nmax, s_pdup[P], s_tdup[2];
+    __shared__ double s_win[FUSED ? kLanesProducers * kBatchesPerProducer * kLaneWindow : 1];   // table windows, one per (producer, batch)
+    if constexpr (FUSED) { curv = fz.k64; dtheta = fz.dth64; }
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     if (tid == 0) { s_nmax = 0; s_tdup[0] = 0; s_tdup[1] = 0; }
     if (tid < P) s_pdup[tid] = 0;
@@ -441,7 +454,96 @@ __global__ __launch_bounds__(kLanesThreads, 2) void k_velocity_lanes(int B, int 
     };
     // forward: a lane notes whether any of its slots had a zero heading difference; the paths' flags are raised once, at
     // the turn, and read back per slot for the backward sweep (k_velocity_seq's per-path decision)
-    sweep(std::false_type());
+    if constexpr (FUSED) {
+        // ---- forward sweep with the sampling inside (vap_sample_lane.h): batch i of this wave is path ctx[i].p, tile after
+        // tile; the rows the forward step needs come out of the sampler's registers, not out of HBM
+        LanePath lp[kBatchesPerProducer];
+        LaneCarry carry[kBatchesPerProducer];
+        int w0[kBatchesPerProducer], runc[kBatchesPerProducer];
+        double wnext[kBatchesPerProducer];
+#pragma unroll
+        for (int i = 0; i < kBatchesPerProducer; i++) {
+            const int b = blockIdx.x * P + __builtin_amdgcn_readfirstlane(ctx[i].p);   // (TS = 64: a batch is one path)
+            const int bb = b < B ? b : B - 1;
+            const double *m = meta + (size_t)bb * kMetaStride, *ax = fz.aux + (size_t)bb * kAuxStride;
+            LanePath &q = lp[i];
+            q.G = fz.W - 1;
+            q.D = fz.lut + (size_t)bb * kLutN;
+            q.coef = fz.power + (size_t)bb * q.G * kCoefDoubles;
+            q.runs = fz.runs + (size_t)bb * kGridRunDoubles;
+            q.t_max = m[0];
+            q.total = m[1];
+            q.lstep = ax[0];
+            q.tstep = ax[1];
+            q.inv_tstep = ax[2];
+            q.n_runs = (int)ax[3];
+            q.end_param = (double)(fz.W - 1);
+            q.tab_n = fz.W * kSamplesPerNode;
+            int n = (int)m[3];
+            q.N = n < S ? n : S;
+            w0[i] = 0;
+            runc[i] = 0;
+            wnext[i] = lane_window_fetch(q, 0, lane);
+        }
+        long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        auto fused_step = [&](auto nb_tag, int it) {
+            constexpr int NB = decltype(nb_tag)::value;
+            const int parity = it & 1;
+            if (it < NT) {
+                unsigned char *rt = L.rec + (size_t)parity * G::rec_bytes;
+#pragma unroll
+                for (int i = 0; i < NB; i++) {
+                    double *win = s_win + ((size_t)pw * kBatchesPerProducer + i) * kLaneWindow;
+                    const double wv_in = opaque(wnext[i]);                      // (the one wait for memory of this batch)
+                    if (lane < kLaneWindow) win[lane] = wv_in;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's own stores, read back below
+                    const int j = it * TS + lane;
+                    int nw0;
+                    const long long tq0 = stats ? __builtin_amdgcn_s_memtime() : 0;
+                    const LaneSample o = lane_sample(lp[i], j, lane, win, w0[i], runc[i], carry[i], nw0, stats ? phase : nullptr);
+                    w0[i] = nw0;
+                    wnext[i] = lane_window_fetch(lp[i], nw0, lane);             // the next tile's window: in flight for a whole step
+                    const SlotCtx &x = ctx[i];
+                    if (x.N > 0 && j < S) {
+                        const bool in = j < x.N;
+                        const size_t o_j = x.row + j;
+                        if (fz.ox) __builtin_nontemporal_store(in ? o.x : 0.0f, &fz.ox[o_j]);
+                        if (fz.oy) __builtin_nontemporal_store(in ? o.y : 0.0f, &fz.oy[o_j]);
+                        if (fz.oh) __builtin_nontemporal_store(in ? o.th : 0.0f, &fz.oh[o_j]);
+                        if (fz.ok) __builtin_nontemporal_store(in ? o.kapf : 0.0f, &fz.ok[o_j]);
+                        fz.k64[o_j] = in ? o.kap : 0.0;
+                        if (j >= 1) fz.dth64[o_j - 1] = o.dth_prev;             // (zero from the end sample on)
+                    }
+                    SlotIn<IO> in_;
+                    in_.k0 = o.kap_m1;
+                    in_.k1 = o.kap_m2;
+                    in_.dth = o.dth_prev;
+                    const long long tq1 = stats ? __builtin_amdgcn_s_memtime() : 0;
+                    L.put_fwd(x, it, in_, rt, saw_dup[i]);
+                    if (stats) { phase[5] += tq1 - tq0; phase[6] += __builtin_amdgcn_s_memtime() - tq1; }
+                }
+            }
+            if (it >= 2 && it - 2 < NT) {
+                const double *ot = L.out + (size_t)parity * (G::out_bytes / 8);
+#pragma unroll
+                for (int i = 0; i < NB; i++) L.flush_fwd(ctx[i], it - 2, ot);
+            }
+        };
+        for (int it = 0; it <= NT + 1; it++) {
+            const long long t0 = stats ? __builtin_amdgcn_s_memtime() : 0;
+            if (four) fused_step(std::integral_constant<int, kBatchesPerProducer>(), it);
+            else fused_step(std::integral_constant<int, kBatchesPerProducer - 1>(), it);
+            if (stats) t_busy += __builtin_amdgcn_s_memtime() - t0;
+            lds_barrier();
+        }
+        if (stats && tid == 64) {
+            // (developer print: cycles of producer 0 by phase of the fused forward sweep, all its batches)
+            printf("[fused, workgroup %d, producer 0] grid %lld search %lld slope/index %lld evaluate %lld neighbours %lld | sample+stores %lld records %lld\n",
+                   (int)blockIdx.x, phase[0], phase[1], phase[2], phase[3], phase[4], phase[5], phase[6]);
+        }
+    } else {
+        sweep(std::false_type());
+    }
 #pragma unroll
     for (int i = 0; i < kBatchesPerProducer; i++)
         if (ctx[i].live && saw_dup[i]) s_pdup[ctx[i].p] = 1;
@@ -458,13 +560,28 @@ __global__ __launch_bounds__(kLanesThreads, 2) void k_velocity_lanes(int B, int 
     for (int p = 0; p < P; p++) {
         const int b = blockIdx.x * P + p;
         if (b >= B) break;
-        for (int j = NT * TS + (tid - 64); j < S; j += kLanesThreads - 64) vel[(size_t)b * S + j] = (IO)0;
+        for (int j = NT * TS + (tid - 64); j < S; j += kLanesThreads - 64) {
+            const size_t o = (size_t)b * S + j;
+            vel[o] = (IO)0;
+            if constexpr (FUSED) {
+                if (fz.ox) fz.ox[o] = 0.0f;
+                if (fz.oy) fz.oy[o] = 0.0f;
+                if (fz.oh) fz.oh[o] = 0.0f;
+                if (fz.ok) fz.ok[o] = 0.0f;
+                fz.k64[o] = 0.0;
+                fz.dth64[o] = 0.0;
+            }
+        }
+        if constexpr (FUSED) {   // (the heading difference of the last tile's last sample has no lane above it to write it)
+            if (tid == 64 && NT * TS - 1 < S && NT > 0) fz.dth64[(size_t)b * S + NT * TS - 1] = 0.0;
+        }
     }
 }
 
 template <typename IO, int P>
 hipError_t launch_lanes_p(hipStream_t st, int B, int S, const double c[6], double sv, double ev, const double *meta,
-                          const double *curv, const double *dth, const void *vcap, const AccRowsV &accv, void *vel, double *ufwd)
+                          const double *curv, const double *dth, const void *vcap, const AccRowsV &accv, void *vel, double *ufwd,
+                          const FusedArgs *fused = nullptr)
 {
     using G = LanesGeo<P>;
     VelConsts<double> vc;
@@ -484,13 +601,23 @@ hipError_t launch_lanes_p(hipStream_t st, int B, int S, const double c[6], doubl
     }
 #define VAP_LANES_LAUNCH(VCAP_, ACC_)                                                                                       \
     do {                                                                                                                    \
-        auto kern = k_velocity_lanes<IO, P, VCAP_, ACC_>;                                                                   \
+        auto kern = k_velocity_lanes<IO, P, VCAP_, ACC_, false>;                                                            \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return e;                                                                                      \
         hipLaunchKernelGGL(kern, grid, block, lds, st, B, S, vc, sv * sv, ev * ev, meta, curv, dth, (const IO *)vcap, acc,  \
-                           (IO *)vel, ufwd, stats);                                                                         \
+                           (IO *)vel, ufwd, stats, FusedArgs());                                                            \
     } while (0)
-    if (acc.fwd) VAP_LANES_LAUNCH(true, true);      // (routes with max_acceleration rows always carry initial velocities too)
+    if constexpr (std::is_same<IO, float>::value && P == 16) {
+        if (fused) {
+            auto kern = k_velocity_lanes<float, 16, false, false, true>;
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, grid, block, lds, st, B, S, vc, sv * sv, ev * ev, meta, curv, dth, (const float *)nullptr, acc,
+                               (float *)vel, ufwd, stats, *fused);
+        }
+    }
+    if (fused) { /* launched above */ }
+    else if (acc.fwd) VAP_LANES_LAUNCH(true, true);      // (routes with max_acceleration rows always carry initial velocities too)
     else if (vcap) VAP_LANES_LAUNCH(true, false);
     else VAP_LANES_LAUNCH(false, false);
 #undef VAP_LANES_LAUNCH
@@ -533,6 +660,22 @@ hipError_t launch_velocity_lanes(hipStream_t st, bool io64, int B, int S, const 
     if (io64) return VAP_LANES(double);
     return VAP_LANES(float);
 #undef VAP_LANES
+}
+
+// The fused step of the default mode (fp32 rows, fp64 recurrence, plain paths): sampling (K3+K4) inside the forward
+// producers of K5w, 16 paths per workgroup.  Writes the caller's rows (any of ox..ok may be NULL), the fp64 side rows
+// k64 / dth64 (context scratch) and the velocities; ufwd as in launch_velocity_lanes.
+hipError_t launch_sample_velocity_fused(hipStream_t st, int B, int W, int S, const double c[6], double sv, double ev,
+                                        const double *meta, const double *power, const double *lut, const double *aux,
+                                        const double *runs, float *ox, float *oy, float *oh, float *ok, double *k64, double *dth64,
+                                        float *vel, double *ufwd)
+{
+    FusedArgs f;
+    f.power = power; f.lut = lut; f.aux = aux; f.runs = runs;
+    f.ox = ox; f.oy = oy; f.oh = oh; f.ok = ok;
+    f.k64 = k64; f.dth64 = dth64;
+    f.W = W;
+    return launch_lanes_p<float, 16>(st, B, S, c, sv, ev, meta, k64, dth64, nullptr, AccRowsV(), vel, ufwd, &f);
 }
 
 }  // namespace vap
