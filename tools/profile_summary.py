@@ -27,8 +27,8 @@ def per_kernel(d, name):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == name and "vap::" in r["Kernel_Name"]:
-            name = r["Kernel_Name"].replace("(anonymous namespace)::", "")
-            acc[name.split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+            kname = r["Kernel_Name"].replace("(anonymous namespace)::", "")
+            acc[kname.split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 

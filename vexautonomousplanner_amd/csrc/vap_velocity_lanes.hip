@@ -592,6 +592,10 @@ hipError_t launch_lanes_p(hipStream_t st, int B, int S, const double c[6], doubl
     acc.fwd = (const IO *)accv.fwd; acc.bwd = (const IO *)accv.bwd; acc.dec = (const IO *)accv.dec;
     const dim3 grid((B + P - 1) / P), block(kLanesThreads);
     const size_t lds = G::lds_bytes;
+    constexpr int kMaxDevices = 64;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev = dev < 0 || dev >= kMaxDevices ? 0 : dev;
     // developer knob: VAP_LANES_STATS=1 prints in-kernel cycle shares (synchronises!)
     static const bool want_stats = getenv("VAP_LANES_STATS") != nullptr;
     long long *stats = nullptr;
@@ -602,8 +606,12 @@ hipError_t launch_lanes_p(hipStream_t st, int B, int S, const double c[6], doubl
 #define VAP_LANES_LAUNCH(VCAP_, ACC_)                                                                                       \
     do {                                                                                                                    \
         auto kern = k_velocity_lanes<IO, P, VCAP_, ACC_, false>;                                                            \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        if (e != hipSuccess) return e;                                                                                      \
+        static bool attr_set[kMaxDevices] = {};   /* (per instantiation and device: the call costs the host ~10 us) */         \
+        if (!attr_set[dev]) {                                                                                               \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return e;                                                                                  \
+            attr_set[dev] = true;                                                                                           \
+        }                                                                                                                   \
         hipLaunchKernelGGL(kern, grid, block, lds, st, B, S, vc, sv * sv, ev * ev, meta, curv, dth, (const IO *)vcap, acc,  \
                            (IO *)vel, ufwd, stats, FusedArgs());                                                            \
     } while (0)
