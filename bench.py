@@ -385,6 +385,14 @@ def main():
                          "frac_of_hbm_peak": bytes_per_point * B * S / (acc["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "stage_ms": {k: round(v, 4) for k, v in acc.items()}},
         }
+        # the counted bytes as a rate: how hard the memory system is actually being driven (the algorithmic fraction above
+        # says how much of that is bytes the caller asked for)
+        if traffic:
+            line["roofline"]["traffic_GBs"] = traffic / (dom_ms * 1e-3) / 1e9
+            line["roofline"]["traffic_frac_of_peak"] = line["roofline"]["traffic_GBs"] / HBM_PEAK_GBS
+        if line["pipeline"]["traffic"]:
+            line["pipeline"]["traffic_GBs"] = line["pipeline"]["traffic"] / (acc["total"] * 1e-3) / 1e9
+            line["pipeline"]["traffic_frac_of_peak"] = line["pipeline"]["traffic_GBs"] / HBM_PEAK_GBS
         if parity is not None:
             line["parity"] = parity
         if other_mode is not None:
