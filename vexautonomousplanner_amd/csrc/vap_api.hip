@@ -453,16 +453,23 @@ int vap_profile_batch(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd
     // does see the caller's max_dec, MPG:572-573 — vap_time_profile.)
     const double cc[6] = {c->max_vel, c->max_acc, c->max_acc, c->friction_coef, c->max_jerk, c->track_width};
     StageTimer tm(ctx);
-    HIP_TRY(vap::launch_fit(ctx->stream, f64, B, W, d_waypoints, nullptr, nullptr, (double *)ctx->seg.ptr,
-                            (double *)ctx->power.ptr, nullptr, meta, flags));
-    tm.mark(VAP_T_FIT);
     vap::GridArgs grid;     // the distance grid is defined in the tail of the table kernel
     grid.S = S;
     grid.dd = dd;
     grid.aux = (double *)ctx->aux.ptr;
     grid.runs = (double *)ctx->runs.ptr;
-    HIP_TRY(vap::launch_lut(ctx->stream, B, W, (const double *)ctx->seg.ptr, (double *)ctx->lut.ptr,
-                            nullptr, meta, flags, grid));   // (the sampling kernel forms the interval slopes itself)
+    if (vap::fit_lut_fusable(B, W)) {
+        // fit and table of a path by one workgroup, one launch (VAP_T_FIT then reads 0, VAP_T_LUT the pair)
+        tm.mark(VAP_T_FIT);
+        HIP_TRY(vap::launch_fit_lut(ctx->stream, f64, B, W, d_waypoints, (double *)ctx->seg.ptr, (double *)ctx->power.ptr,
+                                    (double *)ctx->lut.ptr, meta, flags, grid));
+    } else {
+        HIP_TRY(vap::launch_fit(ctx->stream, f64, B, W, d_waypoints, nullptr, nullptr, (double *)ctx->seg.ptr,
+                                (double *)ctx->power.ptr, nullptr, meta, flags));
+        tm.mark(VAP_T_FIT);
+        HIP_TRY(vap::launch_lut(ctx->stream, B, W, (const double *)ctx->seg.ptr, (double *)ctx->lut.ptr,
+                                nullptr, meta, flags, grid));   // (the sampling kernel forms the interval slopes itself)
+    }
     tm.mark(VAP_T_LUT);
     // the default mode on a large batch: sampling inside the velocity kernel's forward sweep (one launch; VAP_T_SAMPLE
     // then reads 0 and VAP_T_VELOCITY is the fused kernel)

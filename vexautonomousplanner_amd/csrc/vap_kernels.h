@@ -46,6 +46,10 @@ struct GridArgs {
 };
 hipError_t launch_lut(hipStream_t st, int B, int W, const double *seg, double *lut, double *slopes, double *meta,
                       uint32_t *flags, GridArgs grid = GridArgs(), RouteTables rt = RouteTables());
+// K1 + K2 in one launch for the fused call on plain paths (same segments, same table)
+bool fit_lut_fusable(int B, int W);
+hipError_t launch_fit_lut(hipStream_t st, bool f64, int B, int W, const void *wp, double *seg, double *pw, double *lut,
+                          double *meta, uint32_t *flags, GridArgs grid);
 hipError_t launch_fit_routes(hipStream_t st, bool f64, int B, int W, int NS, const void *wp, const RouteSplitInputs &in, double *seg,
                              double *pw, double *seglen, double *sptab, int *nspl, double *meta, uint32_t *flags);
 hipError_t launch_route_offsets(hipStream_t st, int B, int W, int NS, int S, double dd, const double *lut, double *sptab,

@@ -34,16 +34,15 @@ struct FitExtras {
     double *out_first = nullptr, *out_second = nullptr;      // [B][W][2]: the derivatives the segments were built from
 };
 
+// The fit of path b by the calling workgroup (sh: 7*W doubles of LDS).  Ends with a workgroup barrier; the segments,
+// coefficient blocks, meta[0] and flags of the path are then written (visible to this workgroup after a fence).
 template <typename IT>
-__global__ __launch_bounds__(256) void k_fit(int W, const IT *__restrict__ waypoints,
-                                             const double *__restrict__ tan_in,
-                                             const double *__restrict__ tan_out, FitExtras ex,
-                                             double *__restrict__ segments, double *__restrict__ power,
-                                             double *__restrict__ seglen, double *__restrict__ meta,
-                                             uint32_t *__restrict__ flags)
+__device__ __forceinline__ void fit_path(int b, int W, const IT *__restrict__ waypoints, const double *__restrict__ tan_in,
+                                         const double *__restrict__ tan_out, const FitExtras &ex, double *__restrict__ segments,
+                                         double *__restrict__ power, double *__restrict__ seglen, double *__restrict__ meta,
+                                         uint32_t *__restrict__ flags, double *sh)
 {
-    extern __shared__ __attribute__((aligned(16))) double sh[];
-    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int tid = threadIdx.x, nt = blockDim.x;
     const int G = W - 1;
     double *pts = sh;             // 2W
     double *dist = pts + 2 * W;   // G (W slots)
@@ -164,6 +163,18 @@ __global__ __launch_bounds__(256) void k_fit(int W, const IT *__restrict__ waypo
     if (tid == 0 && flags) flags[b] = s_flag;
 }
 
+template <typename IT>
+__global__ __launch_bounds__(256) void k_fit(int W, const IT *__restrict__ waypoints,
+                                             const double *__restrict__ tan_in,
+                                             const double *__restrict__ tan_out, FitExtras ex,
+                                             double *__restrict__ segments, double *__restrict__ power,
+                                             double *__restrict__ seglen, double *__restrict__ meta,
+                                             uint32_t *__restrict__ flags)
+{
+    extern __shared__ __attribute__((aligned(16))) double sh[];
+    fit_path<IT>(blockIdx.x, W, waypoints, tan_in, tan_out, ex, segments, power, seglen, meta, flags, sh);
+}
+
 __global__ void k_grid(int B, int W, int S, double dd_in, double *__restrict__ meta, double *__restrict__ aux,
                        double *__restrict__ runs, uint32_t *__restrict__ flags)
 {
@@ -180,13 +191,11 @@ __global__ void k_grid(int B, int W, int S, double dd_in, double *__restrict__ m
 // Routes cut into several splines (rt.sptab set): grid = (routes, spline slots); the workgroup builds the partial
 // (un-offset) table of one spline, SM:436-454, and k_route_offsets (vap_routes_batch.hip) does the rest.
 template <bool SEG_LDS>
-__global__ __launch_bounds__(256) void k_lut(int W, const double *__restrict__ segments,
-                                             double *__restrict__ lut, double *__restrict__ slopes,
-                                             double *__restrict__ meta, uint32_t *__restrict__ flags,
-                                             GridArgs grid, RouteTables rt, long long *__restrict__ stats)
+__device__ __forceinline__ void lut_path(int W, const double *__restrict__ segments, double *__restrict__ lut,
+                                         double *__restrict__ slopes, double *__restrict__ meta, uint32_t *__restrict__ flags,
+                                         const GridArgs &grid, const RouteTables &rt, long long *__restrict__ stats, double *s_seg)
 {
     const long long tl0 = stats ? __builtin_amdgcn_s_memtime() : 0;
-    extern __shared__ __attribute__((aligned(16))) double s_seg[];   // G * 12 when SEG_LDS
     constexpr int kPad = (kLutN + 31) / 32 * 32;   // the sequential sum walks whole groups of 32
     // one array: magnitudes, then (in place) trapezoid increments, then cumulative distances
     __shared__ __attribute__((aligned(16))) double cum[kPad];
@@ -305,6 +314,31 @@ __global__ __launch_bounds__(256) void k_lut(int W, const double *__restrict__ s
         stats[(size_t)b * 4 + 1] = tl2 - tl1;
         stats[(size_t)b * 4 + 2] = __builtin_amdgcn_s_memtime() - tl2;
     }
+}
+
+template <bool SEG_LDS>
+__global__ __launch_bounds__(256) void k_lut(int W, const double *__restrict__ segments,
+                                             double *__restrict__ lut, double *__restrict__ slopes,
+                                             double *__restrict__ meta, uint32_t *__restrict__ flags,
+                                             GridArgs grid, RouteTables rt, long long *__restrict__ stats)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_seg[];   // G * 12 when SEG_LDS
+    lut_path<SEG_LDS>(W, segments, lut, slopes, meta, flags, grid, rt, stats, s_seg);
+}
+
+// K1 + K2 in one launch for the fused call on plain paths (vap_profile_batch): the workgroup that fits a path builds its
+// table right away — one launch and its ramp less per step (24 + 57 us as two kernels at config 3).  The same two
+// bodies: same segments, same table.
+template <typename IT>
+__global__ __launch_bounds__(128) void k_fit_lut(int W, const IT *__restrict__ waypoints, double *__restrict__ segments,
+                                                 double *__restrict__ power, double *__restrict__ lut,
+                                                 double *__restrict__ meta, uint32_t *__restrict__ flags, GridArgs grid)
+{
+    extern __shared__ __attribute__((aligned(16))) double sh[];     // max(7*W, 12*(W-1)) doubles: the fit's arrays, then the segments
+    fit_path<IT>(blockIdx.x, W, waypoints, nullptr, nullptr, FitExtras(), segments, power, nullptr, meta, flags, sh);
+    __threadfence_block();      // the segments and meta[0] this workgroup wrote, read back below
+    __syncthreads();
+    lut_path<true>(W, segments, lut, nullptr, meta, flags, grid, RouteTables(), nullptr, sh);
 }
 
 // K2 for very many short paths (config 5: 131 072 paths x 8 waypoints): one workgroup builds the tables of 64 paths.
@@ -1804,6 +1838,20 @@ hipError_t launch_fit(hipStream_t st, bool f64, int B, int W, const void *wp, co
     ex.out_second = out_second;
     return f64 ? launch_fit_t<double>(st, B, W, wp, tin, tout, ex, seg, pw, seglen, meta, flags)
                : launch_fit_t<float>(st, B, W, wp, tin, tout, ex, seg, pw, seglen, meta, flags);
+}
+
+// K1 + K2 as one launch (k_fit_lut) where the fused call can take it: plain paths, segments that fit the table
+// kernel's LDS staging, batches below the grouped table kernel's threshold.
+bool fit_lut_fusable(int B, int W) { return W - 1 <= 512 && !(B >= kLutGroupMinPaths && W <= 64) && !(B >= kLutManyMinPaths && W <= 9); }
+hipError_t launch_fit_lut(hipStream_t st, bool f64, int B, int W, const void *wp, double *seg, double *pw, double *lut,
+                          double *meta, uint32_t *flags, GridArgs grid)
+{
+    const size_t n = (size_t)(7 * W > 12 * (W - 1) ? 7 * W : 12 * (W - 1));
+    if (f64)
+        hipLaunchKernelGGL(k_fit_lut<double>, dim3(B), dim3(128), sizeof(double) * n, st, W, (const double *)wp, seg, pw, lut, meta, flags, grid);
+    else
+        hipLaunchKernelGGL(k_fit_lut<float>, dim3(B), dim3(128), sizeof(double) * n, st, W, (const float *)wp, seg, pw, lut, meta, flags, grid);
+    return hipGetLastError();
 }
 
 hipError_t launch_lut(hipStream_t st, int B, int W, const double *seg, double *lut, double *slopes, double *meta,
