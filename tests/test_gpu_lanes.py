@@ -28,6 +28,8 @@ def test_lanes_rows_are_bit_identical_to_the_sequential_sweep(torch_mod, B, W, S
         r = run_gpu(torch_mod, make_gen(dtype, velocity_kernel=which), wp, samples=S)
         assert np.all(r["flags"] == 0), which
         assert np.array_equal(r["velocity"], ref["velocity"]), (which, dtype)
+        # (fp32 rows: the curvature row is written by this kernel's backward sweep, by the sampling kernel under "seq_fast")
+        assert np.array_equal(r["curvature"], ref["curvature"]), (which, dtype)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -41,8 +43,9 @@ def test_lanes_ragged_rows(torch_mod, dtype):
     for which in GROUPS:
         r = run_gpu(torch_mod, make_gen(dtype, velocity_kernel=which), wp, dd=0.005, capacity=2048)
         assert np.array_equal(r["velocity"], ref["velocity"]), which
+        assert np.array_equal(r["curvature"], ref["curvature"]), which
         for b in range(len(wp)):
-            assert np.all(r["velocity"][b][n[b]:] == 0)
+            assert np.all(r["velocity"][b][n[b]:] == 0) and np.all(r["curvature"][b][n[b]:] == 0)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -103,6 +106,22 @@ def test_lanes_node_limits_with_accelerations(torch_mod, dtype):
         assert np.array_equal(rows[which], rows["seq_fast"]), which
 
 
+def test_lanes_degenerate_path_in_a_group(torch_mod):
+    """A flagged path (coincident waypoints) shares a workgroup with good ones: they are unaffected, in both grid modes."""
+    from vexautonomousplanner_amd import _lib
+    from vexautonomousplanner_amd.synth import make_waypoints
+    wp = make_waypoints(9, 6, 23).astype(np.float64)
+    bad = wp.copy()
+    bad[4, 3] = bad[4, 2]
+    keep = [b for b in range(9) if b != 4]
+    for kw in (dict(samples=500), dict(dd=0.005, capacity=2048)):
+        ref = run_gpu(torch_mod, make_gen("f32", velocity_kernel="seq_fast"), wp, **kw)
+        for which in GROUPS:
+            r = run_gpu(torch_mod, make_gen("f32", velocity_kernel=which), bad, **kw)
+            assert r["flags"][4] & _lib.FLAG_DEGENERATE and np.all(r["flags"][keep] == 0)
+            assert np.array_equal(r["velocity"][keep], ref["velocity"][keep]), (which, kw)
+
+
 def test_lanes_refuses_the_fp32_recurrence(torch_mod):
     from vexautonomousplanner_amd import _lib
     from vexautonomousplanner_amd.synth import make_waypoints
@@ -122,6 +141,7 @@ def test_auto_takes_lanes_for_large_batches_and_holds_the_oracle_bound(torch_mod
     f = run_gpu(torch_mod, make_gen(dtype, velocity_kernel="lanes"), wp, samples=S)
     s = run_gpu(torch_mod, make_gen(dtype, velocity_kernel="seq_fast"), wp, samples=S)
     assert np.array_equal(a["velocity"], f["velocity"]) and np.array_equal(a["velocity"], s["velocity"])
+    assert np.array_equal(a["curvature"], s["curvature"])
     idx = np.arange(0, B, 97)
     ref = oracle.profile_batch(wp[idx], S, DEFAULT_CONSTRAINTS, n_threads=8)
     err = np.max(np.abs(a["velocity"][idx] - ref["velocity"]) / ref["velocity"])

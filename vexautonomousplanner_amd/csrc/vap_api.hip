@@ -490,20 +490,18 @@ int vap_profile_batch(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd
         ctx->vhi_B = B;
         ctx->vhi_S = S;
     } else {
-    HIP_TRY(vap::launch_sample(ctx->stream, f64, B, W, S, (const double *)ctx->power.ptr,
-                               (const double *)ctx->lut.ptr, nullptr, meta,
-                               (const double *)ctx->aux.ptr, (const double *)ctx->runs.ptr, d_x, d_y, d_heading, curv,
-                               hi ? nullptr : ctx->dth.ptr, hi ? (double *)ctx->k64.ptr : nullptr,
-                               hi ? (double *)ctx->dth64.ptr : nullptr));
-    tm.mark(VAP_T_SAMPLE);
+        HIP_TRY(vap::launch_sample(ctx->stream, f64, B, W, S, (const double *)ctx->power.ptr, (const double *)ctx->lut.ptr, nullptr,
+                                   meta, (const double *)ctx->aux.ptr, (const double *)ctx->runs.ptr, d_x, d_y, d_heading,
+                                   curv, hi ? nullptr : ctx->dth.ptr, hi ? (double *)ctx->k64.ptr : nullptr,
+                                   hi ? (double *)ctx->dth64.ptr : nullptr));
+        tm.mark(VAP_T_SAMPLE);
+        if (hi)
+            VAP_TRY(run_velocity(ctx, true, false, B, S, cc, start_vel, end_vel, meta, ctx->k64.ptr, ctx->dth64.ptr, nullptr,
+                                 vap::AccRowsV(), d_velocity, flags));
+        else
+            VAP_TRY(run_velocity(ctx, f64, f64, B, S, cc, start_vel, end_vel, meta, curv, ctx->dth.ptr, nullptr, vap::AccRowsV(),
+                                 d_velocity, flags));
     }
-    if (fused) {
-    } else if (hi)
-        VAP_TRY(run_velocity(ctx, true, false, B, S, cc, start_vel, end_vel, meta, ctx->k64.ptr, ctx->dth64.ptr, nullptr,
-                             vap::AccRowsV(), d_velocity, flags));
-    else
-        VAP_TRY(run_velocity(ctx, f64, f64, B, S, cc, start_vel, end_vel, meta, curv, ctx->dth.ptr, nullptr, vap::AccRowsV(),
-                             d_velocity, flags));
     tm.mark(VAP_T_VELOCITY);
     ctx->last_B = B;
     ctx->last_W = W;

@@ -94,7 +94,7 @@ struct SlotCtx {
     FastConsts<double> fc;
     double twodd, adecp_b;
     size_t row;          // b*S of the path (of the last path for lanes past the batch: their loads stay inside the buffers)
-    int N;               // samples of the path (0: no such path)
+    int N;               // samples of the path (-1: no such path — nothing of it is stored)
     int s;               // sample within a tile
     int p;               // path within the group
     int rec_off, cap_off;   // byte offsets of the slot's {rho, g | am, A} and of its cap in a record tile
@@ -220,7 +220,7 @@ struct Lanes {
     __device__ __forceinline__ void flush_bwd(const SlotCtx &c, int tile, const double *ot) const
     {
         const int j = tile * TS + c.s;
-        if (c.N > 0 && j < S) {
+        if (c.N >= 0 && j < S) {
             const double v = j < c.N ? vel_sqrt(ot[c.out_off]) : 0.0;
             __builtin_nontemporal_store((IO)v, &V[c.row + j]);   // (never read again by this kernel: keep it out of the caches)
             // fp32 rows: the scratch row that carried the forward sweep's squared velocities leaves with the fp64
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(kLanesThreads, 2) void k_velocity_lanes(int B, int 
     if (tid < P) {
         const int b = blockIdx.x * P + tid;
         PathConsts pc;
-        pc.N = 0;
+        pc.N = -1;
         pc.twodd = pc.amaxp = pc.adecp = pc.gk = pc.aangp = pc.adecp_b = 0.0;
         if (b < B) {
             const double *m = meta + (size_t)b * kMetaStride;
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(kLanesThreads, 2) void k_velocity_lanes(int B, int 
         const int b = blockIdx.x * P + x.p;
         const PathConsts pc = s_pc[x.p];
         x.live = q >= 0;
-        x.N = x.live ? pc.N : 0;
+        x.N = x.live ? pc.N : -1;
         x.row = (size_t)(b < B ? b : B - 1) * S;
         x.twodd = pc.twodd;
         x.adecp_b = pc.adecp_b;
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(kLanesThreads, 2) void k_velocity_lanes(int B, int 
                     w0[i] = nw0;
                     wnext[i] = lane_window_fetch(lp[i], nw0, lane);             // the next tile's window: in flight for a whole step
                     const SlotCtx &x = ctx[i];
-                    if (x.N > 0 && j < S) {
+                    if (x.N >= 0 && j < S) {
                         const bool in = j < x.N;
                         const size_t o_j = x.row + j;
                         if (fz.ox) __builtin_nontemporal_store(in ? o.x : 0.0f, &fz.ox[o_j]);
