@@ -333,6 +333,11 @@ int vap_profile_batch_host(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, doub
 int vap_eval_host(vap_ctx *ctx, int W, const double *h_segments, double param_last, int order,
                   int n, const double *h_t, double *h_out);
 
+/* QHS:288-322 _get_basis_functions (order 0), QHS:324-363 _get_basis_derivatives (1), QHS:365-416
+ * _get_basis_second_derivatives (2), QHS:418-469 _get_basis_third_derivatives (3) at n local parameters
+ * (0..1 inside a segment): out [n][6] fp64 = [H0..H5] of that order, the reference's association order. */
+int vap_basis_host(vap_ctx *ctx, int order, int n, const double *h_t, double *h_out);
+
 /* SM:291-318 distance_to_time for n distances; SM:332-346 get_heading / get_curvature (table step
  * lookup) for n parameters.  what: 0 = distance_to_time, 1 = curvature, 2 = heading. */
 int vap_lookup_host(vap_ctx *ctx, int W, const double *h_segments, double param_last,

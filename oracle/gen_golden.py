@@ -298,6 +298,23 @@ def run_api_pins(mods):
     print(f"api/pin_spline_api: {len(d)} arrays, {os.path.getsize(path) / 1024:.0f} KiB", flush=True)
 
 
+def run_basis_pins(mods):
+    """The four basis helpers of QuinticHermiteSpline (QHS:288-469), the never-called third-derivative one included,
+    at local parameters inside, at and slightly outside [0, 1]."""
+    qh = mods[1].QuinticHermiteSpline()
+    rng = np.random.default_rng(12)
+    ts = np.concatenate([np.linspace(0.0, 1.0, 41), rng.random(64), [1e-12, 1 - 1e-12, 0.5, 1.0 / 3.0, -0.25, 1.25]])
+    d = {"t": ts}
+    for order, f in enumerate((qh._get_basis_functions, qh._get_basis_derivatives, qh._get_basis_second_derivatives,
+                               qh._get_basis_third_derivatives)):
+        d[f"basis{order}"] = np.array([np.asarray(f(float(t)), dtype=np.float64) for t in ts])
+    out = os.path.join(OUT, "api")
+    os.makedirs(out, exist_ok=True)
+    path = os.path.join(out, "pin_basis.npz")
+    np.savez_compressed(path, **d)
+    print(f"api/pin_basis: {len(d)} arrays, {os.path.getsize(path) / 1024:.0f} KiB", flush=True)
+
+
 def run_table_size_pins(mods):
     """build_lookup_table(min_samples != 1000) and precompute_path_properties(samples_per_node != 1000) (SM:426-475,
     477-548): tables, lookups and the velocity pass of the reference with non-default sizes, on a plain path and on a
@@ -448,6 +465,8 @@ def main():
         run_api_pins(mods)
     if want("table_size_pins"):
         run_table_size_pins(mods)
+    if want("basis_pins"):
+        run_basis_pins(mods)
     if want("feat_mixed"):
         na = [{} for _ in range(8)]
         na[2] = {"is_reverse_node": True, "wait_time": 0.1}

@@ -46,6 +46,7 @@ def lib():
         L.vapo_path_create.restype = C.c_void_p
         L.vapo_path_create.argtypes = [C.c_int, c_double_p, C.POINTER(_Nodes), C.POINTER(_Actions)]
         L.vapo_path_destroy.argtypes = [C.c_void_p]
+        L.vapo_basis.argtypes = [C.c_int, C.c_double, c_double_p]
         L.vapo_n_splines.argtypes = [C.c_void_p]
         L.vapo_n_segments.argtypes = [C.c_void_p]
         L.vapo_get_segments.argtypes = [C.c_void_p, c_double_p, c_double_p, c_double_p]
@@ -225,6 +226,16 @@ class OraclePath:
         if T < 0:
             raise ValueError(f"generate_motion_profile failed ({T})")
         return out[:T].copy(), nmap[:nn.value].copy(), amap[:na.value].copy()
+
+
+def basis(order, ts):
+    """QHS:288-469: rows [H0..H5] of the basis of the given derivative order (0..3) at local parameters ts."""
+    ts = np.atleast_1d(np.asarray(ts, dtype=np.float64))
+    out = np.empty((len(ts), 6), dtype=np.float64)
+    L = lib()
+    for i, t in enumerate(ts):
+        L.vapo_basis(int(order), float(t), _dp(out[i]))
+    return out
 
 
 def profile_batch(waypoints, S, constraints, start_vel=0.01, end_vel=0.01, n_threads=1,

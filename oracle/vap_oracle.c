@@ -96,6 +96,25 @@ static void basis2(double t, double H[6])
     H[5] = 3 * t - 12 * t2 + 10 * t3;
 }
 
+/* QHS:418-469 (in the class, never called by the reference) */
+static void basis3(double t, double H[6])
+{
+    double t2 = t * t;
+    H[0] = -60 + 360 * t - 360 * t2;
+    H[1] = 60 - 360 * t + 360 * t2;
+    H[2] = -36 + 192 * t - 180 * t2;
+    H[3] = -24 + 168 * t - 180 * t2;
+    H[4] = -9 + 36 * t - 30 * t2;
+    H[5] = 3 - 24 * t + 30 * t2;
+}
+void vapo_basis(int order, double t, double H[6])
+{
+    if (order == 0) basis0(t, H);
+    else if (order == 1) basis1(t, H);
+    else if (order == 2) basis2(t, H);
+    else basis3(t, H);
+}
+
 /* QHS:506-541 _normalize_parameter */
 static void normalize_parameter(const spline_t *s, double t, double *local_t, int *idx)
 {

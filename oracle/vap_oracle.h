@@ -51,6 +51,8 @@ int vapo_n_segments(const vapo_path *p); /* total over splines == W-1 */
 void vapo_get_segments(const vapo_path *p, double *seg, double *seglen, double *param_last);
 
 /* scalar evaluators at a GLOBAL parameter (spline_manager.py:204-241) */
+/* QHS:288-469: [H0..H5] of the position / first / second / third derivative basis (order 0..3) at local parameter t */
+void vapo_basis(int order, double t, double H[6]);
 void vapo_point(const vapo_path *p, double t, double out[2]);
 void vapo_derivative(const vapo_path *p, double t, double out[2]);
 void vapo_second_derivative(const vapo_path *p, double t, double out[2]);

@@ -237,6 +237,23 @@ def pins():
     return np.load(os.path.join(gu.GOLDEN, "api", "pin_spline_api.npz"))
 
 
+@pytest.mark.parametrize("order,method", [(0, "_get_basis_functions"), (1, "_get_basis_derivatives"),
+                                          (2, "_get_basis_second_derivatives"), (3, "_get_basis_third_derivatives")])
+def test_basis_helpers_match_reference(mods, order, method):
+    """QHS:288-469 through vap_basis_host: the device rows equal the reference's bit for bit (same association order),
+    the third-derivative basis — which nothing in the reference calls — included."""
+    from oracle import oracle
+    from vexautonomousplanner_amd._device_path import basis_rows
+    from vexautonomousplanner_amd.splines.quintic_hermite_spline import QuinticHermiteSpline
+    p = np.load(os.path.join(gu.GOLDEN, "api", "pin_basis.npz"))
+    rows = basis_rows(order, p["t"])
+    np.testing.assert_array_equal(rows, p[f"basis{order}"])
+    np.testing.assert_array_equal(rows, oracle.basis(order, p["t"]))
+    q = QuinticHermiteSpline()
+    for i in (0, 7, 40, 60):
+        np.testing.assert_array_equal(getattr(q, method)(float(p["t"][i])), p[f"basis{order}"][i])
+
+
 def test_arc_length_api_matches_reference(mods, pins):
     """QuinticHermiteSpline.get_arc_length (Gauss-Legendre, QHS:592-644), get_total_arc_length,
     get_parameter_by_arc_length (bisection, QHS:646-717), percent_* and get_magnitude."""

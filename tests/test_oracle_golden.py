@@ -169,3 +169,11 @@ def test_tables_of_other_sizes_match_reference(tag):
     with pytest.raises(IndexError):
         op.build_tables_sized(1, 1000)
     assert int(p["one_sample_raises"]) == 1
+
+
+@pytest.mark.parametrize("order", [0, 1, 2, 3])
+def test_basis_rows_match_reference(order):
+    """_get_basis_functions / _derivatives / _second_derivatives / _third_derivatives (QHS:288-469; the last one is in
+    the reference's class and called by nothing there): tests/golden/api/pin_basis.npz holds the reference's rows."""
+    p = np.load(os.path.join(gu.GOLDEN, "api", "pin_basis.npz"))
+    np.testing.assert_array_equal(oracle.basis(order, p["t"]), p[f"basis{order}"])

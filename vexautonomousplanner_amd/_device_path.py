@@ -13,6 +13,19 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+def basis_rows(order, ts, device=0):
+    """vap_basis_host: rows [H0..H5] of the quintic Hermite basis of derivative order 0..3 (QHS:288-469)."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("no HIP device visible: vexautonomousplanner_amd has no CPU path")
+    ts = np.ascontiguousarray(np.atleast_1d(ts), dtype=np.float64)
+    out = np.empty((len(ts), 6), dtype=np.float64)
+    dp = C.POINTER(C.c_double)
+    ctx = _lib.default_context(device)
+    _lib.check(_lib.lib().vap_basis_host(ctx.handle, int(order), len(ts), ts.ctypes.data_as(dp), out.ctypes.data_as(dp)),
+               "vap_basis_host")
+    return out
+
+
 class DevicePath:
     """Segments / arc-length table of ONE spline on the GPU + host mirrors of the small arrays."""
 

@@ -40,7 +40,7 @@ EXPORTS = (
     "vap_ctx_destroy", "vap_ctx_set_stream", "vap_ctx_synchronize", "vap_ctx_set_option",
     "vap_ctx_set_timing",
     "vap_last_timing", "vap_fit", "vap_build_lut", "vap_sample", "vap_velocity_pass",
-    "vap_time_profile", "vap_profile_batch", "vap_profile_batch_host", "vap_eval_host", "vap_lookup_host",
+    "vap_time_profile", "vap_profile_batch", "vap_profile_batch_host", "vap_eval_host", "vap_basis_host", "vap_lookup_host",
     "vap_route_create", "vap_route_destroy", "vap_route_info", "vap_route_set_table_sizes", "vap_route_table_sizes", "vap_route_get_splines", "vap_route_eval",
     "vap_route_lookup", "vap_route_sample_count", "vap_route_forward_backward", "vap_route_motion_profile",
     "vap_grid_distances", "vap_route_limits", "vap_velocity_pass_limits", "vap_time_insert_waits", "vap_fit_ex",
@@ -129,6 +129,7 @@ def lib():
                                           C.c_int, vp, vp, vp, vp, vp]
     L.vap_time_insert_events.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(Constraints)] + [vp] * 14
     L.vap_eval_host.argtypes = [vp, C.c_int, dp, C.c_double, C.c_int, C.c_int, dp, dp]
+    L.vap_basis_host.argtypes = [vp, C.c_int, C.c_int, dp, dp]
     L.vap_lookup_host.argtypes = [vp, C.c_int, dp, C.c_double, dp, C.c_int, C.c_int, dp, dp]
     lp = C.POINTER(C.c_long)
     L.vap_route_create.argtypes = [vp, C.POINTER(RouteDesc), C.POINTER(vp)]

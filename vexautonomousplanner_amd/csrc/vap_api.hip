@@ -842,6 +842,20 @@ int vap_eval_host(vap_ctx *ctx, int W, const double *h_segments, double param_la
     return VAP_OK;
 }
 
+int vap_basis_host(vap_ctx *ctx, int order, int n, const double *h_t, double *h_out)
+{
+    VAP_TRY(vap_set_device(ctx));
+    if (order < 0 || order > 3 || n < 0 || (n > 0 && (!h_t || !h_out))) return vap_fail(VAP_ERR_INVALID, "bad argument");
+    if (n == 0) return VAP_OK;
+    VAP_TRY(ctx->ensure(ctx->small_in, (size_t)n * sizeof(double)));
+    VAP_TRY(ctx->ensure(ctx->small_out, (size_t)n * 6 * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(ctx->small_in.ptr, h_t, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(vap::launch_basis(ctx->stream, order, n, (const double *)ctx->small_in.ptr, (double *)ctx->small_out.ptr));
+    HIP_TRY(hipMemcpyAsync(h_out, ctx->small_out.ptr, (size_t)n * 6 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return VAP_OK;
+}
+
 int vap_lookup_host(vap_ctx *ctx, int W, const double *h_segments, double param_last, const double *h_lut,
                     int what, int n, const double *h_in, double *h_out)
 {

@@ -61,11 +61,20 @@ __device__ __forceinline__ void hermite_d1_ref(const double *__restrict__ sg, do
     oy = ay;
 }
 
-// QHS:288-322 / 365-416 position and second-derivative bases in the reference's association order.
+// QHS:288-322 / 324-363 / 365-416 / 418-469 the position, first-, second- and third-derivative bases in the reference's
+// association order.  (The third-derivative basis is in the reference's class but none of its callers: here it is
+// reachable through vap_basis_host, order 3.)
 __device__ __forceinline__ void hermite_basis_ref(int order, double t, double H[6])
 {
     const double t2 = t * t, t3 = t2 * t, t4 = t3 * t, t5 = t4 * t;
-    if (order == 0) {
+    if (order == 3) {
+        H[0] = -60 + 360 * t - 360 * t2;
+        H[1] = 60 - 360 * t + 360 * t2;
+        H[2] = -36 + 192 * t - 180 * t2;
+        H[3] = -24 + 168 * t - 180 * t2;
+        H[4] = -9 + 36 * t - 30 * t2;
+        H[5] = 3 - 24 * t + 30 * t2;
+    } else if (order == 0) {
         H[0] = 1 - 10 * t3 + 15 * t4 - 6 * t5;
         H[1] = 10 * t3 - 15 * t4 + 6 * t5;
         H[2] = t - 6 * t3 + 8 * t4 - 3 * t5;

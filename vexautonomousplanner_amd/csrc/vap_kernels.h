@@ -131,6 +131,7 @@ hipError_t launch_time_waits(hipStream_t st, int B, int W, int M, int cap_in, in
                              double max_vel = 0, double max_acc = 0, double track_width = 0);
 hipError_t launch_eval(hipStream_t st, int W, const double *seg, double t_max, int order, int n, const double *t,
                        double *out);
+hipError_t launch_basis(hipStream_t st, int order, int n, const double *t, double *out);   // out [n][6]
 hipError_t launch_lookup(hipStream_t st, int W, const double *seg, double t_max, const double *lut, int what,
                          int n, const double *in, double *out);
 

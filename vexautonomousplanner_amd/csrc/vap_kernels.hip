@@ -1783,6 +1783,17 @@ __global__ void k_eval(int W, const double *__restrict__ seg, double t_max, int 
     out[2 * i + 1] = y;
 }
 
+// QHS:288-469 _get_basis_functions / _derivatives / _second_derivatives / _third_derivatives at n LOCAL parameters
+__global__ void k_basis(int order, int n, const double *__restrict__ t, double *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double H[6];
+    hermite_basis_ref(order, t[i], H);
+#pragma unroll
+    for (int k = 0; k < 6; k++) out[(size_t)i * 6 + k] = H[k];
+}
+
 // what: 0 = SM:291-318 distance_to_time, 1 = SM:340-346 get_curvature, 2 = SM:332-338 get_heading
 __global__ void k_lookup(int W, const double *__restrict__ seg, double t_max, const double *__restrict__ lut,
                          int what, int n, const double *__restrict__ in, double *__restrict__ out)
@@ -2220,6 +2231,12 @@ hipError_t launch_eval(hipStream_t st, int W, const double *seg, double t_max, i
                        double *out)
 {
     hipLaunchKernelGGL(k_eval, dim3((n + 255) / 256), dim3(256), 0, st, W, seg, t_max, order, n, t, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_basis(hipStream_t st, int order, int n, const double *t, double *out)
+{
+    hipLaunchKernelGGL(k_basis, dim3((n + 255) / 256), dim3(256), 0, st, order, n, t, out);
     return hipGetLastError();
 }
 

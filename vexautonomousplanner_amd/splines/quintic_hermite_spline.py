@@ -144,6 +144,25 @@ class QuinticHermiteSpline(Spline):
         self._require_fit()
         return self._dev.eval(2, t)[0]
 
+    # QHS:288-469: the four basis rows.  The class's own evaluators never come here (the device evaluates point and
+    # derivatives whole); they exist for callers of the reference's helpers, the third-derivative one included (in
+    # the reference's class, called by nothing there).
+    def _basis(self, order: int, t: float) -> np.ndarray:
+        from .._device_path import basis_rows
+        return basis_rows(order, [t])[0]
+
+    def _get_basis_functions(self, t: float) -> np.ndarray:
+        return self._basis(0, t)
+
+    def _get_basis_derivatives(self, t: float) -> np.ndarray:
+        return self._basis(1, t)
+
+    def _get_basis_second_derivatives(self, t: float) -> np.ndarray:
+        return self._basis(2, t)
+
+    def _get_basis_third_derivatives(self, t: float) -> np.ndarray:
+        return self._basis(3, t)
+
     def get_points(self, ts) -> np.ndarray:
         """Vector form of get_point (one device launch for all parameters)."""
         self._require_fit()
