@@ -102,13 +102,16 @@ struct SlotCtx {
     bool live;           // the batch exists for this producer and the path exists
 };
 
-template <typename IO, int P, bool VCAP, bool ACC>
+// D: element type of the heading-difference row (double; float when the sampling kernel left the fp32-row mode's side row
+// as the fp32 values it holds anyway — 4 B/pt less to read in each sweep)
+template <typename IO, int P, bool VCAP, bool ACC, typename D = double>
 struct Lanes {
     using G = LanesGeo<P>;
     static constexpr int TS = G::TS;
 
     int S;
-    const double *K, *DT;
+    const double *K;
+    const D *DT;
     const IO *VC;
     AccRows<IO> acc;
     IO *V;
@@ -134,7 +137,7 @@ struct Lanes {
         const size_t i1 = at(c, j - 1);
         in.k0 = K[i1];
         in.k1 = K[at(c, j - 2)];
-        in.dth = DT[i1];
+        in.dth = (double)DT[i1];
         if constexpr (ACC) in.acc = acc.fwd[i1];
         if constexpr (VCAP) in.vc = VC[at(c, j)];
     }
@@ -179,7 +182,7 @@ struct Lanes {
         const size_t i0 = at(c, j), i1 = at(c, j + 1);
         in.k0 = K[i1];
         in.k1 = K[at(c, j + 2)];
-        in.dth = DT[i0];
+        in.dth = (double)DT[i0];
         in.uf = UF[i0];
         if constexpr (ACC) in.acc = acc.bwd[i1];
     }
@@ -289,11 +292,11 @@ struct Lanes {
 //            tile #(it+1); the chain walks tile #(it-1) out of buffer (it-1)&1 into result buffer (it-1)&1; producers move
 //            tile #(it-2)'s results out of result buffer it&1.
 // (tile #n of the backward sweep is tile NT-1-n of the row.)
-template <typename IO, int P, bool VCAP, bool ACC, bool FUSED>
+template <typename IO, int P, bool VCAP, bool ACC, bool FUSED, typename D = double>
 __global__ __launch_bounds__(kLanesThreads, 2) void k_velocity_lanes(int B, int S, VelConsts<double> c, double start_u, double end_u,
                                                                      const double *__restrict__ meta,
                                                                      const double *__restrict__ curv,
-                                                                     const double *__restrict__ dtheta,
+                                                                     const D *__restrict__ dtheta,
                                                                      const IO *__restrict__ vcap, AccRows<IO> acc,
                                                                      IO *__restrict__ vel, double *__restrict__ ufwd,
                                                                      long long *__restrict__ stats, FusedArgs fz)
@@ -306,6 +309,7 @@ __global__ __launch_bounds__(kLanesThreads, 2) void k_velocity_lanes(int B, int 
     __shared__ PathConsts s_pc[P];
     __shared__ int s_nmax, s_pdup[P], s_tdup[2];
     __shared__ double s_win[FUSED ? kLanesProducers * kBatchesPerProducer * kLaneWindow : 1];   // table windows, one per (producer, batch)
+    static_assert(!FUSED || std::is_same<D, double>::value, "fused sampling writes its own fp64 side rows");
     if constexpr (FUSED) { curv = fz.k64; dtheta = fz.dth64; }
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     if (tid == 0) { s_nmax = 0; s_tdup[0] = 0; s_tdup[1] = 0; }
@@ -336,7 +340,7 @@ __global__ __launch_bounds__(kLanesThreads, 2) void k_velocity_lanes(int B, int 
     __syncthreads();
     const int NT = (s_nmax + TS - 1) / TS;
 
-    Lanes<IO, P, VCAP, ACC> L;
+    Lanes<IO, P, VCAP, ACC, D> L;
     L.S = S;
     L.K = curv; L.DT = dtheta; L.VC = vcap; L.acc = acc; L.V = vel;
     if constexpr (std::is_same<IO, double>::value) L.UF = reinterpret_cast<double *>(vel);   // fp64 rows: in place
@@ -381,12 +385,27 @@ __global__ __launch_bounds__(kLanesThreads, 2) void k_velocity_lanes(int B, int 
                     // a path with a zero heading difference somewhere (dense grids): the sign-aware step, MPG:52-59
                     const unsigned char *rt = L.rec + (size_t)par * G::rec_bytes;
                     double *ot = L.out + (size_t)par * (G::out_bytes / 8) + lane * G::out_row;
-                    for (int s = TS - 1; s >= 0; s--) {
-                        const double2 a = *reinterpret_cast<const double2 *>(rt + G::rec_off(lane, s));
-                        const double2 b2 = *reinterpret_cast<const double2 *>(rt + G::rec_off(lane, s) + 16);
-                        const double cap = *reinterpret_cast<const double *>(rt + G::cap_off(lane, s));
-                        u = fast_backward_a<true, false>(b2.x, a.x, a.y, b2.y, cap, u, up, 0.0);
-                        ot[s] = u;
+                    // (eight steps' records first, then the eight dependent steps, then their results: the loads of a
+                    // step do not wait behind the previous step's store)
+                    constexpr int NBs = 8;
+                    static_assert(TS % NBs == 0, "tile length");
+#pragma unroll 1
+                    for (int s0 = TS - NBs; s0 >= 0; s0 -= NBs) {
+                        double2 a[NBs], b2[NBs];
+                        double cap[NBs], r[NBs];
+#pragma unroll
+                        for (int k = 0; k < NBs; k++) {
+                            a[k] = *reinterpret_cast<const double2 *>(rt + G::rec_off(lane, s0 + k));
+                            b2[k] = *reinterpret_cast<const double2 *>(rt + G::rec_off(lane, s0 + k) + 16);
+                            cap[k] = *reinterpret_cast<const double *>(rt + G::cap_off(lane, s0 + k));
+                        }
+#pragma unroll
+                        for (int k = NBs - 1; k >= 0; k--) {
+                            u = fast_backward_a<true, false>(b2[k].x, a[k].x, a[k].y, b2[k].y, cap[k], u, up, 0.0);
+                            r[k] = u;
+                        }
+#pragma unroll
+                        for (int k = 0; k < NBs; k++) ot[s0 + k] = r[k];
                     }
                     if (lane == 0) s_tdup[par] = 0;   // (the producers raise it again two steps on, behind a barrier)
                     dup_tiles++;
@@ -581,7 +600,7 @@ __global__ __launch_bounds__(kLanesThreads, 2) void k_velocity_lanes(int B, int 
 template <typename IO, int P>
 hipError_t launch_lanes_p(hipStream_t st, int B, int S, const double c[6], double sv, double ev, const double *meta,
                           const double *curv, const double *dth, const void *vcap, const AccRowsV &accv, void *vel, double *ufwd,
-                          const FusedArgs *fused = nullptr)
+                          const FusedArgs *fused = nullptr, const float *dth32 = nullptr)
 {
     using G = LanesGeo<P>;
     VelConsts<double> vc;
@@ -627,7 +646,21 @@ hipError_t launch_lanes_p(hipStream_t st, int B, int S, const double c[6], doubl
     if (fused) { /* launched above */ }
     else if (acc.fwd) VAP_LANES_LAUNCH(true, true);      // (routes with max_acceleration rows always carry initial velocities too)
     else if (vcap) VAP_LANES_LAUNCH(true, false);
-    else VAP_LANES_LAUNCH(false, false);
+    else if (dth32) {
+        if constexpr (std::is_same<IO, float>::value) {
+            auto kern = k_velocity_lanes<float, P, false, false, false, float>;
+            static bool attr_set32[kMaxDevices] = {};
+            if (!attr_set32[dev]) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return e;
+                attr_set32[dev] = true;
+            }
+            hipLaunchKernelGGL(kern, grid, block, lds, st, B, S, vc, sv * sv, ev * ev, meta, curv, dth32, (const float *)nullptr, acc,
+                               (float *)vel, ufwd, stats, FusedArgs());
+        } else {
+            return hipErrorInvalidValue;
+        }
+    } else VAP_LANES_LAUNCH(false, false);
 #undef VAP_LANES_LAUNCH
     if (stats) {
         std::vector<long long> h((size_t)grid.x * 16);
@@ -657,14 +690,16 @@ int velocity_lanes_group(int B)
 
 hipError_t launch_velocity_lanes(hipStream_t st, bool io64, int B, int S, const double c[6], double sv, double ev,
                                  const double *meta, const void *curv, const void *dth, const void *vcap, const AccRowsV &acc,
-                                 void *vel, void *ufwd, int group)
+                                 void *vel, void *ufwd, int group, bool dth_f32)
 {
     if (acc.fwd && !vcap) return hipErrorInvalidValue;
+    if (dth_f32 && (io64 || vcap || acc.fwd)) return hipErrorInvalidValue;   // (plain paths behind fp32 rows only)
+    const float *d32 = dth_f32 ? (const float *)dth : nullptr;
     const int P = group > 0 ? group : velocity_lanes_group(B);
 #define VAP_LANES(IO_)                                                                                                          \
-    (P == 16 ? launch_lanes_p<IO_, 16>(st, B, S, c, sv, ev, meta, (const double *)curv, (const double *)dth, vcap, acc, vel, (double *)ufwd) \
-     : P == 32 ? launch_lanes_p<IO_, 32>(st, B, S, c, sv, ev, meta, (const double *)curv, (const double *)dth, vcap, acc, vel, (double *)ufwd) \
-               : launch_lanes_p<IO_, 64>(st, B, S, c, sv, ev, meta, (const double *)curv, (const double *)dth, vcap, acc, vel, (double *)ufwd))
+    (P == 16 ? launch_lanes_p<IO_, 16>(st, B, S, c, sv, ev, meta, (const double *)curv, (const double *)dth, vcap, acc, vel, (double *)ufwd, nullptr, d32) \
+     : P == 32 ? launch_lanes_p<IO_, 32>(st, B, S, c, sv, ev, meta, (const double *)curv, (const double *)dth, vcap, acc, vel, (double *)ufwd, nullptr, d32) \
+               : launch_lanes_p<IO_, 64>(st, B, S, c, sv, ev, meta, (const double *)curv, (const double *)dth, vcap, acc, vel, (double *)ufwd, nullptr, d32))
     if (io64) return VAP_LANES(double);
     return VAP_LANES(float);
 #undef VAP_LANES
