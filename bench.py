@@ -127,11 +127,10 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
-def profiled_traffic(stage, workload, dtype, paths, recurrence):
-    """HBM bytes per launch of the stage's kernel from the committed PMC profile of this round
-    (profiles/r*_traffic.json, made by tools/profile_round.sh: separate FETCH_SIZE / WRITE_SIZE passes, gfx950
-    corrections applied) — only while that profile was taken on this workload and mode AND on these kernel sources
-    (it records their hash); otherwise (None, reason): a stale figure is not quoted."""
+def committed_profile(workload, dtype, paths, recurrence):
+    """The committed PMC profile of this round (profiles/r*_traffic.json, made by tools/profile_round.sh: separate
+    FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections applied) — only while it was taken on this workload and mode AND on
+    these kernel sources (it records their hash); otherwise (None, reason): a stale figure is not quoted."""
     import glob
     import re
 
@@ -149,20 +148,27 @@ def profiled_traffic(stage, workload, dtype, paths, recurrence):
         return None, f"{name} was taken on another workload / mode"
     if prof.get("kernel_source_sha") != kernel_source_sha():
         return None, f"{name} is stale: the kernel sources changed since it was taken"
+    return prof, name
+
+
+def profiled_traffic(stage, workload, dtype, paths, recurrence):
+    """HBM bytes per launch of the stage's kernel from the committed profile, or (None, reason)."""
+    prof, name = committed_profile(workload, dtype, paths, recurrence)
+    if prof is None:
+        return None, name
     kern = {"sample": "k_sample", "velocity": "k_velocity", "fit": "k_fit", "lut": "k_lut"}[stage]
     vals = [v["hbm_bytes"] for k, v in prof["kernels"].items() if kern in k]
     return (sum(vals), name) if vals else (None, f"{name} has no {kern} entry")
 
 
 def profiled_pipeline_traffic(workload, dtype, paths, recurrence):
-    """HBM bytes per step over all of the step's kernels, from the same committed profile (None when stale)."""
-    t, note = 0.0, None
-    for stage in ("fit", "lut", "sample", "velocity"):
-        v, note = profiled_traffic(stage, workload, dtype, paths, recurrence)
-        if v is None:
-            return None
-        t += v
-    return t
+    """HBM bytes per step over all of the step's kernels (every vap:: kernel the profiled step launched, once each),
+    from the same committed profile (None when stale)."""
+    prof, _ = committed_profile(workload, dtype, paths, recurrence)
+    if prof is None:
+        return None
+    vals = [v["hbm_bytes"] for k, v in prof["kernels"].items() if "vap::" in k]
+    return sum(vals) if vals else None
 
 
 def launch_ranks(n):

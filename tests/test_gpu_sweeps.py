@@ -240,21 +240,24 @@ def test_full_size_batch_is_deterministic_and_order_independent(torch_mod, dtype
 
 
 def test_tolerance_sweep(torch_mod):
-    """BASELINE config 5, "fp64 vs fp32 tolerance sweep" (bench.py --tolerance-sweep), as a gate: 16 384 config-5-shaped
-    paths (8 waypoints x 1024 samples) in the two fp32-row modes against this library's fp64 run of the same batch.
-    Default mode: no path above 1e-5.  All-fp32 recurrence: some are — the sweep keeps biting."""
+    """BASELINE config 5, "fp64 vs fp32 tolerance sweep" (bench.py --tolerance-sweep), as a gate, at the per-GPU share of
+    the full config: 131 072 config-5-shaped paths (8 waypoints x 1024 samples) in the two fp32-row modes against this
+    library's fp64 run of the same batch.  Default mode: no path above 1e-5, the worst far inside (the size matters: with
+    the heading differences rounded to fp32 — tried in round 3 — 16 384 paths showed a worst of 4e-7 and this batch one of
+    9.6e-6: the recurrence's amplification has a long tail).  All-fp32 recurrence: some paths are outside — the sweep
+    keeps biting."""
     import os
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
     from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
     torch = torch_mod
-    B, W, S = 16384, 8, 1024
+    B, W, S = 131072, 8, 1024
     wp = torch.tensor(make_waypoints(B, W, 5, dtype=np.float32), dtype=torch.float32, device="cuda:0")
     sweep = bench.tolerance_sweep(0, wp, list(DEFAULT_CONSTRAINTS), S)
     default = sweep["modes"]["f32 rows, f64 recurrence (default)"]
     f32rec = sweep["modes"]["f32 rows, f32 recurrence"]
     print(sweep)
     assert default["paths"] == B and f32rec["paths"] == B
-    assert default["paths_above_1e-5"] == 0 and default["worst"] <= 2e-6
+    assert default["paths_above_1e-5"] == 0 and default["worst"] <= 5e-7
     assert f32rec["paths_above_1e-5"] > 0 and f32rec["worst"] > 1e-5

@@ -62,18 +62,8 @@ constexpr int kLanesMinPaths = 2048;   // AUTO: batches from here on take the la
 // K5 dispatch.  auto: register-resident relaxation whenever the row fits, else the sequential sweep.
 // f64 = arithmetic type of the recurrence = type of the curv / dth rows; io64 = type of the caller's rows (vcap,
 // acc, vel).  f64 && !io64: the fp64 recurrence behind fp32 outputs (VAP_F32 with VAP_RECURRENCE_F64).
-// Does a plain pass (no per-sample limits) of the fp64 recurrence over B paths go to the lane-per-path kernel?
-// (vap_profile_batch asks before it samples: that kernel reads the heading differences as the fp32 row.)
-bool velocity_takes_lanes(const vap_ctx *ctx, int B)
-{
-    const int m = ctx->velocity_kernel;
-    return (m == VAP_VELOCITY_AUTO && B >= kLanesMinPaths) || (m >= VAP_VELOCITY_LANES && m <= VAP_VELOCITY_LANES_64);
-}
-
-// dth_f32: `dth` is the fp32 row although the recurrence is fp64 behind fp32 rows (lane-per-path kernel, plain paths)
 int run_velocity(vap_ctx *ctx, bool f64, bool io64, int B, int S, const double cc[6], double sv, double ev, const double *meta,
-                 const void *curv, const void *dth, const void *vcap, const vap::AccRowsV &acc, void *vel, uint32_t *flags,
-                 bool dth_f32 = false)
+                 const void *curv, const void *dth, const void *vcap, const vap::AccRowsV &acc, void *vel, uint32_t *flags)
 {
     int mode = ctx->velocity_kernel;
     ctx->vhi_for = nullptr;
@@ -98,11 +88,10 @@ int run_velocity(vap_ctx *ctx, bool f64, bool io64, int B, int S, const double c
             ufwd = ctx->ufwd.ptr;
         }
         const int group = mode == VAP_VELOCITY_LANES ? 0 : (mode == VAP_VELOCITY_LANES_16 ? 16 : (mode == VAP_VELOCITY_LANES_32 ? 32 : 64));
-        HIP_TRY(vap::launch_velocity_lanes(ctx->stream, io64, B, S, cc, sv, ev, meta, curv, dth, vcap, acc, vel, ufwd, group, dth_f32));
+        HIP_TRY(vap::launch_velocity_lanes(ctx->stream, io64, B, S, cc, sv, ev, meta, curv, dth, vcap, acc, vel, ufwd, group));
         if (want_hi) keep_hi(ufwd);
         return VAP_OK;
     }
-    if (dth_f32) return vap_fail(VAP_ERR_UNSUPPORTED, "fp32 heading differences handed to a kernel that reads them in fp64");
     if (mode == VAP_VELOCITY_AUTO)
         mode = (vcap && S > relax_limit) ? VAP_VELOCITY_SEQ_FAST : VAP_VELOCITY_RELAX;
     const int forced = mode;
@@ -368,7 +357,6 @@ int vap_sample(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd, const
     ctx->grid_S = S;
     ctx->rows_valid = hi;
     ctx->rows_hi = hi;
-    ctx->rows_dth32 = false;
     ctx->rows_dt = dt;
     ctx->route_NS = 0;
     return VAP_OK;
@@ -392,13 +380,6 @@ int vap_velocity_pass_limits(vap_ctx *ctx, vap_dtype dt, int B, int S, const vap
                             "the last sampling call left %s %d x %d, dtype %d)", B, S, (int)dt, ctx->rows_valid ? "rows of" : "no rows;",
                             ctx->grid_B, ctx->grid_S, ctx->rows_dt);
         if (ctx->rows_hi) {   // VAP_F32 with the fp64 recurrence: both rows come from the context, in fp64
-            if (ctx->rows_dth32) {
-                // the fused call left |dtheta| as the fp32 row (the lane-per-path kernel reads that): the kernels with
-                // per-sample limits take the fp64 row of the same values
-                VAP_TRY(ctx->ensure(ctx->dth64, (size_t)B * S * sizeof(double)));
-                HIP_TRY(vap::launch_widen(ctx->stream, (size_t)B * S, (const float *)ctx->dth.ptr, (double *)ctx->dth64.ptr));
-                ctx->rows_dth32 = false;
-            }
             d_curvature = ctx->k64.ptr;
             d_dtheta = ctx->dth64.ptr;
             r64 = true;
@@ -445,13 +426,9 @@ int vap_profile_batch(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd
     VAP_TRY(ctx->ensure(ctx->runs, (size_t)B * vap::kGridRunBlockDoubles * sizeof(double)));
     // VAP_F32 with the fp64 recurrence (the default): the velocity pass reads fp64 curvature / |dtheta| rows
     const bool hi = !f64 && ctx->f32_recurrence == VAP_RECURRENCE_F64;
-    // ... and |dtheta| is kept as its fp32 value there (k_sample): the lane-per-path kernel reads it as the fp32 row
-    // (4 B/pt per sweep instead of 8), the other kernels as an fp64 row of the same values
-    const bool dth32 = hi && velocity_takes_lanes(ctx, B) && ctx->fused_sampling != 1;
     if (hi) {
         VAP_TRY(ctx->ensure(ctx->k64, n_pts * sizeof(double)));
-        if (dth32) VAP_TRY(ctx->ensure(ctx->dth, n_pts * sizeof(float)));
-        else VAP_TRY(ctx->ensure(ctx->dth64, n_pts * sizeof(double)));
+        VAP_TRY(ctx->ensure(ctx->dth64, n_pts * sizeof(double)));
     } else {
         VAP_TRY(ctx->ensure(ctx->dth, n_pts * esz(dt)));
     }
@@ -515,12 +492,12 @@ int vap_profile_batch(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd
     } else {
         HIP_TRY(vap::launch_sample(ctx->stream, f64, B, W, S, (const double *)ctx->power.ptr, (const double *)ctx->lut.ptr, nullptr,
                                    meta, (const double *)ctx->aux.ptr, (const double *)ctx->runs.ptr, d_x, d_y, d_heading,
-                                   curv, (hi && !dth32) ? nullptr : ctx->dth.ptr, hi ? (double *)ctx->k64.ptr : nullptr,
-                                   (hi && !dth32) ? (double *)ctx->dth64.ptr : nullptr));
+                                   curv, hi ? nullptr : ctx->dth.ptr, hi ? (double *)ctx->k64.ptr : nullptr,
+                                   hi ? (double *)ctx->dth64.ptr : nullptr));
         tm.mark(VAP_T_SAMPLE);
         if (hi)
-            VAP_TRY(run_velocity(ctx, true, false, B, S, cc, start_vel, end_vel, meta, ctx->k64.ptr,
-                                 dth32 ? ctx->dth.ptr : ctx->dth64.ptr, nullptr, vap::AccRowsV(), d_velocity, flags, dth32));
+            VAP_TRY(run_velocity(ctx, true, false, B, S, cc, start_vel, end_vel, meta, ctx->k64.ptr, ctx->dth64.ptr, nullptr,
+                                 vap::AccRowsV(), d_velocity, flags));
         else
             VAP_TRY(run_velocity(ctx, f64, f64, B, S, cc, start_vel, end_vel, meta, curv, ctx->dth.ptr, nullptr, vap::AccRowsV(),
                                  d_velocity, flags));
@@ -533,7 +510,6 @@ int vap_profile_batch(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd
     ctx->grid_S = S;
     ctx->rows_valid = true;
     ctx->rows_hi = hi;
-    ctx->rows_dth32 = dth32;
     ctx->rows_dt = dt;
     ctx->route_NS = 0;
     return VAP_OK;
@@ -636,7 +612,6 @@ int vap_profile_routes(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double d
     ctx->grid_S = S;
     ctx->rows_valid = true;
     ctx->rows_hi = hi;
-    ctx->rows_dth32 = false;
     ctx->rows_dt = dt;
     ctx->route_NS = NS;
     return VAP_OK;

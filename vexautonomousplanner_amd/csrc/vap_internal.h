@@ -54,8 +54,7 @@ struct vap_ctx {
     // rows the last sampling call left for a velocity pass with d_dtheta == NULL:
     //   rows_hi:  k64 / dth64 hold the fp64 curvature and |dtheta| rows of a VAP_F32 call (fused or staged)
     //   !rows_hi: dth holds the |dtheta| rows in rows_dt (the fused call only; curvature comes from the caller)
-    //   rows_dth32 (with rows_hi): |dtheta| is in `dth` as fp32 values instead (the fused call, lane-per-path kernel)
-    bool rows_valid = false, rows_hi = false, rows_dth32 = false;
+    bool rows_valid = false, rows_hi = false;
     int rows_dt = 0;
 
     int ensure(VapBuffer &b, size_t bytes)

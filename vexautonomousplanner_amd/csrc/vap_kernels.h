@@ -90,11 +90,10 @@ hipError_t launch_velocity_long(hipStream_t st, bool f64, bool io64, int B, int 
                                 void *ufwd, void *state, int *counters, void *vhi = nullptr);
 // K5w (vap_velocity_lanes.hip), fp64 recurrence only: lane per path, `group` paths per workgroup (0 = by batch size).
 // ufwd: [B][S] doubles of scratch for the forward sweep's squared velocities (unused when io64: the rows are used in place)
-// dth_f32: `dth` holds floats (fp32 rows, plain paths: the side row as the sampling kernel's fp32 values)
 int velocity_lanes_group(int B);
 hipError_t launch_velocity_lanes(hipStream_t st, bool io64, int B, int S, const double c[6], double sv, double ev,
                                  const double *meta, const void *curv, const void *dth, const void *vcap, const AccRowsV &acc,
-                                 void *vel, void *ufwd, int group = 0, bool dth_f32 = false);
+                                 void *vel, void *ufwd, int group = 0);
 // K3+K4 fused into K5w's forward producers (vap_sample_lane.h): the default mode's step for batches of plain paths
 hipError_t launch_sample_velocity_fused(hipStream_t st, int B, int W, int S, const double c[6], double sv, double ev,
                                         const double *meta, const double *power, const double *lut, const double *aux,
@@ -132,7 +131,6 @@ hipError_t launch_time_waits(hipStream_t st, int B, int W, int M, int cap_in, in
                              double max_vel = 0, double max_acc = 0, double track_width = 0);
 hipError_t launch_eval(hipStream_t st, int W, const double *seg, double t_max, int order, int n, const double *t,
                        double *out);
-hipError_t launch_widen(hipStream_t st, size_t n, const float *in, double *out);   // out[i] = (double)in[i]
 hipError_t launch_basis(hipStream_t st, int order, int n, const double *t, double *out);   // out [n][6]
 hipError_t launch_lookup(hipStream_t st, int W, const double *seg, double t_max, const double *lut, int what,
                          int n, const double *in, double *out);

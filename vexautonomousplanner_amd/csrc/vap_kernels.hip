@@ -500,9 +500,8 @@ __global__ void k_lut_slopes(int B, const double *__restrict__ lut, const double
 // Arithmetic: parameter/index path, derivative evaluation and curvature in fp64 (DESIGN.md
 // §Numerics); no fp64 division on the per-sample path.
 // ------------------------------------------------------------------------------------------------
-// HI (fp32 outputs only): also write the curvature row in fp64 (ok64) for the fp64 velocity recurrence behind fp32
-// outputs.  |dtheta| is formed in fp64 there and kept as its fp32 value: it leaves as the fp32 row (odth), as an fp64
-// row holding the same values (odth64), or both — either may be NULL.
+// HI (fp32 outputs only): also write the curvature and |dtheta| rows in fp64 (ok64, odth64) for the fp64
+// velocity recurrence behind fp32 outputs; the fp32 |dtheta| row is then optional (odth may be NULL).
 template <typename OT, bool COEF_LDS, bool HI>
 __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int tile, int tiles_per_block,
                                                            const double *__restrict__ power,
@@ -628,7 +627,7 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int 
             }
         };
         auto store_hi = [&](double *dst, const double v[kSPT]) {   // rows of S doubles: 16-byte aligned when S is even
-            if (!dst || !writer) return;
+            if (!writer) return;
             if ((S & 1) == 0 && kbase + kSPT <= S) {
                 *reinterpret_cast<double2 *>(dst + row + kbase) = make_double2(v[0], v[1]);
                 *reinterpret_cast<double2 *>(dst + row + kbase + 2) = make_double2(v[2], v[3]);
@@ -747,12 +746,8 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int 
                     if constexpr (sizeof(OT) == 8) {
                         vd[i] = fabs(nth - vh[i]);
                     } else if constexpr (HI) {
-                        // formed in fp64 (the fp32 headings' difference would carry their rounding: relative errors of
-                        // 1e-3 on a dense grid), kept as the fp32 value: 6e-8 relative on 1/dtheta moves a velocity by
-                        // 5e-7 at worst (tests/test_gpu_sweeps.py) and the velocity kernel reads 4 bytes per sample
-                        // and sweep instead of 8.  The fp64 side row, where a kernel wants one, holds the same values.
-                        if (nj != jjv[i]) vd[i] = (OT)dtheta_f64(d1x[i], d1y[i], nx, ny, vh[i], nth);
-                        vd64[i] = (double)vd[i];
+                        if (nj != jjv[i]) vd64[i] = dtheta_f64(d1x[i], d1y[i], nx, ny, vh[i], nth);
+                        vd[i] = (OT)vd64[i];   // (only stored when the staged API asked for the fp32 row as well)
                     } else {
                         if (nj != jjv[i]) vd[i] = dtheta_f32(d1x[i], d1y[i], nx, ny, vh[i], nth);
                     }
@@ -1922,7 +1917,7 @@ hipError_t launch_sample(hipStream_t st, bool f64, int B, int W, int S, const do
                          const double *slopes, const double *meta, const double *aux, const double *runs, void *x,
                          void *y, void *h, void *k, void *dth, double *k64, double *dth64)
 {
-    const bool hi = !f64 && k64;      // (dth64 may be NULL: the fp32 row `dth` holds the same values)
+    const bool hi = !f64 && k64 && dth64;
     // one workgroup stages a path's tables once and walks tiles_per_block consecutive tiles; paths are
     // split over several workgroups only when the batch alone cannot fill the chip
     // a tile is kSampleTile samples (the last thread only feeds its neighbour's |dtheta|) unless the whole
@@ -2236,18 +2231,6 @@ hipError_t launch_eval(hipStream_t st, int W, const double *seg, double t_max, i
                        double *out)
 {
     hipLaunchKernelGGL(k_eval, dim3((n + 255) / 256), dim3(256), 0, st, W, seg, t_max, order, n, t, out);
-    return hipGetLastError();
-}
-
-__global__ void k_widen(size_t n, const float *__restrict__ in, double *__restrict__ out)
-{
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (double)in[i];
-}
-
-hipError_t launch_widen(hipStream_t st, size_t n, const float *in, double *out)
-{
-    hipLaunchKernelGGL(k_widen, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, in, out);
     return hipGetLastError();
 }
 

@@ -385,8 +385,8 @@ __global__ __launch_bounds__(kRouteThreads) void k_sample_routes(int W, int NS, 
             if constexpr (sizeof(OT) == 8) {
                 dth = fabs(nth - me.th);
             } else if constexpr (HI) {
-                if (nj != me.jj) dth = (OT)dtheta_f64(me.ex, me.ey, nx, ny, me.th, nth);
-                dth64 = (double)dth;      // (the fp32 value, as k_sample keeps it)
+                if (nj != me.jj) dth64 = dtheta_f64(me.ex, me.ey, nx, ny, me.th, nth);
+                dth = (OT)dth64;
             } else {
                 if (nj != me.jj) dth = dtheta_f32(me.ex, me.ey, nx, ny, me.th, nth);
             }

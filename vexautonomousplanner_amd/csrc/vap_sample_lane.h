@@ -164,7 +164,7 @@ __device__ __forceinline__ LaneSample lane_sample(const LanePath &p, int j, int 
     // |heading[j] - heading[j-1]| of the reference's raw atan2 values (row index j-1): zero when the two samples share a
     // table entry, and for the samples past the end
     double dth = 0.0;
-    if (j >= 1 && j <= N - 1 && pjj != jj) dth = (double)(float)dtheta_f64(pex, pey, ex, ey, pth, o.th);   // (the fp32 value, as k_sample keeps it)
+    if (j >= 1 && j <= N - 1 && pjj != jj) dth = dtheta_f64(pex, pey, ex, ey, pth, o.th);
     o.dth_prev = dth;
     o.kap_m1 = pk;
     o.kap_m2 = pk2;

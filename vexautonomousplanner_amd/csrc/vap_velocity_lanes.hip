@@ -102,16 +102,13 @@ struct SlotCtx {
     bool live;           // the batch exists for this producer and the path exists
 };
 
-// D: element type of the heading-difference row (double; float when the sampling kernel left the fp32-row mode's side row
-// as the fp32 values it holds anyway — 4 B/pt less to read in each sweep)
-template <typename IO, int P, bool VCAP, bool ACC, typename D = double>
+template <typename IO, int P, bool VCAP, bool ACC>
 struct Lanes {
     using G = LanesGeo<P>;
     static constexpr int TS = G::TS;
 
     int S;
-    const double *K;
-    const D *DT;
+    const double *K, *DT;
     const IO *VC;
     AccRows<IO> acc;
     IO *V;
@@ -137,7 +134,7 @@ struct Lanes {
         const size_t i1 = at(c, j - 1);
         in.k0 = K[i1];
         in.k1 = K[at(c, j - 2)];
-        in.dth = (double)DT[i1];
+        in.dth = DT[i1];
         if constexpr (ACC) in.acc = acc.fwd[i1];
         if constexpr (VCAP) in.vc = VC[at(c, j)];
     }
@@ -182,7 +179,7 @@ struct Lanes {
         const size_t i0 = at(c, j), i1 = at(c, j + 1);
         in.k0 = K[i1];
         in.k1 = K[at(c, j + 2)];
-        in.dth = (double)DT[i0];
+        in.dth = DT[i0];
         in.uf = UF[i0];
         if constexpr (ACC) in.acc = acc.bwd[i1];
     }
@@ -292,11 +289,11 @@ struct Lanes {
 //            tile #(it+1); the chain walks tile #(it-1) out of buffer (it-1)&1 into result buffer (it-1)&1; producers move
 //            tile #(it-2)'s results out of result buffer it&1.
 // (tile #n of the backward sweep is tile NT-1-n of the row.)
-template <typename IO, int P, bool VCAP, bool ACC, bool FUSED, typename D = double>
+template <typename IO, int P, bool VCAP, bool ACC, bool FUSED>
 __global__ __launch_bounds__(kLanesThreads, 2) void k_velocity_lanes(int B, int S, VelConsts<double> c, double start_u, double end_u,
                                                                      const double *__restrict__ meta,
                                                                      const double *__restrict__ curv,
-                                                                     const D *__restrict__ dtheta,
+                                                                     const double *__restrict__ dtheta,
                                                                      const IO *__restrict__ vcap, AccRows<IO> acc,
                                                                      IO *__restrict__ vel, double *__restrict__ ufwd,
                                                                      long long *__restrict__ stats, FusedArgs fz)
@@ -309,7 +306,6 @@ __global__ __launch_bounds__(kLanesThreads, 2) void k_velocity_lanes(int B, int 
     __shared__ PathConsts s_pc[P];
     __shared__ int s_nmax, s_pdup[P], s_tdup[2];
     __shared__ double s_win[FUSED ? kLanesProducers * kBatchesPerProducer * kLaneWindow : 1];   // table windows, one per (producer, batch)
-    static_assert(!FUSED || std::is_same<D, double>::value, "fused sampling writes its own fp64 side rows");
     if constexpr (FUSED) { curv = fz.k64; dtheta = fz.dth64; }
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     if (tid == 0) { s_nmax = 0; s_tdup[0] = 0; s_tdup[1] = 0; }
@@ -340,7 +336,7 @@ __global__ __launch_bounds__(kLanesThreads, 2) void k_velocity_lanes(int B, int 
     __syncthreads();
     const int NT = (s_nmax + TS - 1) / TS;
 
-    Lanes<IO, P, VCAP, ACC, D> L;
+    Lanes<IO, P, VCAP, ACC> L;
     L.S = S;
     L.K = curv; L.DT = dtheta; L.VC = vcap; L.acc = acc; L.V = vel;
     if constexpr (std::is_same<IO, double>::value) L.UF = reinterpret_cast<double *>(vel);   // fp64 rows: in place
@@ -600,7 +596,7 @@ __global__ __launch_bounds__(kLanesThreads, 2) void k_velocity_lanes(int B, int 
 template <typename IO, int P>
 hipError_t launch_lanes_p(hipStream_t st, int B, int S, const double c[6], double sv, double ev, const double *meta,
                           const double *curv, const double *dth, const void *vcap, const AccRowsV &accv, void *vel, double *ufwd,
-                          const FusedArgs *fused = nullptr, const float *dth32 = nullptr)
+                          const FusedArgs *fused = nullptr)
 {
     using G = LanesGeo<P>;
     VelConsts<double> vc;
@@ -646,21 +642,7 @@ hipError_t launch_lanes_p(hipStream_t st, int B, int S, const double c[6], doubl
     if (fused) { /* launched above */ }
     else if (acc.fwd) VAP_LANES_LAUNCH(true, true);      // (routes with max_acceleration rows always carry initial velocities too)
     else if (vcap) VAP_LANES_LAUNCH(true, false);
-    else if (dth32) {
-        if constexpr (std::is_same<IO, float>::value) {
-            auto kern = k_velocity_lanes<float, P, false, false, false, float>;
-            static bool attr_set32[kMaxDevices] = {};
-            if (!attr_set32[dev]) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                if (e != hipSuccess) return e;
-                attr_set32[dev] = true;
-            }
-            hipLaunchKernelGGL(kern, grid, block, lds, st, B, S, vc, sv * sv, ev * ev, meta, curv, dth32, (const float *)nullptr, acc,
-                               (float *)vel, ufwd, stats, FusedArgs());
-        } else {
-            return hipErrorInvalidValue;
-        }
-    } else VAP_LANES_LAUNCH(false, false);
+    else VAP_LANES_LAUNCH(false, false);
 #undef VAP_LANES_LAUNCH
     if (stats) {
         std::vector<long long> h((size_t)grid.x * 16);
@@ -690,16 +672,14 @@ int velocity_lanes_group(int B)
 
 hipError_t launch_velocity_lanes(hipStream_t st, bool io64, int B, int S, const double c[6], double sv, double ev,
                                  const double *meta, const void *curv, const void *dth, const void *vcap, const AccRowsV &acc,
-                                 void *vel, void *ufwd, int group, bool dth_f32)
+                                 void *vel, void *ufwd, int group)
 {
     if (acc.fwd && !vcap) return hipErrorInvalidValue;
-    if (dth_f32 && (io64 || vcap || acc.fwd)) return hipErrorInvalidValue;   // (plain paths behind fp32 rows only)
-    const float *d32 = dth_f32 ? (const float *)dth : nullptr;
     const int P = group > 0 ? group : velocity_lanes_group(B);
 #define VAP_LANES(IO_)                                                                                                          \
-    (P == 16 ? launch_lanes_p<IO_, 16>(st, B, S, c, sv, ev, meta, (const double *)curv, (const double *)dth, vcap, acc, vel, (double *)ufwd, nullptr, d32) \
-     : P == 32 ? launch_lanes_p<IO_, 32>(st, B, S, c, sv, ev, meta, (const double *)curv, (const double *)dth, vcap, acc, vel, (double *)ufwd, nullptr, d32) \
-               : launch_lanes_p<IO_, 64>(st, B, S, c, sv, ev, meta, (const double *)curv, (const double *)dth, vcap, acc, vel, (double *)ufwd, nullptr, d32))
+    (P == 16 ? launch_lanes_p<IO_, 16>(st, B, S, c, sv, ev, meta, (const double *)curv, (const double *)dth, vcap, acc, vel, (double *)ufwd) \
+     : P == 32 ? launch_lanes_p<IO_, 32>(st, B, S, c, sv, ev, meta, (const double *)curv, (const double *)dth, vcap, acc, vel, (double *)ufwd) \
+               : launch_lanes_p<IO_, 64>(st, B, S, c, sv, ev, meta, (const double *)curv, (const double *)dth, vcap, acc, vel, (double *)ufwd))
     if (io64) return VAP_LANES(double);
     return VAP_LANES(float);
 #undef VAP_LANES
