@@ -201,6 +201,9 @@ def main():
     ap.add_argument("--paths-per-gpu", type=int, default=None)
     ap.add_argument("--spinup-ms", type=float, default=80.0,
                     help="untimed device spin-up before the warm-up steps: run the step for this long so the clocks settle")
+    ap.add_argument("--in-flight", type=int, default=1,
+                    help="after the timed region (N = 1): also time the steps with this many batches in flight on as many "
+                         "HIP streams, reported as `pipelined` (1 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-mode", action="store_true",
                     help="skip the after-the-fact measurement of the other recurrence arithmetic (fp32 rows, N = 1)")
@@ -353,6 +356,32 @@ def main():
             other_mode["parity"] = parity_check(oout, wp, S, constraints, min(args.parity_paths, B), "f32")
         del ogen, oout
 
+    # after the timed region, N = 1, for the record — never `value`: the same K steps with TWO batches in flight (two
+    # contexts, two HIP streams, the steps taken in turn): the sampling kernel of one batch fills issue slots that the
+    # chain-bound velocity kernel of the other leaves idle.  A step of `value` is one batch, start to end.
+    pipelined = None
+    if world == 1 and args.in_flight > 1 and B * S * 40 * args.in_flight < 64e9:
+        n = args.in_flight
+        gens = [gen] + [BatchedTrajectoryGenerator(local_rank, args.dtype, recurrence=args.recurrence) for _ in range(n - 1)]
+        streams = [torch.cuda.Stream(dev) for _ in range(n)]
+        outs = [out] + [None] * (n - 1)
+
+        def turn(k):
+            for i in range(k):
+                q = i % n
+                with torch.cuda.stream(streams[q]):
+                    outs[q] = gens[q].profile(wp, constraints=constraints, samples=S, out=outs[q])
+        torch.cuda.synchronize(dev)
+        turn(2 * n + args.warmup)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        turn(args.steps)
+        torch.cuda.synchronize(dev)
+        pms = (time.perf_counter() - t1) / args.steps * 1e3
+        pipelined = {"batches_in_flight": n, "ms_per_step": pms, "value": B * S / (pms * 1e-3), "steps": args.steps}
+        out = outs[0]
+        del gens, outs, streams
+
     # BASELINE config 5, "fp64 vs fp32 tolerance sweep": this rank's whole batch in every mode, compared on the device
     sweep = None
     if args.tolerance_sweep:
@@ -413,6 +442,8 @@ def main():
             line["parity"] = parity
         if other_mode is not None:
             line["other_mode"] = other_mode
+        if pipelined is not None:
+            line["pipelined"] = pipelined
         if sweep is not None:
             line["tolerance_sweep"] = sweep
         if time_domain is not None:

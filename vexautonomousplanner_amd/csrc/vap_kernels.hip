@@ -190,15 +190,16 @@ __global__ void k_grid(int B, int W, int S, double dd_in, double *__restrict__ m
 // ------------------------------------------------------------------------------------------------
 // Routes cut into several splines (rt.sptab set): grid = (routes, spline slots); the workgroup builds the partial
 // (un-offset) table of one spline, SM:436-454, and k_route_offsets (vap_routes_batch.hip) does the rest.
+constexpr int kLutPad = (kLutN + 31) / 32 * 32;
 template <bool SEG_LDS>
 __device__ __forceinline__ void lut_path(int W, const double *__restrict__ segments, double *__restrict__ lut,
                                          double *__restrict__ slopes, double *__restrict__ meta, uint32_t *__restrict__ flags,
-                                         const GridArgs &grid, const RouteTables &rt, long long *__restrict__ stats, double *s_seg)
+                                         const GridArgs &grid, const RouteTables &rt, long long *__restrict__ stats, double *s_seg,
+                                         double *cum)
 {
     const long long tl0 = stats ? __builtin_amdgcn_s_memtime() : 0;
-    constexpr int kPad = (kLutN + 31) / 32 * 32;   // the sequential sum walks whole groups of 32
-    // one array: magnitudes, then (in place) trapezoid increments, then cumulative distances
-    __shared__ __attribute__((aligned(16))) double cum[kPad];
+    constexpr int kPad = kLutPad;   // the sequential sum walks whole groups of 32
+    // cum (LDS, kLutPad doubles, 16-byte aligned): magnitudes, then (in place) trapezoid increments, then cumulative distances
     double *mag = cum;
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     int G = W - 1;
@@ -323,22 +324,28 @@ __global__ __launch_bounds__(256) void k_lut(int W, const double *__restrict__ s
                                              GridArgs grid, RouteTables rt, long long *__restrict__ stats)
 {
     extern __shared__ __attribute__((aligned(16))) double s_seg[];   // G * 12 when SEG_LDS
-    lut_path<SEG_LDS>(W, segments, lut, slopes, meta, flags, grid, rt, stats, s_seg);
+    __shared__ __attribute__((aligned(16))) double cum[kLutPad];
+    lut_path<SEG_LDS>(W, segments, lut, slopes, meta, flags, grid, rt, stats, s_seg, cum);
 }
 
 // K1 + K2 in one launch for the fused call on plain paths (vap_profile_batch): the workgroup that fits a path builds its
 // table right away — one launch and its ramp less per step (24 + 57 us as two kernels at config 3).  The same two
-// bodies: same segments, same table.
+// bodies: same segments, same table.  Sized so that a CU holds sixteen of these workgroups at once — config 3's 4096
+// paths are then ONE round over the 256 CUs, not a full one and a third: at most 64 registers, and one LDS array for both
+// phases (the fit's arrays, then the table: max(1024, 7 W) doubles), the segment rows read back through L1.
 template <typename IT>
-__global__ __launch_bounds__(128) void k_fit_lut(int W, const IT *__restrict__ waypoints, double *__restrict__ segments,
-                                                 double *__restrict__ power, double *__restrict__ lut,
-                                                 double *__restrict__ meta, uint32_t *__restrict__ flags, GridArgs grid)
+__global__ __launch_bounds__(128, 8) void k_fit_lut(int W, const IT *__restrict__ waypoints, double *__restrict__ segments,
+                                                    double *__restrict__ power, double *__restrict__ lut,
+                                                    double *__restrict__ meta, uint32_t *__restrict__ flags, GridArgs grid,
+                                                    long long *__restrict__ stats)
 {
-    extern __shared__ __attribute__((aligned(16))) double sh[];     // max(7*W, 12*(W-1)) doubles: the fit's arrays, then the segments
+    extern __shared__ __attribute__((aligned(16))) double sh[];     // max(kLutPad, 7 * W) doubles
+    const long long t0 = stats ? __builtin_amdgcn_s_memtime() : 0;
     fit_path<IT>(blockIdx.x, W, waypoints, nullptr, nullptr, FitExtras(), segments, power, nullptr, meta, flags, sh);
     __threadfence_block();      // the segments and meta[0] this workgroup wrote, read back below
     __syncthreads();
-    lut_path<true>(W, segments, lut, nullptr, meta, flags, grid, RouteTables(), nullptr, sh);
+    if (stats && threadIdx.x == 0) stats[(size_t)blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime() - t0;
+    lut_path<false>(W, segments, lut, nullptr, meta, flags, grid, RouteTables(), stats, nullptr, sh);
 }
 
 // K2 for very many short paths (config 5: 131 072 paths x 8 waypoints): one workgroup builds the tables of 64 paths.
@@ -1857,11 +1864,26 @@ bool fit_lut_fusable(int B, int W) { return W - 1 <= 512 && !(B >= kLutGroupMinP
 hipError_t launch_fit_lut(hipStream_t st, bool f64, int B, int W, const void *wp, double *seg, double *pw, double *lut,
                           double *meta, uint32_t *flags, GridArgs grid)
 {
-    const size_t n = (size_t)(7 * W > 12 * (W - 1) ? 7 * W : 12 * (W - 1));
+    const size_t n = (size_t)(7 * W > kLutPad ? 7 * W : kLutPad);
+    // developer knob: VAP_LUT_STATS=1 prints in-kernel cycle shares (synchronises!)
+    static const bool want_stats = getenv("VAP_LUT_STATS") != nullptr;
+    long long *stats = nullptr;
+    if (want_stats) (void)hipMalloc(&stats, (size_t)B * 4 * sizeof(long long));
     if (f64)
-        hipLaunchKernelGGL(k_fit_lut<double>, dim3(B), dim3(128), sizeof(double) * n, st, W, (const double *)wp, seg, pw, lut, meta, flags, grid);
+        hipLaunchKernelGGL(k_fit_lut<double>, dim3(B), dim3(128), sizeof(double) * n, st, W, (const double *)wp, seg, pw, lut, meta, flags, grid, stats);
     else
-        hipLaunchKernelGGL(k_fit_lut<float>, dim3(B), dim3(128), sizeof(double) * n, st, W, (const float *)wp, seg, pw, lut, meta, flags, grid);
+        hipLaunchKernelGGL(k_fit_lut<float>, dim3(B), dim3(128), sizeof(double) * n, st, W, (const float *)wp, seg, pw, lut, meta, flags, grid, stats);
+    if (stats) {
+        std::vector<long long> h((size_t)B * 4);
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(h.data(), stats, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+        (void)hipFree(stats);
+        double sum[4] = {0, 0, 0, 0};
+        for (int b = 0; b < B; b++)
+            for (int k = 0; k < 4; k++) sum[k] += (double)h[(size_t)b * 4 + k];
+        fprintf(stderr, "[fit+lut] mean ticks per workgroup: fit %.0f  magnitudes %.0f  increments+sum %.0f  store %.0f\n", sum[3] / B,
+                sum[0] / B, sum[1] / B, sum[2] / B);
+    }
     return hipGetLastError();
 }
 
