@@ -68,8 +68,9 @@ int run_velocity(vap_ctx *ctx, bool f64, bool io64, int B, int S, const double c
     int mode = ctx->velocity_kernel;
     ctx->vhi_for = nullptr;
     const bool want_hi = f64 && !io64;   // fp32 rows behind the fp64 recurrence: the velocities stay on the context in fp64
-    auto keep_hi = [&](const void *rows) {
+    auto keep_hi = [&](const void *rows, bool is_res = false) {
         ctx->vhi_ptr = rows;
+        ctx->vhi_is_res = is_res;
         ctx->vhi_for = vel;
         ctx->vhi_B = B;
         ctx->vhi_S = S;
@@ -83,13 +84,16 @@ int run_velocity(vap_ctx *ctx, bool f64, bool io64, int B, int S, const double c
     if (mode >= VAP_VELOCITY_LANES && mode <= VAP_VELOCITY_LANES_64) {
         if (!f64) return vap_fail(VAP_ERR_UNSUPPORTED, "the lane-per-path velocity kernel runs the fp64 recurrence only");
         void *ufwd = nullptr;
+        float *vres = nullptr;
         if (!io64) {
             VAP_TRY(ctx->ensure(ctx->ufwd, (size_t)B * S * 8));
+            VAP_TRY(ctx->ensure(ctx->vhi, (size_t)B * S * sizeof(float)));
             ufwd = ctx->ufwd.ptr;
+            vres = (float *)ctx->vhi.ptr;
         }
         const int group = mode == VAP_VELOCITY_LANES ? 0 : (mode == VAP_VELOCITY_LANES_16 ? 16 : (mode == VAP_VELOCITY_LANES_32 ? 32 : 64));
-        HIP_TRY(vap::launch_velocity_lanes(ctx->stream, io64, B, S, cc, sv, ev, meta, curv, dth, vcap, acc, vel, ufwd, group));
-        if (want_hi) keep_hi(ufwd);
+        HIP_TRY(vap::launch_velocity_lanes(ctx->stream, io64, B, S, cc, sv, ev, meta, curv, dth, vcap, acc, vel, ufwd, group, vres));
+        if (want_hi) keep_hi(vres, true);
         return VAP_OK;
     }
     if (mode == VAP_VELOCITY_AUTO)
@@ -153,10 +157,15 @@ int run_velocity(vap_ctx *ctx, bool f64, bool io64, int B, int S, const double c
 // fp64 recurrence in this context — the fp64 velocities that pass left behind (MPG:566-584 integrates positions
 // from the row; an fp32 row moves a position by ~1e-7 relative, now and then across a boundary of the reference's
 // step lookup, SM:550-580).
-const void *time_domain_velocity(vap_ctx *ctx, vap_dtype dt, int B, int S, const void *d_velocity, bool &is64)
+const void *time_domain_velocity(vap_ctx *ctx, vap_dtype dt, int B, int S, const void *d_velocity, bool &is64, const float *&vres)
 {
     is64 = dt == VAP_F64;
+    vres = nullptr;
     if (dt == VAP_F32 && ctx->vhi_for == d_velocity && ctx->vhi_ptr && ctx->vhi_B == B && ctx->vhi_S == S) {
+        if (ctx->vhi_is_res) {          // the fp32 row plus what it lost
+            vres = (const float *)ctx->vhi_ptr;
+            return d_velocity;
+        }
         is64 = true;
         return ctx->vhi_ptr;
     }
@@ -479,13 +488,15 @@ int vap_profile_batch(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd
     if (fused) {
         tm.mark(VAP_T_SAMPLE);
         VAP_TRY(ctx->ensure(ctx->ufwd, n_pts * sizeof(double)));
+        VAP_TRY(ctx->ensure(ctx->vhi, n_pts * sizeof(float)));
         ctx->vhi_for = nullptr;
         HIP_TRY(vap::launch_sample_velocity_fused(ctx->stream, B, W, S, cc, start_vel, end_vel, meta, (const double *)ctx->power.ptr,
                                                   (const double *)ctx->lut.ptr, (const double *)ctx->aux.ptr,
                                                   (const double *)ctx->runs.ptr, (float *)d_x, (float *)d_y, (float *)d_heading,
                                                   (float *)d_curvature, (double *)ctx->k64.ptr, (double *)ctx->dth64.ptr,
-                                                  (float *)d_velocity, (double *)ctx->ufwd.ptr));
-        ctx->vhi_ptr = ctx->ufwd.ptr;
+                                                  (float *)d_velocity, (double *)ctx->ufwd.ptr, (float *)ctx->vhi.ptr));
+        ctx->vhi_ptr = ctx->vhi.ptr;
+        ctx->vhi_is_res = true;
         ctx->vhi_for = d_velocity;
         ctx->vhi_B = B;
         ctx->vhi_S = S;
@@ -695,9 +706,11 @@ int vap_time_profile(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, const doub
         d_lut = (const double *)ctx->lut.ptr;
     }
     bool v64;
-    const void *vrow = time_domain_velocity(ctx, dt, B, S, d_velocity, v64);
+    const float *vres;
+    const void *vrow = time_domain_velocity(ctx, dt, B, S, d_velocity, v64, vres);
     HIP_TRY(vap::launch_time_profile(ctx->stream, v64, B, W, S, d_segments, d_lut, d_meta, vrow, c->max_acc,
-                                     c->max_dec, time_step, capacity_rows, d_rows, d_counts, d_nodes_map, d_flags));
+                                     c->max_dec, time_step, capacity_rows, d_rows, d_counts, d_nodes_map, d_flags, vap::RouteTables(),
+                                     nullptr, vres));
     return VAP_OK;
 }
 
@@ -749,10 +762,11 @@ int vap_time_profile_routes(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, con
         rt.NS = ctx->route_NS;
     }
     bool v64;
-    const void *vrow = time_domain_velocity(ctx, dt, B, S, d_velocity, v64);
+    const float *vres;
+    const void *vrow = time_domain_velocity(ctx, dt, B, S, d_velocity, v64, vres);
     HIP_TRY(vap::launch_time_profile(ctx->stream, v64, B, W, S, (const double *)ctx->seg.ptr, (const double *)ctx->lut.ptr,
                                      d_meta, vrow, c->max_acc, c->max_dec, time_step, capacity_rows, d_rows, d_counts,
-                                     d_nodes_map, d_flags, rt, d_node_reverse));
+                                     d_nodes_map, d_flags, rt, d_node_reverse, vres));
     return VAP_OK;
 }
 

@@ -90,15 +90,16 @@ hipError_t launch_velocity_long(hipStream_t st, bool f64, bool io64, int B, int 
                                 void *ufwd, void *state, int *counters, void *vhi = nullptr);
 // K5w (vap_velocity_lanes.hip), fp64 recurrence only: lane per path, `group` paths per workgroup (0 = by batch size).
 // ufwd: [B][S] doubles of scratch for the forward sweep's squared velocities (unused when io64: the rows are used in place)
+// vres (fp32 rows): [B][S] floats, v64 - (double)(float)v64 of every velocity written (what the time domain adds back)
 int velocity_lanes_group(int B);
 hipError_t launch_velocity_lanes(hipStream_t st, bool io64, int B, int S, const double c[6], double sv, double ev,
                                  const double *meta, const void *curv, const void *dth, const void *vcap, const AccRowsV &acc,
-                                 void *vel, void *ufwd, int group = 0);
+                                 void *vel, void *ufwd, int group = 0, float *vres = nullptr);
 // K3+K4 fused into K5w's forward producers (vap_sample_lane.h): the default mode's step for batches of plain paths
 hipError_t launch_sample_velocity_fused(hipStream_t st, int B, int W, int S, const double c[6], double sv, double ev,
                                         const double *meta, const double *power, const double *lut, const double *aux,
                                         const double *runs, float *ox, float *oy, float *oh, float *ok, double *k64, double *dth64,
-                                        float *vel, double *ufwd);
+                                        float *vel, double *ufwd, float *vres);
 // fp32, one wave per path, one launch per window of 2560 samples and direction (no host synchronisation)
 size_t velocity_windows_state_bytes(int B, int S);
 hipError_t launch_velocity_windows(hipStream_t st, int B, int S, const double c[6], double sv, double ev,
@@ -108,7 +109,7 @@ hipError_t launch_power(hipStream_t st, int n_seg, const double *seg, double *pw
 hipError_t launch_time_profile(hipStream_t st, bool f64, int B, int W, int S, const double *segments, const double *lut,
                                const double *meta, const void *vel, double max_acc, double max_dec, double dt, int cap,
                                double *rows, int *counts, int *nodes_map, uint32_t *flags, RouteTables rt = RouteTables(),
-                               const int *node_reverse = nullptr);
+                               const int *node_reverse = nullptr, const float *vres = nullptr);   // vres: fp32 rows only, see k_time_integrate
 // vap_limits.hip: sample of every event (node / action point), then the per-sample limit rows
 struct LimitInputs {
     const double *node_mv = nullptr, *node_ma = nullptr;   // [B][W] per-node max_velocity / max_acceleration (<= 0: none)

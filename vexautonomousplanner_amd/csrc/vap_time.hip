@@ -30,9 +30,10 @@ constexpr int kRowWidth = 8;   // time, position, velocity, acceleration, headin
 // (4096 paths, ~1280 steps each): this one 1.6 ms (2.5 ms with the loops); eight lanes per path with a
 // prefetched LDS ring of the row 2.4 ms against 2.5 (before the loops went: the arithmetic hid the gain); one
 // wavefront per path with an LDS window 4.7 ms; per-lane LDS windows refilled wave-wide 6.9 ms.
-template <typename R>
+template <typename R, bool RES>
 __global__ __launch_bounds__(64) void k_time_integrate(int B, int S, const double *__restrict__ meta,
-                                                       const R *__restrict__ vel, double max_acc, double max_dec,
+                                                       const R *__restrict__ vel, const float *__restrict__ vres,
+                                                       double max_acc, double max_dec,
                                                        double dt, int cap, double *__restrict__ rows,
                                                        int *__restrict__ counts, uint32_t *__restrict__ flags)
 {
@@ -42,8 +43,15 @@ __global__ __launch_bounds__(64) void k_time_integrate(int B, int S, const doubl
     const double total = m[1], dd = m[2], inv_dd = 1.0 / dd;
     const int N = (int)m[3];
     const R *v = vel + (size_t)b * S;
+    // vres (fp32 rows only, optional): what the fp32 row lost of the velocity kernel's fp64 value, v64 - (double)(float)v64
+    // as an fp32 number — the sum is v64 to 2^-48 (the lane-per-path kernel leaves the row this way: 4 B/pt, not 8)
+    const float *vr = RES ? vres + (size_t)b * S : nullptr;
+    auto at = [&](int i) {
+        if constexpr (RES) return (double)v[i] + (double)vr[i];
+        else return (double)v[i];
+    };
     double *out = rows + (size_t)b * cap * kRowWidth;
-    double current_time = 0, current_pos = 0, current_vel = N > 0 ? (double)v[0] : 0.0;   // MPG:413-418
+    double current_time = 0, current_pos = 0, current_vel = N > 0 ? at(0) : 0.0;   // MPG:413-418
     int T = 0;
     bool full = false;
     // `total > 0` also keeps degenerate paths (NaN / zero length) out of the loop
@@ -53,8 +61,8 @@ __global__ __launch_bounds__(64) void k_time_integrate(int B, int S, const doubl
         // samples are fetched together: one memory round trip per step instead of two.
         const double ahead = current_pos + dd;
         const int i0 = grid_index(current_pos, dd, inv_dd, N), i1 = grid_index_from(ahead, dd, inv_dd, N, i0 + 1);
-        const double a0 = (double)v[clamp_index(i0, N)], a1 = (double)v[clamp_index(i0 + 1, N)];
-        const double c0 = (double)v[clamp_index(i1, N)], c1 = (double)v[clamp_index(i1 + 1, N)];
+        const double a0 = at(clamp_index(i0, N)), a1 = at(clamp_index(i0 + 1, N));
+        const double c0 = at(clamp_index(i1, N)), c1 = at(clamp_index(i1 + 1, N));
         double target_vel = lerp_at(current_pos, dd, i0, N, a0, a1);
         const double next_target_vel = lerp_at(ahead, dd, i1, N, c0, c1);
         target_vel = (target_vel + next_target_vel) / 2;
@@ -202,15 +210,19 @@ __global__ __launch_bounds__(256) void k_time_geometry(int W, int cap, const dou
 
 hipError_t launch_time_profile(hipStream_t st, bool f64, int B, int W, int S, const double *segments, const double *lut,
                                const double *meta, const void *vel, double max_acc, double max_dec, double dt, int cap,
-                               double *rows, int *counts, int *nodes_map, uint32_t *flags, RouteTables rt, const int *node_reverse)
+                               double *rows, int *counts, int *nodes_map, uint32_t *flags, RouteTables rt, const int *node_reverse,
+                               const float *vres)
 {
     const int nblk = (B + 63) / 64;
     if (f64)
-        hipLaunchKernelGGL(k_time_integrate<double>, dim3(nblk), dim3(64), 0, st, B, S, meta, (const double *)vel, max_acc,
+        hipLaunchKernelGGL((k_time_integrate<double, false>), dim3(nblk), dim3(64), 0, st, B, S, meta, (const double *)vel,
+                           (const float *)nullptr, max_acc, max_dec, dt, cap, rows, counts, flags);
+    else if (vres)
+        hipLaunchKernelGGL((k_time_integrate<float, true>), dim3(nblk), dim3(64), 0, st, B, S, meta, (const float *)vel, vres, max_acc,
                            max_dec, dt, cap, rows, counts, flags);
     else
-        hipLaunchKernelGGL(k_time_integrate<float>, dim3(nblk), dim3(64), 0, st, B, S, meta, (const float *)vel, max_acc,
-                           max_dec, dt, cap, rows, counts, flags);
+        hipLaunchKernelGGL((k_time_integrate<float, false>), dim3(nblk), dim3(64), 0, st, B, S, meta, (const float *)vel,
+                           (const float *)nullptr, max_acc, max_dec, dt, cap, rows, counts, flags);
     const size_t seg_bytes = sizeof(double) * 12 * (size_t)(W - 1);
     const bool in_lds = seg_bytes <= 40 * 1024;
 #define VAP_TG(LDS_, RT_)                                                                                              \

@@ -113,6 +113,7 @@ struct Lanes {
     AccRows<IO> acc;
     IO *V;
     double *UF;
+    float *RES;             // fp32 rows: what the stored velocity lost, v64 - (double)(float)v64 (for the time domain)
     double end_u;
     unsigned char *rec;     // LDS: two record tiles
     double *out;            // LDS: two result tiles
@@ -222,11 +223,12 @@ struct Lanes {
         const int j = tile * TS + c.s;
         if (c.N >= 0 && j < S) {
             const double v = j < c.N ? vel_sqrt(ot[c.out_off]) : 0.0;
-            __builtin_nontemporal_store((IO)v, &V[c.row + j]);   // (never read again by this kernel: keep it out of the caches)
-            // fp32 rows: the scratch row that carried the forward sweep's squared velocities leaves with the fp64
-            // velocities (what the time-domain resample integrates, MPG:566-584: an fp32 row moves a position by 1e-7
-            // relative, now and then across a boundary of the reference's step lookup)
-            if constexpr (!std::is_same<IO, double>::value) __builtin_nontemporal_store(v, &UF[c.row + j]);
+            const IO vs = (IO)v;
+            __builtin_nontemporal_store(vs, &V[c.row + j]);   // (never read again by this kernel: keep it out of the caches)
+            // fp32 rows: what the rounding dropped goes to a side row, as an fp32 number (row + side row = the fp64
+            // velocity to 2^-48: what the time-domain resample integrates, MPG:566-584 — an fp32 row alone moves a
+            // position by 1e-7 relative, now and then across a boundary of the reference's step lookup)
+            if constexpr (!std::is_same<IO, double>::value) { if (RES) __builtin_nontemporal_store((float)(v - (double)vs), &RES[c.row + j]); }
         }
     }
 
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(kLanesThreads, 2) void k_velocity_lanes(int B, int 
                                                                      const double *__restrict__ dtheta,
                                                                      const IO *__restrict__ vcap, AccRows<IO> acc,
                                                                      IO *__restrict__ vel, double *__restrict__ ufwd,
-                                                                     long long *__restrict__ stats, FusedArgs fz)
+                                                                     long long *__restrict__ stats, FusedArgs fz, float *__restrict__ vres)
 {
     using G = LanesGeo<P>;
     constexpr int TS = G::TS;
@@ -339,6 +341,7 @@ __global__ __launch_bounds__(kLanesThreads, 2) void k_velocity_lanes(int B, int 
     Lanes<IO, P, VCAP, ACC> L;
     L.S = S;
     L.K = curv; L.DT = dtheta; L.VC = vcap; L.acc = acc; L.V = vel;
+    L.RES = vres;
     if constexpr (std::is_same<IO, double>::value) L.UF = reinterpret_cast<double *>(vel);   // fp64 rows: in place
     else L.UF = ufwd;
     L.end_u = end_u;
@@ -596,7 +599,7 @@ __global__ __launch_bounds__(kLanesThreads, 2) void k_velocity_lanes(int B, int 
 template <typename IO, int P>
 hipError_t launch_lanes_p(hipStream_t st, int B, int S, const double c[6], double sv, double ev, const double *meta,
                           const double *curv, const double *dth, const void *vcap, const AccRowsV &accv, void *vel, double *ufwd,
-                          const FusedArgs *fused = nullptr)
+                          const FusedArgs *fused = nullptr, float *vres = nullptr)
 {
     using G = LanesGeo<P>;
     VelConsts<double> vc;
@@ -628,7 +631,7 @@ hipError_t launch_lanes_p(hipStream_t st, int B, int S, const double c[6], doubl
             attr_set[dev] = true;                                                                                           \
         }                                                                                                                   \
         hipLaunchKernelGGL(kern, grid, block, lds, st, B, S, vc, sv * sv, ev * ev, meta, curv, dth, (const IO *)vcap, acc,  \
-                           (IO *)vel, ufwd, stats, FusedArgs());                                                            \
+                           (IO *)vel, ufwd, stats, FusedArgs(), vres);                                                      \
     } while (0)
     if constexpr (std::is_same<IO, float>::value && P == 16) {
         if (fused) {
@@ -636,7 +639,7 @@ hipError_t launch_lanes_p(hipStream_t st, int B, int S, const double c[6], doubl
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(kern, grid, block, lds, st, B, S, vc, sv * sv, ev * ev, meta, curv, dth, (const float *)nullptr, acc,
-                               (float *)vel, ufwd, stats, *fused);
+                               (float *)vel, ufwd, stats, *fused, vres);
         }
     }
     if (fused) { /* launched above */ }
@@ -672,14 +675,14 @@ int velocity_lanes_group(int B)
 
 hipError_t launch_velocity_lanes(hipStream_t st, bool io64, int B, int S, const double c[6], double sv, double ev,
                                  const double *meta, const void *curv, const void *dth, const void *vcap, const AccRowsV &acc,
-                                 void *vel, void *ufwd, int group)
+                                 void *vel, void *ufwd, int group, float *vres)
 {
     if (acc.fwd && !vcap) return hipErrorInvalidValue;
     const int P = group > 0 ? group : velocity_lanes_group(B);
 #define VAP_LANES(IO_)                                                                                                          \
-    (P == 16 ? launch_lanes_p<IO_, 16>(st, B, S, c, sv, ev, meta, (const double *)curv, (const double *)dth, vcap, acc, vel, (double *)ufwd) \
-     : P == 32 ? launch_lanes_p<IO_, 32>(st, B, S, c, sv, ev, meta, (const double *)curv, (const double *)dth, vcap, acc, vel, (double *)ufwd) \
-               : launch_lanes_p<IO_, 64>(st, B, S, c, sv, ev, meta, (const double *)curv, (const double *)dth, vcap, acc, vel, (double *)ufwd))
+    (P == 16 ? launch_lanes_p<IO_, 16>(st, B, S, c, sv, ev, meta, (const double *)curv, (const double *)dth, vcap, acc, vel, (double *)ufwd, nullptr, vres) \
+     : P == 32 ? launch_lanes_p<IO_, 32>(st, B, S, c, sv, ev, meta, (const double *)curv, (const double *)dth, vcap, acc, vel, (double *)ufwd, nullptr, vres) \
+               : launch_lanes_p<IO_, 64>(st, B, S, c, sv, ev, meta, (const double *)curv, (const double *)dth, vcap, acc, vel, (double *)ufwd, nullptr, vres))
     if (io64) return VAP_LANES(double);
     return VAP_LANES(float);
 #undef VAP_LANES
@@ -691,14 +694,14 @@ hipError_t launch_velocity_lanes(hipStream_t st, bool io64, int B, int S, const 
 hipError_t launch_sample_velocity_fused(hipStream_t st, int B, int W, int S, const double c[6], double sv, double ev,
                                         const double *meta, const double *power, const double *lut, const double *aux,
                                         const double *runs, float *ox, float *oy, float *oh, float *ok, double *k64, double *dth64,
-                                        float *vel, double *ufwd)
+                                        float *vel, double *ufwd, float *vres)
 {
     FusedArgs f;
     f.power = power; f.lut = lut; f.aux = aux; f.runs = runs;
     f.ox = ox; f.oy = oy; f.oh = oh; f.ok = ok;
     f.k64 = k64; f.dth64 = dth64;
     f.W = W;
-    return launch_lanes_p<float, 16>(st, B, S, c, sv, ev, meta, k64, dth64, nullptr, AccRowsV(), vel, ufwd, &f);
+    return launch_lanes_p<float, 16>(st, B, S, c, sv, ev, meta, k64, dth64, nullptr, AccRowsV(), vel, ufwd, &f, vres);
 }
 
 }  // namespace vap
