@@ -23,7 +23,9 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 WS = [113, 114, 200, 513, 1000, 2048] if len(sys.argv) > 2 and sys.argv[2] == "big" else [2, 3, 4, 5, 8, 13, 32, 57]
 rng = np.random.default_rng(20260101)
 gens = {"f32": BatchedTrajectoryGenerator(0, "f32"), "f64": BatchedTrajectoryGenerator(0, "f64")}
-tol = {"f32": 1e-5, "f64": 1e-9}
+# fp64 rows: 1e-7 is the stated bound: the recurrence amplifies last-bit differences between libm and
+# NumPy up to a few 1e-8; geometry columns stay at 1e-11 and below
+tol = {"f32": 1e-5, "f64": 1e-7}
 worst = {"f32": {}, "f64": {}}
 fails = 0
 t0 = time.time()

@@ -5,20 +5,21 @@
 //   * wave 0, the CHAIN wave, walks all P recurrences in lock step, one sample per step — forward over every tile of
 //     the rows, then backward — with the hand-scheduled loops of vap_chain_asm.h (four dependent fp64 instructions
 //     per step; the step's five coefficients come out of LDS in blocks of eight steps, because an LDS instruction
-//     between two dependent VALU instructions costs the wave ~15 cycles and ~4 back to back — tools/ubench_chain_lds.hip);
+//     between two dependent VALU instructions costs the wave ~15 cycles and ~4-7 back to back — tools/ubench_chain_lds.hip);
 //   * waves 1..7, the PRODUCERS, stream the curvature / heading-difference rows from HBM (coalesced along a row, one
 //     tile ahead of the chain, loads in flight across the tile barrier), derive the step coefficients of vap_device.h
-//     for tiles of 1024 (path, sample) slots and write them as 48-byte records into a double-buffered LDS tile in
-//     [sample][path] order (the chain's reads are conflict-free, the producers' writes too: the step stride is
-//     P*48+16 bytes); they also move the chain's results (one double per slot, LDS) to HBM: the forward sweep's
-//     squared velocities to a scratch row, which the backward sweep's producers fold into its caps (commit mode of
-//     k_velocity_relax), the backward sweep's as velocities in the caller's type.
+//     for tiles of 1024 (path, sample) slots and write them into a double-buffered LDS tile as 80-byte records per
+//     (path, pair of samples) in [pair][path] order (the chain's 16-byte reads are conflict-free, the producers' stores
+//     too: the pair stride is P*80+64 bytes); they also move the chain's results (one double per slot, LDS) to HBM: the
+//     forward sweep's squared velocities to a scratch row, which the backward sweep's producers fold into its caps
+//     (commit mode of k_velocity_relax), the backward sweep's as velocities in the caller's type — plus, behind fp32
+//     rows, what that rounding dropped, as an fp32 residual row for the time domain.
 // No speculation and no convergence test: every sample is evaluated exactly once per direction, in order, so the
 // result IS the sequential sweep's — the coefficient expressions are k_velocity_relax's, the step is step4 — bit for
-// bit (tests/test_gpu_parity.py holds every instantiation to k_velocity_seq<FAST>).
-// Cost: the chain's ~57 cycles per sample and direction whatever the batch size up to 256 workgroups, against
-// k_velocity_relax's one path per CU at a time; HBM: 8+8 B/pt read per direction, 8 B/pt scratch write + read, and
-// the velocity row.
+// bit (tests/test_gpu_lanes.py holds every instantiation to k_velocity_seq<FAST>).
+// Cost: the chain's ~56 cycles per sample and direction whatever the batch size up to 256 workgroups, against
+// k_velocity_relax's one path per CU at a time; HBM: 8+8 B/pt read per direction, 8 B/pt scratch write + read, the
+// velocity row and its 4 B/pt residual — 56 B/pt.
 #include "vap_chain_asm.h"
 #include "vap_device.h"
 #include "vap_kernels.h"
@@ -113,6 +114,8 @@ struct Lanes {
     AccRows<IO> acc;
     IO *V;
     double *UF;
+    bool stats_on = false;  // VAP_LANES_STATS: time the producers' wait for their rows
+    mutable long long t_take = 0;
     float *RES;             // fp32 rows: what the stored velocity lost, v64 - (double)(float)v64 (for the time domain)
     double end_u;
     unsigned char *rec;     // LDS: two record tiles
@@ -250,6 +253,7 @@ struct Lanes {
                                                     bool (&saw_dup)[kBatchesPerProducer]) const
     {
         SlotIn<IO> cur[NB];
+        const long long tk0 = stats_on ? __builtin_amdgcn_s_memtime() : 0;
 #pragma unroll
         for (int i = 0; i < NB; i++) {
             cur[i].k0 = opaque(rows[i].k0);
@@ -259,6 +263,7 @@ struct Lanes {
             if constexpr (ACC) cur[i].acc = opaque(rows[i].acc);
             if constexpr (VCAP && !BWD) cur[i].vc = opaque(rows[i].vc);
         }
+        if (stats_on) t_take += __builtin_amdgcn_s_memtime() - tk0;
         __builtin_amdgcn_sched_barrier(0);
         // (unconditional: a tile index outside the row loads clamped, unused values)
 #pragma unroll
@@ -342,6 +347,7 @@ __global__ __launch_bounds__(kLanesThreads, 2) void k_velocity_lanes(int B, int 
     L.S = S;
     L.K = curv; L.DT = dtheta; L.VC = vcap; L.acc = acc; L.V = vel;
     L.RES = vres;
+    L.stats_on = stats != nullptr;
     if constexpr (std::is_same<IO, double>::value) L.UF = reinterpret_cast<double *>(vel);   // fp64 rows: in place
     else L.UF = ufwd;
     L.end_u = end_u;
@@ -573,6 +579,7 @@ __global__ __launch_bounds__(kLanesThreads, 2) void k_velocity_lanes(int B, int 
     for (int i = 0; i < kBatchesPerProducer; i++) saw_dup[i] = s_pdup[ctx[i].p] != 0;
     sweep(std::true_type());
     if (stats && tid == 64) stats[(size_t)blockIdx.x * 16 + 7] = t_busy;   // ... both sweeps
+    if (stats && tid == 64) stats[(size_t)blockIdx.x * 16 + 15] = L.t_take;   // producer 0: of that, waiting for its rows
     if (stats && lane == 0) stats[(size_t)blockIdx.x * 16 + 8 + pw] = t_busy;   // every producer, both sweeps
     // rows longer than the longest path of the group: zeros past the last tile
     for (int p = 0; p < P; p++) {
@@ -657,7 +664,8 @@ hipError_t launch_lanes_p(hipStream_t st, int B, int S, const double c[6], doubl
             for (int k = 0; k < 16; k++) sum[k] += (double)h[(size_t)w * 16 + k] / grid.x;
         fprintf(stderr, "[lanes P=%d, %u workgroups] tiles %.0f | mean ticks: forward chain loops %.0f of sweep %.0f | backward chain loops %.0f | both sweeps %.0f | producer 0 busy forward %.0f, both %.0f | per step: chain %.1f, sweep %.1f | backward tiles with a zero heading difference %.2f\n",
                 P, grid.x, sum[0], sum[1], sum[2], sum[3], sum[4], sum[5], sum[7], sum[1] / (sum[0] * G::TS), sum[2] / (sum[0] * G::TS), sum[6]);
-        fprintf(stderr, "        producers busy, both sweeps: %.0f %.0f %.0f %.0f %.0f %.0f %.0f\n", sum[8], sum[9], sum[10], sum[11], sum[12], sum[13], sum[14]);
+        fprintf(stderr, "        producers busy, both sweeps: %.0f %.0f %.0f %.0f %.0f %.0f %.0f | producer 0 waiting for its rows: %.0f\n", sum[8], sum[9],
+                sum[10], sum[11], sum[12], sum[13], sum[14], sum[15]);
     }
     return hipGetLastError();
 }
