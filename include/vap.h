@@ -92,12 +92,15 @@ int vap_ctx_synchronize(vap_ctx *ctx);
  * experiments (slower on MI355X for the sizes measured).  LANES (fp64 recurrence) is "a wavefront of paths": a
  * lane walks a path, 16-64 paths per workgroup, coefficients streamed through LDS by producer waves — every
  * sample evaluated once per direction, bit-identical to SEQ_FAST, any row length; AUTO picks it for batches of
- * 2048 paths and more.  LANES_16 / _32 / _64 force its group size (tests). */
+ * 2048 paths and more.  LANES_16 / _32 / _64 force its group size (tests).  Rows too long for the register-resident
+ * kernel (config 2) are cut into super-chunks whose interface states are handed on by look-back inside one launch per
+ * direction; RELAX_ROUNDS forces the earlier form of that kernel (one launch per super-round, convergence checked
+ * on the host) — the same rows bit for bit (tests). */
 enum { VAP_OPT_VELOCITY_KERNEL = 0, VAP_OPT_F32_RECURRENCE = 1, VAP_OPT_FUSED_SAMPLING = 2 };
 enum { VAP_VELOCITY_AUTO = 0, VAP_VELOCITY_SEQ_LITERAL = 1, VAP_VELOCITY_SEQ_FAST = 2, VAP_VELOCITY_RELAX = 3,
        VAP_VELOCITY_RELAX_BLOCK = 4 /* workgroup per path */, VAP_VELOCITY_RELAX_WAVE = 5 /* wave per path, fp32 */,
        VAP_VELOCITY_LANES = 6 /* lane per path, fp64 recurrence */, VAP_VELOCITY_LANES_16 = 7, VAP_VELOCITY_LANES_32 = 8,
-       VAP_VELOCITY_LANES_64 = 9 };
+       VAP_VELOCITY_LANES_64 = 9, VAP_VELOCITY_RELAX_ROUNDS = 10 /* long rows: host-checked super-rounds */ };
 /* VAP_OPT_F32_RECURRENCE: arithmetic of the forward/backward velocity recurrence in VAP_F32 calls.
  *   VAP_RECURRENCE_F64 (default): the sampling kernel keeps fp64 curvature / heading-difference rows in
  *     context scratch and the recurrence runs in fp64 on them; inputs and every output row stay fp32.  The

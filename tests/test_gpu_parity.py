@@ -582,19 +582,63 @@ def test_dup_path_relaxation_matches_sequential(torch_mod, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B,W,S,seed", [(2, 64, 30001, 41), (1, 32, 20481, 42), (3, 16, 45000, 43)])
+# (2, 3, 30001): a dense grid — most samples share a table entry with their neighbour, the sign-aware backward step
+@pytest.mark.parametrize("B,W,S,seed", [(2, 64, 30001, 41), (1, 32, 20481, 42), (3, 16, 45000, 43), (2, 3, 30001, 32)])
 def test_long_row_relaxation_is_bit_identical_to_sequential_sweep(torch_mod, B, W, S, seed, dtype):
-    """Rows beyond the register-resident kernel go through the two-level relaxation (K5c)."""
+    """Rows beyond the register-resident kernel go through the two-level relaxation (K5c): "relax" hands the
+    super-chunk interfaces on by look-back inside one launch per direction, "relax_rounds" is the earlier form with one
+    launch per super-round and a host check — both must equal the sequential sweep bit for bit."""
     from vexautonomousplanner_amd.batch import BatchedTrajectoryGenerator
     from vexautonomousplanner_amd.synth import make_waypoints
     wp = make_waypoints(B, W, seed).astype(np.float64)
     outs = {}
-    for which in ("relax", "seq_fast"):
+    for which in ("relax", "relax_rounds", "seq_fast"):
         gen = make_gen(dtype, velocity_kernel=which)
         r = run_gpu(torch_mod, gen, wp, samples=S)
         assert np.all(r["flags"] == 0), which
         outs[which] = r["velocity"]
+        kk = r["curvature"]
+    if W == 3:
+        assert np.mean(kk[:, 1:] == kk[:, :-1]) > 0.5
     assert np.array_equal(outs["relax"], outs["seq_fast"])
+    assert np.array_equal(outs["relax_rounds"], outs["seq_fast"])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_long_rows_more_super_chunks_than_the_chip_holds(torch_mod, dtype):
+    """The look-back kernel waits only for workgroups with lower tickets, so a grid that is not resident all at once
+    (here 48 paths x 59 or 24 super-chunks of one wavefront each; the chip holds 2048 such wavefronts, 1024 for the fp32
+    kernel) drains in ticket order — and repeated calls on one context start from zeroed records every time."""
+    from vexautonomousplanner_amd.synth import make_waypoints
+    B, W, S = 48, 24, 60001
+    wp = make_waypoints(B, W, 77).astype(np.float64)
+    ref = run_gpu(torch_mod, make_gen(dtype, velocity_kernel="seq_fast"), wp, samples=S)
+    gen = make_gen(dtype, velocity_kernel="relax")
+    for rep in range(3):
+        r = run_gpu(torch_mod, gen, wp, samples=S)
+        assert np.all(r["flags"] == 0), rep
+        assert np.array_equal(r["velocity"], ref["velocity"]), rep
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_long_ragged_rows_look_back(torch_mod, dtype):
+    """Ragged long rows (the reference's own grid, a fixed dd): paths end in different super-chunks, the row capacity
+    leaves super-chunks with no sample at all, and the zero tail must be written."""
+    from vexautonomousplanner_amd.synth import make_waypoints
+    wp = make_waypoints(5, 12, 91).astype(np.float64)
+    wp[1] *= 0.55
+    wp[3] *= 0.8
+    outs = {}
+    for which in ("relax", "seq_fast"):
+        gen = make_gen(dtype, velocity_kernel=which)
+        r = run_gpu(torch_mod, gen, wp, dd=0.00015, capacity=70000)
+        assert np.all(r["flags"] == 0), which
+        outs[which] = r
+    n = outs["relax"]["meta"][:, 3].astype(int)
+    assert n.min() > 20480 and len(set(n.tolist())) > 1 and n.max() < 70000 - 2600
+    assert np.array_equal(outs["relax"]["velocity"], outs["seq_fast"]["velocity"])
+    for b in range(5):
+        assert np.all(outs["relax"]["velocity"][b, n[b]:] == 0)
 
 
 @pytest.mark.parametrize("B,W,S,seed", [(8, 32, 10000, 3), (5, 8, 2561, 5), (3, 16, 7001, 13), (4, 32, 4097, 12),

@@ -31,6 +31,7 @@ RECURRENCE_F64, RECURRENCE_F32 = 0, 1
 VELOCITY_AUTO, VELOCITY_SEQ_LITERAL, VELOCITY_SEQ_FAST, VELOCITY_RELAX = 0, 1, 2, 3
 VELOCITY_RELAX_BLOCK, VELOCITY_RELAX_WAVE = 4, 5
 VELOCITY_LANES, VELOCITY_LANES_16, VELOCITY_LANES_32, VELOCITY_LANES_64 = 6, 7, 8, 9
+VELOCITY_RELAX_ROUNDS = 10
 LUT_SAMPLES = 1000
 SAMPLES_PER_NODE = 1000
 

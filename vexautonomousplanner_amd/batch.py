@@ -58,12 +58,12 @@ class BatchedTrajectoryGenerator:
 
     def set_velocity_kernel(self, which):
         """"auto" | "seq_literal" | "seq_fast" | "relax" | "relax_block" | "relax_wave" | "lanes" | "lanes16" | "lanes32" |
-        "lanes64" (VAP_OPT_VELOCITY_KERNEL)."""
+        "lanes64" | "relax_rounds" (VAP_OPT_VELOCITY_KERNEL)."""
         table = {"auto": _lib.VELOCITY_AUTO, "seq_literal": _lib.VELOCITY_SEQ_LITERAL,
                  "seq_fast": _lib.VELOCITY_SEQ_FAST, "relax": _lib.VELOCITY_RELAX,
                  "relax_block": _lib.VELOCITY_RELAX_BLOCK, "relax_wave": _lib.VELOCITY_RELAX_WAVE,
                  "lanes": _lib.VELOCITY_LANES, "lanes16": _lib.VELOCITY_LANES_16, "lanes32": _lib.VELOCITY_LANES_32,
-                 "lanes64": _lib.VELOCITY_LANES_64}
+                 "lanes64": _lib.VELOCITY_LANES_64, "relax_rounds": _lib.VELOCITY_RELAX_ROUNDS}
         self.ctx.set_option(_lib.OPT_VELOCITY_KERNEL, table[which])
 
     def profile(self, waypoints, constraints=DEFAULT_CONSTRAINTS, samples=None, dd=None,

@@ -99,7 +99,7 @@ int run_velocity(vap_ctx *ctx, bool f64, bool io64, int B, int S, const double c
     if (mode == VAP_VELOCITY_AUTO)
         mode = (vcap && S > relax_limit) ? VAP_VELOCITY_SEQ_FAST : VAP_VELOCITY_RELAX;
     const int forced = mode;
-    if (mode == VAP_VELOCITY_RELAX_BLOCK || mode == VAP_VELOCITY_RELAX_WAVE) mode = VAP_VELOCITY_RELAX;
+    if (mode == VAP_VELOCITY_RELAX_BLOCK || mode == VAP_VELOCITY_RELAX_WAVE || mode == VAP_VELOCITY_RELAX_ROUNDS) mode = VAP_VELOCITY_RELAX;
     if (mode == VAP_VELOCITY_RELAX) {
         if (vcap && (forced == VAP_VELOCITY_RELAX_WAVE || S > relax_limit))
             return vap_fail(VAP_ERR_UNSUPPORTED, "per-sample limits: rows up to %d samples in the relaxation kernel, or the sequential sweep",
@@ -126,18 +126,24 @@ int run_velocity(vap_ctx *ctx, bool f64, bool io64, int B, int S, const double c
             HIP_TRY(vap::launch_velocity_relax(ctx->stream, f64, io64, B, S, cc, sv, ev, meta, curv, dth, vcap, acc, vel, flags, vhi));
             if (want_hi) keep_hi(vhi);
         } else {
-            // long rows: two-level relaxation (host-synchronised super-rounds); its scratch row holds the forward
-            // values until the last super-round, so the fp64 velocities get a row of their own
+            // long rows: two-level relaxation; its scratch row holds the forward values until the backward sweep has
+            // read them, so the fp64 velocities get a row of their own.  Interfaces between super-chunks are handed on
+            // inside one launch per direction (look-back); RELAX_ROUNDS: one launch per super-round, checked on the host
+            const bool rounds = forced == VAP_VELOCITY_RELAX_ROUNDS;
             VAP_TRY(ctx->ensure(ctx->ufwd, (size_t)B * S * (f64 ? 8 : 4)));
-            VAP_TRY(ctx->ensure(ctx->lstate, vap::velocity_long_state_bytes(f64, B, S)));
-            VAP_TRY(ctx->ensure(ctx->lcount, vap::velocity_long_counter_bytes(f64, B, S)));
+            VAP_TRY(ctx->ensure(ctx->lstate, rounds ? vap::velocity_long_state_bytes(f64, B, S) : vap::velocity_chase_state_bytes(f64, B, S)));
+            VAP_TRY(ctx->ensure(ctx->lcount, rounds ? vap::velocity_long_counter_bytes(f64, B, S) : vap::velocity_chase_counter_bytes(B)));
             void *vhi = nullptr;
             if (want_hi) {
                 VAP_TRY(ctx->ensure(ctx->vhi, (size_t)B * S * 8));
                 vhi = ctx->vhi.ptr;
             }
-            HIP_TRY(vap::launch_velocity_long(ctx->stream, f64, io64, B, S, cc, sv, ev, meta, curv, dth, vel, flags,
-                                              ctx->ufwd.ptr, ctx->lstate.ptr, (int *)ctx->lcount.ptr, vhi));
+            if (rounds)
+                HIP_TRY(vap::launch_velocity_long(ctx->stream, f64, io64, B, S, cc, sv, ev, meta, curv, dth, vel, flags,
+                                                  ctx->ufwd.ptr, ctx->lstate.ptr, (int *)ctx->lcount.ptr, vhi));
+            else
+                HIP_TRY(vap::launch_velocity_chase(ctx->stream, f64, io64, B, S, cc, sv, ev, meta, curv, dth, vel, flags,
+                                                   ctx->ufwd.ptr, ctx->lstate.ptr, (int *)ctx->lcount.ptr, vhi));
             if (want_hi) keep_hi(vhi);
         }
     } else {
@@ -262,7 +268,7 @@ int vap_ctx_synchronize(vap_ctx *ctx)
 int vap_ctx_set_option(vap_ctx *ctx, int option, int value)
 {
     if (!ctx) return vap_fail(VAP_ERR_INVALID, "null context");
-    if (option == VAP_OPT_VELOCITY_KERNEL && value >= VAP_VELOCITY_AUTO && value <= VAP_VELOCITY_LANES_64) {
+    if (option == VAP_OPT_VELOCITY_KERNEL && value >= VAP_VELOCITY_AUTO && value <= VAP_VELOCITY_RELAX_ROUNDS) {
         ctx->velocity_kernel = value;
         return VAP_OK;
     }

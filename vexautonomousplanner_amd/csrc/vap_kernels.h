@@ -88,6 +88,13 @@ size_t velocity_long_counter_bytes(bool f64, int B, int S);
 hipError_t launch_velocity_long(hipStream_t st, bool f64, bool io64, int B, int S, const double c[6], double sv, double ev,
                                 const double *meta, const void *curv, const void *dth, void *vel, uint32_t *flags,
                                 void *ufwd, void *state, int *counters, void *vhi = nullptr);
+// the same rows in one launch per direction: super-chunk interfaces handed on by look-back inside the launch (no host
+// round trip, any number of super-chunks); the default for long rows
+size_t velocity_chase_state_bytes(bool f64, int B, int S);
+size_t velocity_chase_counter_bytes(int B);
+hipError_t launch_velocity_chase(hipStream_t st, bool f64, bool io64, int B, int S, const double c[6], double sv, double ev,
+                                 const double *meta, const void *curv, const void *dth, void *vel, uint32_t *flags,
+                                 void *ufwd, void *state, int *counters, void *vhi = nullptr);
 // K5w (vap_velocity_lanes.hip), fp64 recurrence only: lane per path, `group` paths per workgroup (0 = by batch size).
 // ufwd: [B][S] doubles of scratch for the forward sweep's squared velocities (unused when io64: the rows are used in place)
 // vres (fp32 rows): [B][S] floats, v64 - (double)(float)v64 of every velocity written (what the time domain adds back)

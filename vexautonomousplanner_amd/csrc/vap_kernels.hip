@@ -1763,6 +1763,410 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_long(int S, int nsc, in
 }
 
 // ------------------------------------------------------------------------------------------------
+// K5c': the same two-level relaxation with the interfaces handed on INSIDE a launch — decoupled
+// look-back between super-chunks, one launch per direction, no host round trip (config 2).
+// A workgroup is one wavefront and owns the super-chunk of 64*L samples its TICKET names (tickets are
+// drawn in dispatch order, so a workgroup only ever waits for workgroups that already run: no
+// residency assumption, any number of super-chunks).  It relaxes its super-chunk from a guessed
+// incoming state and publishes a record {incoming state used, outgoing state}; then it looks back at
+// the records of its (up to) 64 predecessors at once, one per lane:
+//   * predecessor's outgoing state differs from the state it used -> relax again from that state
+//     (only the entry lane starts; the change ripples as far as it has to) and publish again;
+//   * it is FINAL as soon as some predecessor j is final and every link between j and itself is
+//     consistent (record k used exactly what record k-1 published): a record's outgoing state is a
+//     function of the incoming state it names, so such a chain carries the sequential sweep's values
+//     whatever the moments the records were read at.  Finality therefore travels 64 super-chunks per
+//     hop where nothing changes, and at the speed of the recurrence where a ramp is being walked.
+// Super-chunk 0 (backwards: the one holding the end sample) knows its incoming state and is final
+// after one evaluation.  Records are 8-byte {tag, half-word} granules written by single agent-scope
+// stores; a record is taken only when all its tags agree (tag = version, top bit = final; zeroed
+// before every launch).  Every spin is bounded: a workgroup that waits longer than kChaseTimeout
+// raises VAP_FLAG_NOCONVERGE, publishes what it has as final and goes on, so the grid always drains.
+// The fixed point is the sequential sweep bit for bit, like k_velocity_long's.
+// ------------------------------------------------------------------------------------------------
+using gu64 = __attribute__((address_space(1))) unsigned long long;
+using gu32 = __attribute__((address_space(1))) unsigned int;
+constexpr int kChaseRecGranules = 8;                 // 64-byte records
+constexpr uint32_t kChaseFinal = 0x80000000u;
+constexpr long long kChaseTimeout = 100000000ll;     // wall_clock64 ticks (100 MHz): 1 s
+
+template <typename R>
+__device__ __forceinline__ R wave_bcast(R x, int src)
+{
+    if constexpr (sizeof(R) == 8) {
+        const uint64_t v = __builtin_bit_cast(uint64_t, x);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
+        return __builtin_bit_cast(R, ((uint64_t)hi << 32) | lo);
+    } else {
+        return __builtin_bit_cast(R, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), src));
+    }
+}
+
+// the four values of a record, wave-uniform, leave as G = 4 * sizeof(R) / 4 granules from lanes 0..G-1
+template <typename R>
+__device__ __forceinline__ void chase_publish(gu64 *rec, uint32_t tag, R in_u, R in_w, R out_u, R out_w, int lane)
+{
+    constexpr int H = sizeof(R) / 4, G = 4 * H;
+    const int vi = lane / H, h = lane % H;
+    const R sel = vi == 0 ? in_u : (vi == 1 ? in_w : (vi == 2 ? out_u : out_w));
+    uint32_t half;
+    if constexpr (sizeof(R) == 8) {
+        const uint64_t b = __builtin_bit_cast(uint64_t, sel);
+        half = h ? (uint32_t)(b >> 32) : (uint32_t)b;
+    } else {
+        half = __builtin_bit_cast(uint32_t, sel);
+    }
+    if (lane < G) __hip_atomic_store(rec + lane, ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The sign-aware backward step (fast_backward_a<true, false>, vap_device.h) with its compare / select / max taken off the
+// dependent chain: the penalty max(t, other)*|g| with other = (g < 0 ? 0 : -t) is the larger of t*|g| and -t*gn,
+// gn = (g < 0 ? 0 : |g|), and rounding is monotone, so
+//     clamp01(am - max(t, other)*|g|) = clamp01(min(fma(-t, |g|, am), fma(t, gn, am)))        bit for bit
+// (g >= 0: the two FMAs are am -+ |t||g|, the smaller one is the old value; g < 0: t > 0 gives am - t|g| <= am = the
+// second, t <= 0 gives max(t, 0) = 0 -> am = the second exactly).  Two independent FMAs and a min with the clamp modifier
+// instead of xor / cndmask / cndmask / max / fma: the chain is fma, fma, min, fma, min.
+__device__ __forceinline__ double bwd_step_dup2(double am, double rho, double g, double gn, double A, double cap, double u,
+                                                double &uprev)
+{
+    double r, c2;
+    asm("v_fma_f64 %0, -%3, %4, %2\n\t"
+        "v_fma_f64 %1, %0, %6, %7\n\t"
+        "v_fma_f64 %0, -%0, |%5|, %7\n\t"
+        "v_min_f64 %0, %0, %1 clamp\n\t"
+        "v_fma_f64 %0, %8, %0, %2\n\t"
+        "v_min_f64 %0, %0, %9"
+        : "=&v"(r), "=&v"(c2)
+        : "v"(u), "v"(rho), "v"(uprev), "v"(g), "v"(gn), "v"(am), "v"(A), "v"(cap));
+    uprev = u;
+    return r;
+}
+__device__ __forceinline__ float bwd_step_dup2(float am, float rho, float g, float gn, float A, float cap, float u, float &uprev)
+{
+    (void)gn;
+    return bwd_step<true, true>(am, rho, g, A, cap, u, uprev, 0.0f);
+}
+
+template <typename R, typename IO, int L, bool BWD>
+__global__ __launch_bounds__(64, 2) void k_velocity_chase(int B, int S, int nsc, VelConsts<R> c, R start_u, R end_u,
+                                                          const double *__restrict__ meta, const R *__restrict__ curv,
+                                                          const R *__restrict__ dtheta, R *__restrict__ ufwd,
+                                                          IO *__restrict__ vel, unsigned long long *records,
+                                                          unsigned int *ticket, int *dupflag, uint32_t *__restrict__ flags,
+                                                          R *__restrict__ vhi, long long *__restrict__ stats)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    R *stage = reinterpret_cast<R *>(smem_raw);
+    constexpr int T = 64;
+    constexpr int SC = T * L;
+    constexpr int H = sizeof(R) / 4, G = 4 * H;
+    const int tid = threadIdx.x, lane = tid;
+    // dispatch-ordered ticket -> (path, position in the sweep's order)
+    unsigned int tk = 0;
+    if (lane == 0) tk = __hip_atomic_fetch_add((gu32 *)ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tk = (unsigned int)__builtin_amdgcn_readfirstlane((int)tk);
+    const int b = (int)(tk / (unsigned int)nsc), idx = (int)(tk % (unsigned int)nsc);
+    if (b >= B) return;
+    const double *m = meta + (size_t)b * kMetaStride;
+    const R twodd = (R)2 * (R)m[2];
+    const int N = (int)m[3];
+    const int last_sc = (N - 1) / SC;
+    const int sc = BWD ? last_sc - idx : idx;
+    if (idx > last_sc) return;                          // nobody looks back at these
+    const int base = sc * SC;
+    const size_t row = (size_t)b * S;
+    const R *K = curv + row, *DT = dtheta + row;
+    const FastConsts<R> fc = make_fast(c, twodd);
+    // zero heading differences anywhere on the path (the sign-aware backward step): the forward launch finds them,
+    // the backward launch reads the flag
+    const bool any_dup = BWD ? dupflag[b] != 0 : false;
+    const long long t_start = stats ? wall_clock64() : 0;
+    const int lo = tid * L;
+    gu64 *path_recs = (gu64 *)records + (size_t)b * nsc * kChaseRecGranules;
+    gu64 *my_rec = path_recs + (size_t)idx * kChaseRecGranules;
+    const bool exact_in = idx == 0;
+    R in0_u = exact_in ? (BWD ? end_u : start_u) : (R)0, in0_w = (R)0;
+
+    // q[] = rho, g[] = g*k^2 (vap_device.h).  Backwards the forward value of a sample is folded into its cap once
+    // (min is exact, so min(min(x, cap), u_fwd) = min(x, min(cap, u_fwd)): k_velocity_relax's commit mode) and the
+    // results are committed into cp[] — one dependent instruction less per step and no u[] to keep in registers
+    R q[L], g[L], A[L], cp[L], u[BWD ? 1 : L];
+    constexpr bool PSA = ScaledStep<R>::value;
+    R am[PSA ? L : 1];
+    R gn[(PSA && BWD) ? L : 1];   // backwards: g with the zero-heading-difference slots zeroed (the sign-aware step)
+    const R base_p = BWD ? fc.adecp : fc.amaxp;
+    constexpr int VW = 16 / (int)sizeof(R);
+    const int g0 = BWD ? base : (base > 0 ? base - VW : 0);
+    const int n_k = BWD ? SC + 2 : SC + VW;
+    const bool aligned = (S % VW) == 0;
+    {
+        int n = N - g0;
+        n = n < 0 ? 0 : (n > n_k ? n_k : n);
+        stage_load<R, L>(stage, K + g0, n, n_k, aligned, tid, T);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < L; s++) {
+        const int j = base + lo + s;
+        const bool valid = BWD ? (j <= N - 2) : (j >= 1 && j <= N - 1);
+        const int src = BWD ? j + 1 : j - 1;
+        const int prv = BWD ? j + 2 : j - 2;
+        const bool has_prv = valid && prv >= 0 && prv <= N - 1;
+        const R kabs = (R)fabs(stage[stage_pos<R, L>(valid ? src - g0 : 0)]);
+        const R kpv = (R)fabs(stage[stage_pos<R, L>(has_prv ? prv - g0 : 0)]);
+        fast_derive_k(fc, kabs, has_prv ? kpv : (R)0, base_p, q[s], g[s], A[s], cp[s]);
+        if (!valid) idle_coef(q[s], g[s], A[s], cp[s]);
+        if constexpr (!BWD) u[s] = start_u;
+    }
+    __syncthreads();
+    {
+        int n = N - g0;
+        n = n < 0 ? 0 : (n > n_k ? n_k : n);
+        stage_load<R, L>(stage, DT + g0, n, n_k, aligned, tid, T);
+    }
+    __syncthreads();
+    bool saw_dup = false;
+#pragma unroll
+    for (int s = 0; s < L; s++) {
+        const int j = base + lo + s;
+        const bool valid = BWD ? (j <= N - 2) : (j >= 1 && j <= N - 1);
+        const int src = BWD ? j : j - 1;
+        const R dth = stage[stage_pos<R, L>(valid ? src - g0 : 0)];
+        const R gq = fast_gq(fast_gg(fc, dth), g[s]);
+        if constexpr (!BWD) saw_dup |= valid && gq < (R)0;   // k_dup_scan's predicate, on the same values
+        R amv, gv;
+        fast_scale(fc.amaxp, valid ? gq : (R)0, A[s], amv, gv);
+        g[s] = gv;
+        if constexpr (PSA) am[s] = amv;
+        if constexpr (PSA && BWD) gn[s] = gv < (R)0 ? (R)0 : gv;
+    }
+    if constexpr (!BWD) {
+        if (__ballot(saw_dup) != 0ull && tid == 0) atomicOr(&dupflag[b], 1);
+    }
+    if constexpr (BWD) {
+        __syncthreads();
+        int n = N - base;
+        n = n < 0 ? 0 : (n > SC ? SC : n);
+        stage_load<R, L>(stage, ufwd + row + base, n, SC, aligned, tid, T);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < L; s++) {
+            const int j = base + lo + s;
+            const R uf = j <= N - 2 ? stage[stage_pos<R, L>(lo + s)] : end_u;   // (a slot that holds no step restarts the chain at end_u)
+            cp[s] = vmin(cp[s], uf);
+            if (s == L - 1) u[0] = uf;
+        }
+    }
+    // chunk-local incoming states (k_velocity_long's, for one wavefront)
+    R in_u, in_w;
+    const int local_last = BWD ? ((N - 1 - base) / L) : 0;
+    const bool bwd_has_end = BWD && sc == last_sc;
+    constexpr int entry = BWD ? T - 1 : 0;              // the lane a neighbour's state comes in at
+    constexpr int owner = BWD ? 0 : T - 1;              // the lane whose outgoing state leaves the super-chunk
+    if constexpr (!BWD) {
+        if (!exact_in) { in0_u = wave_bcast(cp[0], 0); in0_w = in0_u; }
+        if (tid == 0) { in_u = in0_u; in_w = in0_w; }
+        else { in_u = cp[0]; in_w = in_u; }
+    } else {
+        if (!exact_in) { in0_u = wave_bcast(u[0], T - 1); in0_w = in0_u; }
+        const bool tail = bwd_has_end ? tid >= local_last : false;
+        if (tail) { in_u = end_u; in_w = (R)0; }
+        else if (tid == T - 1) { in_u = in0_u; in_w = in0_w; }
+        else { in_u = u[0]; in_w = in_u; }
+    }
+    const bool active = BWD ? (!bwd_has_end || tid <= local_last) : (base + lo <= N - 1);
+    const bool in_wave_nb = BWD ? (lane < 63 && (!bwd_has_end || tid < local_last)) : (lane > 0 && active);
+    R out_u = in_u, out_w = in_w;
+    bool need = active;
+    uint32_t version = 0;
+    bool timed_out = false;
+    const long long t_begin = wall_clock64();
+    long long t_first = 0;
+    int n_evals = 0, n_iters = 0, n_polls = 0;
+    while (true) {
+        // relax the super-chunk for the incoming state in0: states move lane to lane by DPP
+        int it = 0;
+        while (true) {
+            if (need) {
+                R uu = in_u, wp = in_w;
+                if constexpr (!BWD) {
+#pragma unroll
+                    for (int s = 0; s < L; s++) {
+                        if (s == 0 && tid == 0 && base == 0) continue;   // sample 0 is the given start velocity
+                        uu = step_fwd(PSA ? am[PSA ? s : 0] : fc.amaxp, q[s], g[s], A[s], cp[s], uu, wp);
+                        u[s] = uu;
+                    }
+                } else if (any_dup) {
+#pragma unroll
+                    for (int s = L - 1; s >= 0; s--) uu = bwd_step_dup2(PSA ? am[PSA ? s : 0] : fc.amaxp, q[s], g[s], gn[(PSA && BWD) ? s : 0], A[s], cp[s], uu, wp);
+                } else {
+#pragma unroll
+                    for (int s = L - 1; s >= 0; s--) uu = bwd_step<false, true>(PSA ? am[PSA ? s : 0] : fc.amaxp, q[s], g[s], A[s], cp[s], uu, wp, (R)0);
+                }
+                out_u = uu;
+                out_w = wp;
+            }
+            const R nu = BWD ? wave_shift_down(out_u) : wave_shift_up(out_u);
+            const R nw = BWD ? wave_shift_down(out_w) : wave_shift_up(out_w);
+            need = false;
+            if (in_wave_nb) {
+                need = !(same_bits(nu, in_u) && same_bits(nw, in_w));
+                in_u = nu;
+                in_w = nw;
+            }
+            n_iters++;
+            if (__ballot(need) == 0) break;
+            if (++it > 2 * T + 8) {
+                if (tid == 0 && flags) atomicOr(&flags[b], VAP_FLAG_NOCONVERGE_BIT);
+                break;
+            }
+        }
+        const R pub_u = wave_bcast(out_u, owner), pub_w = wave_bcast(out_w, owner);
+        if (stats && n_evals == 0) t_first = wall_clock64();
+        n_evals++;
+        if (exact_in) {
+            chase_publish<R>(my_rec, kChaseFinal | 1u, in0_u, in0_w, pub_u, pub_w, lane);
+            break;
+        }
+        // look back: lane i reads the record of predecessor idx-1-i
+        bool final_now = false, again = false;
+        bool published = false;
+        while (true) {
+            n_polls++;
+            const int p = idx - 1 - lane;
+            unsigned long long gr[G];
+            if (p >= 0) {
+                gu64 *pr = path_recs + (size_t)p * kChaseRecGranules;
+#pragma unroll
+                for (int k = 0; k < G; k++) gr[k] = __hip_atomic_load(pr + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+#pragma unroll
+                for (int k = 0; k < G; k++) gr[k] = 0ull;
+            }
+            const uint32_t tag = (uint32_t)(gr[0] >> 32);
+            bool ok = p >= 0 && tag != 0u;
+#pragma unroll
+            for (int k = 1; k < G; k++) ok = ok && (uint32_t)(gr[k] >> 32) == tag;
+            R pv[4];
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                if constexpr (sizeof(R) == 8)
+                    pv[v] = __builtin_bit_cast(R, ((gr[2 * v + 1] & 0xffffffffull) << 32) | (gr[2 * v] & 0xffffffffull));
+                else
+                    pv[v] = __builtin_bit_cast(R, (uint32_t)gr[v]);
+            }
+            const unsigned long long okmask = __ballot(ok);
+            const bool ok0 = (okmask & 1ull) != 0;
+            const R cand_u = wave_bcast(pv[2], 0), cand_w = wave_bcast(pv[3], 0);
+            if (ok0 && !(same_bits(cand_u, in0_u) && same_bits(cand_w, in0_w))) {
+                in0_u = cand_u;
+                in0_w = cand_w;
+                again = true;
+            }
+            // links: record k (lane i) used what record k-1 (lane i+1) published
+            const R nxt_u = wave_shift_down(pv[2]), nxt_w = wave_shift_down(pv[3]);
+            const bool nxt_ok = lane < 63 && ((okmask >> (lane + 1)) & 1ull) != 0;
+            const bool link = ok && nxt_ok && same_bits(pv[0], nxt_u) && same_bits(pv[1], nxt_w);
+            const unsigned long long fin = __ballot(ok && (tag & kChaseFinal) != 0u);
+            const unsigned long long links = __ballot(link);
+            bool chain = false;
+            if (ok0 && fin != 0ull) {
+                const int j = __builtin_ctzll(fin);
+                const unsigned long long mask = (j == 0) ? 0ull : (~0ull >> (64 - j));
+                chain = (links & mask) == mask;
+            }
+            if (again) { final_now = false; break; }   // relax from the new state first; the next look-back decides
+            if (chain) { final_now = true; break; }
+            if (!published) {
+                // what this evaluation produced, for the successors to work with meanwhile
+                version++;
+                chase_publish<R>(my_rec, version, in0_u, in0_w, pub_u, pub_w, lane);
+                published = true;
+            }
+            if (wall_clock64() - t_begin > kChaseTimeout) { timed_out = true; break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        if (timed_out) {
+            if (tid == 0 && flags) atomicOr(&flags[b], VAP_FLAG_NOCONVERGE_BIT);
+            version++;
+            chase_publish<R>(my_rec, kChaseFinal | version, in0_u, in0_w, pub_u, pub_w, lane);
+            break;
+        }
+        if (final_now) {
+            version++;
+            chase_publish<R>(my_rec, kChaseFinal | version, in0_u, in0_w, pub_u, pub_w, lane);
+            break;
+        }
+        // again: the entry lane restarts from the new incoming state
+        need = false;
+        if (lane == entry) {
+            need = true;
+            in_u = in0_u;
+            in_w = in0_w;
+        }
+    }
+    const long long t_final = stats ? wall_clock64() : 0;
+    if constexpr (BWD) {
+        if (active) {
+            R uu = in_u, wp = in_w;
+            if (any_dup) {
+#pragma unroll
+                for (int s = L - 1; s >= 0; s--) cp[s] = uu = bwd_step_dup2(PSA ? am[PSA ? s : 0] : fc.amaxp, q[s], g[s], gn[(PSA && BWD) ? s : 0], A[s], cp[s], uu, wp);
+            } else {
+#pragma unroll
+                for (int s = L - 1; s >= 0; s--) cp[s] = uu = bwd_step<false, true>(PSA ? am[PSA ? s : 0] : fc.amaxp, q[s], g[s], A[s], cp[s], uu, wp, (R)0);
+            }
+        }
+    }
+    // rows leave through the stage: forward -> u (squared velocity) scratch, backward -> final velocity
+    __syncthreads();
+    int n = S - base;
+    n = n > SC ? SC : n;
+    if constexpr (BWD) {
+        IO *ostage = reinterpret_cast<IO *>(smem_raw);
+#pragma unroll
+        for (int s = 0; s < L; s++) {
+            const int j = base + lo + s;
+            ostage[stage_pos<IO, L>(lo + s)] = j < N ? (IO)vel_sqrt(cp[s]) : (IO)0;
+        }
+        __syncthreads();
+        IO *dst = vel + row + base;
+        for (int i = tid; i < n; i += T) dst[i] = ostage[stage_pos<IO, L>(i)];
+        if (sc == last_sc)
+            for (int j = (last_sc + 1) * SC + tid; j < S; j += T) vel[row + j] = (IO)0;
+        if constexpr (!std::is_same<R, IO>::value) {
+            if (vhi) {   // the velocities in the arithmetic type as well (the time-domain resample behind fp32 rows)
+#pragma unroll
+                for (int s = 0; s < L; s++) {
+                    const int j = base + lo + s;
+                    if (j < S) vhi[row + j] = j < N ? vel_sqrt(cp[s]) : (R)0;
+                }
+                if (sc == last_sc)
+                    for (int j = (last_sc + 1) * SC + tid; j < S; j += T) vhi[row + j] = (R)0;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < L; s++) stage[stage_pos<R, L>(lo + s)] = u[s];
+        __syncthreads();
+        R *dst = ufwd + row + base;
+        for (int i = tid; i < n; i += T) dst[i] = stage[stage_pos<R, L>(i)];
+    }
+    if (stats && tid == 0) {
+        long long *my = stats + ((size_t)b * nsc + idx) * 8;
+        my[0] = t_start;
+        my[1] = t_begin;
+        my[2] = t_first;
+        my[3] = t_final;
+        my[4] = wall_clock64();
+        my[5] = n_evals;
+        my[6] = n_iters;
+        my[7] = n_polls;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Segment blocks -> monomial coefficients (scratch used by k_sample).
 // ------------------------------------------------------------------------------------------------
 __global__ void k_power(int n_seg, const double *__restrict__ segments, double *__restrict__ power)
@@ -2203,6 +2607,102 @@ hipError_t launch_velocity_long(hipStream_t st, bool f64, bool io64, int B, int 
     if (blocks256 < 512)
         return velocity_long_t<float, float, 40, 64, 2>(st, B, S, c, sv, ev, meta, curv, dth, vel, flags, ufwd, state, counters, nullptr);
     return velocity_long_t<float, float, 40, 256, 2>(st, B, S, c, sv, ev, meta, curv, dth, vel, flags, ufwd, state, counters, nullptr);
+}
+
+// K5c': one launch per direction, interfaces handed on by look-back (k_velocity_chase).
+//   state    [2][B][nsc] records of 64 bytes (zeroed per call: tag 0 = nothing published)
+//   counters [B] dup flags | [2] tickets
+template <typename R, typename IO, int L>
+static hipError_t velocity_chase_t(hipStream_t st, int B, int S, const double c[6], double sv, double ev, const double *meta,
+                                   const void *curv, const void *dth, void *vel, uint32_t *flags, void *ufwd, void *state,
+                                   int *counters, void *vhi)
+{
+    constexpr int SC = 64 * L;
+    const int nsc = (S + SC - 1) / SC;
+    const R s = (R)sv, e = (R)ev;
+    const size_t lds = sizeof(R) * ((size_t)64 * L + 64 + 8);
+    const size_t rec_bytes = (size_t)B * nsc * kChaseRecGranules * 8;
+    unsigned long long *rec = (unsigned long long *)state;
+    int *dup = counters;
+    unsigned int *ticket = (unsigned int *)(counters + B);
+    hipError_t err;
+    if ((err = hipMemsetAsync(state, 0, 2 * rec_bytes, st)) != hipSuccess) return err;
+    if ((err = hipMemsetAsync(counters, 0, sizeof(int) * ((size_t)B + 2), st)) != hipSuccess) return err;
+    const unsigned int grid = (unsigned int)((size_t)B * nsc);
+    // developer knob: VAP_CHASE_STATS=1 prints the timeline of the super-chunks (synchronises!)
+    static const bool want_stats = getenv("VAP_CHASE_STATS") != nullptr;
+    long long *stats = nullptr;
+    if (want_stats) {
+        (void)hipMalloc(&stats, (size_t)2 * grid * 8 * sizeof(long long));
+        (void)hipMemsetAsync(stats, 0, (size_t)2 * grid * 8 * sizeof(long long), st);
+    }
+    hipLaunchKernelGGL((k_velocity_chase<R, IO, L, false>), dim3(grid), dim3(64), lds, st, B, S, nsc, make_consts<R>(c), s * s,
+                       e * e, meta, (const R *)curv, (const R *)dth, (R *)ufwd, (IO *)vel, rec, ticket, dup, flags, (R *)vhi,
+                       stats);
+    if ((err = hipGetLastError()) != hipSuccess) return err;
+    hipLaunchKernelGGL((k_velocity_chase<R, IO, L, true>), dim3(grid), dim3(64), lds, st, B, S, nsc, make_consts<R>(c), s * s,
+                       e * e, meta, (const R *)curv, (const R *)dth, (R *)ufwd, (IO *)vel, rec + rec_bytes / 8, ticket + 1, dup,
+                       flags, (R *)vhi, stats ? stats + (size_t)grid * 8 : nullptr);
+    if (stats) {
+        std::vector<long long> h((size_t)2 * grid * 8);
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(h.data(), stats, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+        (void)hipFree(stats);
+        for (int dir = 0; dir < 2; dir++) {
+            const long long *d = h.data() + (size_t)dir * grid * 8;
+            long long t0 = 0, t_end = 0;
+            for (unsigned int i = 0; i < grid; i++)
+                if (d[i * 8]) {
+                    if (!t0 || d[i * 8] < t0) t0 = d[i * 8];
+                    if (d[i * 8 + 4] > t_end) t_end = d[i * 8 + 4];
+                }
+            double ev = 0, it = 0, po = 0;
+            long long mev = 0, n = 0;
+            for (unsigned int i = 0; i < grid; i++)
+                if (d[i * 8]) {
+                    n++;
+                    ev += (double)d[i * 8 + 5];
+                    it += (double)d[i * 8 + 6];
+                    po += (double)d[i * 8 + 7];
+                    if (d[i * 8 + 5] > mev) mev = d[i * 8 + 5];
+                }
+            fprintf(stderr, "[chase %s L=%d] %lld super-chunks, span %.1f us | per super-chunk: evaluations mean %.2f max %lld, inner rounds %.1f, look-backs %.1f\n",
+                    dir ? "bwd" : "fwd", L, n, (double)(t_end - t0) * 0.01, ev / (double)n, mev, it / (double)n, po / (double)n);
+            // the first path's timeline (us from the first start): where finality advanced by more than 3 us from one
+            // super-chunk to the next, and every 1/8 of the row
+            const int step = nsc >= 8 ? nsc / 8 : 1;
+            long long prev_final = 0;
+            for (int i = 0; i < nsc; i++) {
+                const long long *r = d + (size_t)i * 8;
+                if (!r[0]) continue;
+                if (i % step == 0 || r[3] - prev_final > 300)
+                    fprintf(stderr, "   idx %5d: start %7.1f derived %7.1f relaxed %7.1f final %7.1f (+%5.1f) end %7.1f | evals %lld rounds %lld polls %lld\n", i,
+                            (double)(r[0] - t0) * 0.01, (double)(r[1] - t0) * 0.01, (double)(r[2] - t0) * 0.01, (double)(r[3] - t0) * 0.01,
+                            (double)(r[3] - prev_final) * 0.01, (double)(r[4] - t0) * 0.01, r[5], r[6], r[7]);
+                prev_final = r[3];
+            }
+        }
+    }
+    return hipGetLastError();
+}
+
+size_t velocity_chase_state_bytes(bool f64, int B, int S)
+{
+    const int SC = f64 ? 64 * 16 : 64 * 40;
+    const int nsc = (S + SC - 1) / SC;
+    return 2 * (size_t)B * nsc * kChaseRecGranules * 8 + 64;
+}
+size_t velocity_chase_counter_bytes(int B) { return sizeof(int) * ((size_t)B + 2) + 64; }
+
+hipError_t launch_velocity_chase(hipStream_t st, bool f64, bool io64, int B, int S, const double c[6], double sv, double ev,
+                                 const double *meta, const void *curv, const void *dth, void *vel, uint32_t *flags,
+                                 void *ufwd, void *state, int *counters, void *vhi)
+{
+    if (f64) {
+        if (io64) return velocity_chase_t<double, double, 16>(st, B, S, c, sv, ev, meta, curv, dth, vel, flags, ufwd, state, counters, vhi);
+        return velocity_chase_t<double, float, 16>(st, B, S, c, sv, ev, meta, curv, dth, vel, flags, ufwd, state, counters, vhi);
+    }
+    return velocity_chase_t<float, float, 40>(st, B, S, c, sv, ev, meta, curv, dth, vel, flags, ufwd, state, counters, nullptr);
 }
 
 // K5b': many paths, fp32: one wave per path walks the row in windows of 64*L samples, one launch per
