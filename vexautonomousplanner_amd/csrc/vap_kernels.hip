@@ -654,6 +654,10 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int 
             }
             continue;
         }
+        // interior tiles (every sample and its right-hand neighbour before the path's last sample, not the first tile, rows
+        // 16-byte aligned): the same body without the end-of-path selects, chosen per tile — wave-uniform
+        auto tile_body = [&](auto interior_tag) {
+            constexpr bool INTERIOR = decltype(interior_tag)::value;
         OT vx[kSPT], vy[kSPT], vh[kSPT], vk[kSPT], vd[kSPT];
         double vd64[HI ? kSPT : 1];
         [[maybe_unused]] double kap_even = 0.0;   // HI: the fp64 curvature row leaves in pairs as soon as a pair exists
@@ -669,19 +673,19 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int 
         for (int i = 0; i < kSPT; i++) {
             // samples past the end of the grid (last tile only) are evaluated at the end sample and
             // blanked on store: the body stays straight-line
-            const int k = kbase + i < N - 1 ? kbase + i : N - 1;
+            const int k = INTERIOR ? kbase + i : (kbase + i < N - 1 ? kbase + i : N - 1);
             if (i > 0) sk = sk + dd;
-            const double s = (k == N - 1) ? total : sk;
+            const double s = INTERIOR ? sk : ((k == N - 1) ? total : sk);
             // SM:291-318 distance_to_time.  s = 0 lands on entry 1 with t = 0 exactly; s = total is the
             // reference's early return of len(nodes)-1.
             if (i == 0) idx = lut_search_left(sD, s);
             else while (idx < kLutN - 1 && sD[idx] < s) idx++;
-            idx = idx < 1 ? 1 : idx;
+            if constexpr (!INTERIOR) idx = idx < 1 ? 1 : idx;
             const double d0 = sD[idx - 1];
             const double t0 = (double)(idx - 1) * lstep;
-            const bool exact = s <= 0.0 || s >= total;      // the reference's early returns: t is exact
+            const bool exact = INTERIOR ? false : (s <= 0.0 || s >= total);      // the reference's early returns: t is exact
             double t = fma(sWt[idx], s - d0, t0);
-            t = s >= total ? end_param : t;
+            if constexpr (!INTERIOR) t = s >= total ? end_param : t;
             // SM:340-346 / 550-580: the table entry the reference's step lookup selects
             bool near;
             int jj = table_index_fast(t, tab_n, inv_tstep, near);
@@ -707,8 +711,8 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int 
                     kap_even = kap;
                 } else if (writer) {
                     const int ke = kbase + i - 1;
-                    const double v0 = ke < N ? kap_even : 0.0, v1 = ke + 1 < N ? kap : 0.0;
-                    if ((S & 1) == 0 && ke + 2 <= S) {
+                    const double v0 = (INTERIOR || ke < N) ? kap_even : 0.0, v1 = (INTERIOR || ke + 1 < N) ? kap : 0.0;
+                    if (INTERIOR || ((S & 1) == 0 && ke + 2 <= S)) {
                         *reinterpret_cast<double2 *>(ok64 + row + ke) = make_double2(v0, v1);
                     } else {
                         if (ke < S) ok64[row + ke] = v0;
@@ -745,7 +749,7 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int 
 #pragma unroll
             for (int i = 0; i < kSPT; i++) {
                 const int k = kbase + i;
-                if (k < N - 1) {
+                if (INTERIOR || k < N - 1) {
                     const double nx = (i + 1 < kSPT) ? d1x[(i + 1) % kSPT] : s_dx[pb][tid + 1];
                     const double ny = (i + 1 < kSPT) ? d1y[(i + 1) % kSPT] : s_dy[pb][tid + 1];
                     const int nj = (i + 1 < kSPT) ? jjv[(i + 1) % kSPT] : s_j[pb][tid + 1];
@@ -760,7 +764,7 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int 
                     }
                 }
             }
-            if (k0 + kSampleChunk > N) {   // only the path's last tile has samples to blank
+            if (!INTERIOR && k0 + kSampleChunk > N) {   // only the path's last tile has samples to blank
 #pragma unroll
                 for (int i = 0; i < kSPT; i++)
                     if (kbase + i >= N) {
@@ -772,6 +776,10 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int 
             if constexpr (HI) store_hi(odth64, vd64);
             store_vec(odth, vd);
         }
+            };
+        const bool interior = k0 > 0 && k0 + kSampleThreads * kSPT < N - 1 && aligned && (S & 1) == 0 && k0 + kSampleThreads * kSPT <= S;
+        if (interior) tile_body(std::true_type{});
+        else tile_body(std::false_type{});
     }
     if (stats && (tid & 63) == 0) {
         long long *st = stats + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + (tid >> 6)) * 4;
