@@ -237,7 +237,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # under a launcher (WORLD_SIZE in the environment) the process group is set up even for one rank, so that
+    # `python -m torch.distributed.run --nproc-per-node 1 bench.py` takes RCCL through the same calls as N ranks do
+    distributed = world > 1 or ("WORLD_SIZE" in os.environ and "MASTER_PORT" in os.environ)
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -280,7 +283,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -291,7 +294,7 @@ def main():
     torch.cuda.synchronize(dev)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if distributed:
         te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
@@ -386,7 +389,7 @@ def main():
     sweep = None
     if args.tolerance_sweep:
         sweep = tolerance_sweep(local_rank, wp, constraints, S)
-        if world > 1:
+        if distributed:
             # worst over ranks, counts summed: three small all-reduces after the timed region
             for mode in sweep["modes"].values():
                 t = torch.tensor([mode["worst"]], dtype=torch.float64, device=dev)
@@ -454,7 +457,7 @@ def main():
             line["cpu_baseline"]["reference_python"] = {"value": 5.3e3, "unit": "sample-points/s", "cores": 1,
                                                         "measured": "build container, 1 Xeon 2.1 GHz core, config 1 (BASELINE.md)"}
         print(json.dumps(line))
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 

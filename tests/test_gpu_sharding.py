@@ -135,3 +135,29 @@ def test_bench_starts_its_own_ranks(torch_mod):
                          text=True, timeout=600, env=env)
     assert bad.returncode != 0
     assert not [ln for ln in bad.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_one_rank_over_rccl_under_the_launcher(torch_mod):
+    """The driver's multi-GPU command with one rank: `python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1`.
+    Under a launcher bench.py sets the process group up whatever the world size, so this takes the `nccl` backend —
+    RCCL on ROCm — through every call the N-rank run makes (init with a device id, the constraints broadcast, the two
+    barriers around the timed region, the max-over-ranks all-reduce, the padded summary all-gather, the sweep's
+    reductions) on the one GPU this box has."""
+    import json
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--workload", "c5", "--paths-per-gpu", "2048", "--tolerance-sweep", "--no-cpu-baseline", "--parity-paths", "0"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and rec["config"]["global_paths"] == 2048 and rec["value"] > 0
+    assert rec["config"]["flags_or"] == 0
