@@ -1036,3 +1036,23 @@ def test_staged_api_equals_fused_call(torch_mod, dtype):
         torch.equal(rows[b, :int(counts[b, 0])], fused_tp["rows"][b, :int(counts[b, 0])]) for b in range(B))
     for b in range(B):
         assert torch.equal(nmap[b, :int(counts[b, 1])], fused_tp["nodes_map"][b, :int(counts[b, 1])])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("kw", [dict(samples=1024), dict(samples=700), dict(dd=0.02, capacity=1024)])
+def test_two_paths_per_workgroup_sampling_is_bit_identical(torch_mod, dtype, kw):
+    """Rows of one tile in batches of 8192 paths and more are sampled two paths per workgroup (their staging loads in
+    flight together).  An odd batch of 8195 paths must give, row for row and bit for bit, what the same paths give in two
+    halves (below 8192: one path per workgroup) — fixed grids, a grid shorter than the tile, ragged rows."""
+    from vexautonomousplanner_amd.synth import make_waypoints
+    B = 8195
+    wp = make_waypoints(B, 8, 123).astype(np.float64)
+    wp[1::7] *= 0.6
+    gen = make_gen(dtype)
+    whole = run_gpu(torch_mod, gen, wp, **kw)
+    cut = 4100
+    parts = [run_gpu(torch_mod, gen, wp[:cut], **kw), run_gpu(torch_mod, gen, wp[cut:], **kw)]
+    assert np.all(whole["flags"] == 0)
+    for k in ("x", "y", "heading", "curvature", "velocity", "meta"):
+        both = np.concatenate([parts[0][k], parts[1][k]], axis=0)
+        assert np.array_equal(whole[k], both, equal_nan=True), k

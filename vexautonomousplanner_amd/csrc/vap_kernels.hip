@@ -509,8 +509,8 @@ __global__ void k_lut_slopes(int B, const double *__restrict__ lut, const double
 // ------------------------------------------------------------------------------------------------
 // HI (fp32 outputs only): also write the curvature and |dtheta| rows in fp64 (ok64, odth64) for the fp64
 // velocity recurrence behind fp32 outputs; the fp32 |dtheta| row is then optional (odth may be NULL).
-template <typename OT, bool COEF_LDS, bool HI>
-__global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int tile, int tiles_per_block,
+template <typename OT, bool COEF_LDS, bool HI, int PPB = 1>
+__global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int B, int W, int S, int tile, int tiles_per_block,
                                                            const double *__restrict__ power,
                                                            const double *__restrict__ lut,
                                                            const double *__restrict__ slopes,
@@ -523,46 +523,86 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int 
                                                            double *__restrict__ odth64, long long *__restrict__ stats)
 {
     static_assert(!HI || sizeof(OT) == 4, "the fp64 side rows belong to the fp32 output mode");
-    extern __shared__ __attribute__((aligned(16))) double s_coef[];   // G * kCoefDoubles when COEF_LDS
-    __shared__ double sD[kLutN], sWt[kLutN];
+    // PPB paths per workgroup (blockIdx.y * PPB + pp).  Rows that are one tile long (config 5: 1024 samples) leave a
+    // workgroup as much time in staging — a chain of dependent memory round trips: meta, aux, tables, run table — as in
+    // the tile itself; with PPB = 2 the loads of both paths are in flight together and the chain is paid once for two.
+    extern __shared__ __attribute__((aligned(16))) double s_coef[];   // PPB * G * kCoefDoubles when COEF_LDS
+    __shared__ double sD_all[PPB * kLutN], sWt_all[PPB * kLutN];
     // neighbour exchange, double-buffered by tile parity (one barrier per tile)
     __shared__ double s_dx[2][kSampleThreads], s_dy[2][kSampleThreads];
     __shared__ int s_j[2][kSampleThreads];
     __shared__ OT s_th[2][kSampleThreads];
     const long long ts0 = stats ? __builtin_amdgcn_s_memtime() : 0;
-    const int b = blockIdx.y, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int G = W - 1;
-    const double *m = meta + (size_t)b * kMetaStride;
-    const double t_max = m[0], total = m[1], dd = m[2];
-    const int N = (int)m[3];
-    const double *ax = aux + (size_t)b * kAuxStride;
-    const double lstep = ax[0], tstep = ax[1], inv_tstep = ax[2];
-    const int n_runs = (int)ax[3];
     const int tile0 = blockIdx.x * tiles_per_block;
     if (tile0 * tile >= S) return;
-    const size_t row = (size_t)b * S;
     // tile == kSampleChunk: the whole row is one tile, so the last thread's last sample is the row's last
     // and needs no neighbour — every thread writes
     const bool writer = tile == kSampleChunk || tid < kSampleThreads - 1;
     constexpr int VW = 16 / sizeof(OT);   // elements per 16-byte store
     const bool aligned = (S % VW) == 0;   // rows (and tile starts, multiples of kSPT) then start 16-byte aligned
 
-    // the path's tables are staged once and serve every tile of this workgroup
-    const double *pw = power + (size_t)b * G * kCoefDoubles;
-    // (touch the head of the run table now: its lookup below depends on meta / aux and would otherwise wait
-    // for memory a second time)
-    const double run_touch = runs[(size_t)b * kGridRunDoubles + (tid < 120 ? tid : 0)];
-    if (tile0 * tile < N) {
-        lds_fill<4>(sD, lut + (size_t)b * kLutN, kLutN, tid, kSampleThreads);
-        if (slopes) lds_fill<4>(sWt, slopes + (size_t)b * kLutN, kLutN, tid, kSampleThreads);
-        if constexpr (COEF_LDS) lds_fill<4>(s_coef, pw, G * kCoefDoubles, tid, kSampleThreads);
+    // per path: the scalars of its grid and tables
+    int p_b[PPB], p_N[PPB], p_nruns[PPB];
+    bool p_live[PPB];
+    double p_tmax[PPB], p_total[PPB], p_dd[PPB], p_lstep[PPB], p_tstep[PPB], p_inv[PPB], p_sk[PPB];
+    double run_touch = 0.0;
+#pragma unroll
+    for (int pp = 0; pp < PPB; pp++) {
+        const int bq = blockIdx.y * PPB + pp;
+        p_live[pp] = bq < B;
+        const int b = p_live[pp] ? bq : B - 1;
+        p_b[pp] = b;
+        const double *m = meta + (size_t)b * kMetaStride;
+        p_tmax[pp] = m[0]; p_total[pp] = m[1]; p_dd[pp] = m[2];
+        p_N[pp] = (int)m[3];
+        const double *ax = aux + (size_t)b * kAuxStride;
+        p_lstep[pp] = ax[0]; p_tstep[pp] = ax[1]; p_inv[pp] = ax[2];
+        p_nruns[pp] = (int)ax[3];
+        // (touch the head of the run table now: its lookup below depends on meta / aux and would otherwise wait
+        // for memory a second time)
+        run_touch += runs[(size_t)b * kGridRunDoubles + (tid < 120 ? tid : 0)];
+    }
+    // the paths' tables are staged once and serve every tile of this workgroup; all loads first
+    {
+        constexpr int ITER = 4;
+        double vD[PPB][ITER], vW[PPB][ITER];
+#pragma unroll
+        for (int pp = 0; pp < PPB; pp++) {
+            const bool go = p_live[pp] && tile0 * tile < p_N[pp];
+#pragma unroll
+            for (int it = 0; it < ITER; it++) {
+                const int i = tid + it * kSampleThreads;
+                vD[pp][it] = (go && i < kLutN) ? lut[(size_t)p_b[pp] * kLutN + i] : 0.0;
+                vW[pp][it] = (go && slopes && i < kLutN) ? slopes[(size_t)p_b[pp] * kLutN + i] : 0.0;
+            }
+        }
+        static_assert(ITER * kSampleThreads >= kLutN, "one pass covers the table");
+        if constexpr (COEF_LDS) {
+#pragma unroll
+            for (int pp = 0; pp < PPB; pp++)
+                if (p_live[pp] && tile0 * tile < p_N[pp])
+                    lds_fill<4>(s_coef + (size_t)pp * G * kCoefDoubles, power + (size_t)p_b[pp] * G * kCoefDoubles, G * kCoefDoubles, tid,
+                                kSampleThreads);
+        }
+#pragma unroll
+        for (int pp = 0; pp < PPB; pp++) {
+#pragma unroll
+            for (int it = 0; it < ITER; it++) {
+                const int i = tid + it * kSampleThreads;
+                if (i < kLutN) {
+                    sD_all[pp * kLutN + i] = vD[pp][it];
+                    if (slopes) sWt_all[pp * kLutN + i] = vW[pp][it];
+                }
+            }
+        }
     }
     // MPG:112-122 distance grid: the reference accumulates current_dist += dd.  A thread's first sample of a
     // tile comes from the path's run table (that sum in closed form, vap_device.h), the following ones by the
     // reference's own addition.
-    const double *run_tab = runs + (size_t)b * kGridRunDoubles;
-    const int dd_exp = (__double2hiint(dd) >> 20) & 0x7ff;
-    auto grid_first = [&](int kb0) {
+    auto grid_first_of = [&](const double *run_tab, double dd, int N, int n_runs, int kb0) {
+        const int dd_exp = (__double2hiint(dd) >> 20) & 0x7ff;
         const int kf = kb0 < N - 1 ? kb0 : N - 1;
         // the run from the exponent of kf*dd: right except next to a binade boundary
         int r = 2 + 2 * (((__double2hiint((double)kf * dd) >> 20) & 0x7ff) - dd_exp);
@@ -582,29 +622,57 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int 
         return sa + (double)(kf - ka) * da;
     };
     // the first tile's lookup goes out together with the staging loads
-    const double sk_first = tile0 * tile < N ? grid_first(tile0 * tile + tid * kSPT) : 0.0;
+#pragma unroll
+    for (int pp = 0; pp < PPB; pp++)
+        p_sk[pp] = (p_live[pp] && tile0 * tile < p_N[pp])
+                       ? grid_first_of(runs + (size_t)p_b[pp] * kGridRunDoubles, p_dd[pp], p_N[pp], p_nruns[pp], tile0 * tile + tid * kSPT)
+                       : 0.0;
     if (!slopes) {
         // the interval slopes (t1 - t0)/(d1 - d0) of SM:311-317 from the staged distances — the expression k_lut uses, so
         // the same numbers, without 8 KB per path going to HBM and back (config 5: a fifth of the step's traffic)
         __syncthreads();
-        if (tile0 * tile < N) {
-            for (int j = tid; j < kLutN; j += kSampleThreads) {
-                double w = 0.0;
-                if (j > 0) {
-                    const double t0 = (double)(j - 1) * lstep, t1 = (j == kLutN - 1) ? t_max : (double)j * lstep;
-                    w = (t1 - t0) / (sD[j] - sD[j - 1]);
+#pragma unroll
+        for (int pp = 0; pp < PPB; pp++) {
+            if (p_live[pp] && tile0 * tile < p_N[pp]) {
+                const double *sDp = sD_all + pp * kLutN;
+                for (int j = tid; j < kLutN; j += kSampleThreads) {
+                    double w = 0.0;
+                    if (j > 0) {
+                        const double t0 = (double)(j - 1) * p_lstep[pp], t1 = (j == kLutN - 1) ? p_tmax[pp] : (double)j * p_lstep[pp];
+                        w = (t1 - t0) / (sDp[j] - sDp[j - 1]);
+                    }
+                    sWt_all[pp * kLutN + j] = w;
                 }
-                sWt[j] = w;
             }
         }
     }
     __syncthreads();
     asm volatile("" ::"v"(run_touch));
-    const double *coef = COEF_LDS ? s_coef : pw;
     const long long ts1 = stats ? __builtin_amdgcn_s_memtime() : 0;
     const double end_param = (double)(W - 1);
     const int tab_n = W * kSamplesPerNode;
+    int tiles_done = 0;   // parity of the neighbour exchange
 
+#pragma unroll 1
+    for (int pp = 0; pp < PPB; pp++) {
+    // (the path's scalars again, from the scalar cache: carrying them through the tile loop as arrays indexed by pp
+    // costs registers the tile body does not have)
+    const int bq = blockIdx.y * PPB + pp;
+    if (bq >= B) break;
+    const int b = bq;
+    const double *m = meta + (size_t)b * kMetaStride;
+    const double t_max = m[0], total = m[1], dd = m[2];
+    const int N = (int)m[3];
+    const double *ax = aux + (size_t)b * kAuxStride;
+    const double lstep = ax[0], tstep = ax[1], inv_tstep = ax[2];
+    const int n_runs = (int)ax[3];
+    const size_t row = (size_t)b * S;
+    const double *sD = sD_all + pp * kLutN, *sWt = sWt_all + pp * kLutN;
+    const double *pw = power + (size_t)b * G * kCoefDoubles;
+    const double *coef = COEF_LDS ? s_coef + (size_t)pp * G * kCoefDoubles : pw;
+    const double *run_tab = runs + (size_t)b * kGridRunDoubles;
+    const double sk_first = PPB == 1 ? p_sk[0] : (pp == 0 ? p_sk[0] : p_sk[PPB - 1]);
+    auto grid_first = [&](int kb0) { return grid_first_of(run_tab, dd, N, n_runs, kb0); };
     for (int tl = 0; tl < tiles_per_block; tl++) {
         const int k0 = (tile0 + tl) * tile;
         if (k0 >= S) break;
@@ -738,7 +806,8 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int 
             }
             vd[i] = (OT)0;
         }
-        const int pb = tl & 1;
+        const int pb = tiles_done & 1;
+        tiles_done++;
         s_dx[pb][tid] = d1x[0];
         s_dy[pb][tid] = d1y[0];
         s_j[pb][tid] = jjv[0];
@@ -781,6 +850,7 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int W, int S, int 
         if (interior) tile_body(std::true_type{});
         else tile_body(std::false_type{});
     }
+    }   // paths of this workgroup
     if (stats && (tid & 63) == 0) {
         long long *st = stats + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + (tid >> 6)) * 4;
         st[0] = ts1 - ts0;                                 // staging + barrier
@@ -2361,20 +2431,26 @@ hipError_t launch_sample(hipStream_t st, bool f64, int B, int W, int S, const do
     int split = (2048 + B - 1) / B;
     split = split < 1 ? 1 : (split > n_tiles ? n_tiles : split);
     const int tiles_per_block = (n_tiles + split - 1) / split;
-    const dim3 grid((n_tiles + tiles_per_block - 1) / tiles_per_block, B);
     const bool in_lds = (W - 1) <= kLdsCoefSegments;
-    const size_t lds = in_lds ? sizeof(double) * (size_t)(W - 1) * kCoefDoubles : 0;
+    // rows of one tile in large batches: two paths per workgroup (their staging loads in flight together)
+    const int ppb = (n_tiles == 1 && B >= 8192 && in_lds && (W - 1) <= 16) ? 2 : 1;
+    const dim3 grid((n_tiles + tiles_per_block - 1) / tiles_per_block, (B + ppb - 1) / ppb);
+    const size_t lds = in_lds ? sizeof(double) * (size_t)ppb * (W - 1) * kCoefDoubles : 0;
     // developer knob: VAP_SAMPLE_STATS=1 prints in-kernel cycle shares per wave (synchronises!)
     static const bool want_stats = getenv("VAP_SAMPLE_STATS") != nullptr;
     long long *stats = nullptr;
     const size_t n_waves = (size_t)grid.x * grid.y * 4;
     if (want_stats) (void)hipMalloc(&stats, n_waves * 4 * sizeof(long long));
-#define VAP_SAMPLE(OT_, LDS_, HI_)                                                                                 \
-    hipLaunchKernelGGL((k_sample<OT_, LDS_, HI_>), grid, dim3(kSampleThreads), lds, st, W, S, tile, tiles_per_block, pw, lut, \
+#define VAP_SAMPLE(OT_, LDS_, HI_, PPB_)                                                                            \
+    hipLaunchKernelGGL((k_sample<OT_, LDS_, HI_, PPB_>), grid, dim3(kSampleThreads), lds, st, B, W, S, tile, tiles_per_block, pw, lut, \
                        slopes, meta, aux, runs, (OT_ *)x, (OT_ *)y, (OT_ *)h, (OT_ *)k, (OT_ *)dth, k64, dth64, stats)
-    if (f64) { if (in_lds) VAP_SAMPLE(double, true, false); else VAP_SAMPLE(double, false, false); }
-    else if (hi) { if (in_lds) VAP_SAMPLE(float, true, true); else VAP_SAMPLE(float, false, true); }
-    else { if (in_lds) VAP_SAMPLE(float, true, false); else VAP_SAMPLE(float, false, false); }
+    if (ppb == 2) {
+        if (f64) VAP_SAMPLE(double, true, false, 2);
+        else if (hi) VAP_SAMPLE(float, true, true, 2);
+        else VAP_SAMPLE(float, true, false, 2);
+    } else if (f64) { if (in_lds) VAP_SAMPLE(double, true, false, 1); else VAP_SAMPLE(double, false, false, 1); }
+    else if (hi) { if (in_lds) VAP_SAMPLE(float, true, true, 1); else VAP_SAMPLE(float, false, true, 1); }
+    else { if (in_lds) VAP_SAMPLE(float, true, false, 1); else VAP_SAMPLE(float, false, false, 1); }
 #undef VAP_SAMPLE
     if (stats) {
         std::vector<long long> h(n_waves * 4);
