@@ -1056,3 +1056,28 @@ def test_two_paths_per_workgroup_sampling_is_bit_identical(torch_mod, dtype, kw)
     for k in ("x", "y", "heading", "curvature", "velocity", "meta"):
         both = np.concatenate([parts[0][k], parts[1][k]], axis=0)
         assert np.array_equal(whole[k], both, equal_nan=True), k
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_long_rows_on_two_streams_at_once(torch_mod, dtype):
+    """Two look-back launches in flight on two HIP streams (two contexts), each with more super-chunks than the chip
+    holds: a workgroup waits only for lower tickets of its OWN launch — workgroups that already run — so the two grids
+    cannot starve each other whatever the dispatcher interleaves.  Rows equal the sequential sweep's bit for bit, no
+    NOCONVERGE flag (a workgroup that gave up after its bounded wait would raise it)."""
+    from vexautonomousplanner_amd.synth import make_waypoints
+    B, W, S = 40, 16, 60001
+    wps = [make_waypoints(B, W, 300 + i).astype(np.float64) for i in range(2)]
+    refs = [run_gpu(torch_mod, make_gen(dtype, velocity_kernel="seq_fast"), w, samples=S)["velocity"] for w in wps]
+    gens = [make_gen(dtype, velocity_kernel="relax") for _ in range(2)]
+    streams = [torch_mod.cuda.Stream(device=gens[0].device) for _ in range(2)]
+    tens = [torch_mod.tensor(w, dtype=g.tdtype, device=g.device) for w, g in zip(wps, gens)]
+    torch_mod.cuda.synchronize()
+    outs = [None, None]
+    for rep in range(3):
+        for i in range(2):
+            with torch_mod.cuda.stream(streams[i]):
+                outs[i] = gens[i].profile(tens[i], samples=S, out=outs[i])
+        torch_mod.cuda.synchronize()
+        for i in range(2):
+            assert int(outs[i]["flags"].abs().sum().item()) == 0, (rep, i)
+            assert np.array_equal(outs[i]["velocity"].cpu().numpy().astype(np.float64), refs[i]), (rep, i)
