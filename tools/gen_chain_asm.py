@@ -25,7 +25,11 @@ slots 0..TS-1, backward tiles TS-1..0.
 import os
 import sys
 
-NB = 8                      # steps per batch (register bank = NB records)
+NB = 4                      # steps per batch (register bank = NB records): banks of four fit v64-v151, so the kernel's
+                            # waves fit 168 registers (three per SIMD); `--nb 8` writes the earlier banks of eight (v64-v239)
+for _i, _a in enumerate(sys.argv):
+    if _a == "--nb":
+        NB = int(sys.argv[_i + 1])
 BANK = [64, 64 + 10 * NB]   # first VGPR of bank A / B: NB*8 registers of {rho,g,am,A}, then NB*2 of cap
 RES = 64 + 20 * NB          # NB result pairs
 LAST = RES + 2 * NB - 1

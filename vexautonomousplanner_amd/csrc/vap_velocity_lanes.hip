@@ -34,15 +34,20 @@ namespace vap {
 
 namespace {
 
-constexpr int kLanesThreads = 512;
+constexpr int kLanesThreads = 768;                        // twelve waves: three per SIMD (the chain loop's banks of four steps leave room)
+constexpr int kLanesStats = 32;                           // long longs per workgroup of VAP_LANES_STATS
 constexpr int kLanesProducers = kLanesThreads / 64 - 1;   // wave 0 is the chain wave
 constexpr int kPairBytes = 80;                            // the records of two consecutive samples of a path (vap_chain_asm.h)
 constexpr int kTileRecords = 1024;                        // (path, sample) slots per tile = 16 producer batches of 64
 constexpr int kTileBatches = kTileRecords / 64;
-// Batches of a tile by producer wave: producer pw takes batches pw, pw + 7, pw + 14 — three for the first two waves, two
-// for the others.  (Waves of a workgroup go to the CU's four SIMDs in turn, so wave 4 shares SIMD 0 with the chain wave
-// and has that SIMD's vector pipe mostly to itself; giving it four batches and the others two was measured: it then sets
-// the step time, at ~950 cycles per batch against ~675 for a SIMD shared by two producers.)
+// Batches of a tile by producer wave: producer pw takes batches pw and pw + 11 — two for the first five waves, one for the
+// others.  Twelve waves = three per SIMD: the chain loop keeps its records in banks of FOUR steps (vap_chain_asm.h:
+// v64-v151; banks of eight, v64-v239, allowed two waves per SIMD), so every wave of the workgroup fits 168 registers
+// and a producer step — a chain of reciprocal / Newton latencies and LDS round trips — overlaps with two others on its
+// SIMD instead of one.  Measured (same box, alternating builds): both sweeps 1.31 M -> 1.22 M cycles at config 3, now within
+// 5 % of the chain loops themselves; step 1.005 -> 0.986 ms, config 4 share 1.967 -> 1.924, config 5 share 4.73 -> 4.66.
+// (A SIMD still works through its producers' batches at ~650 cycles each, oldest wave first; 16 batches over four SIMDs,
+// one of which hosts the chain, is 3 + 5 + 4 + 4.)
 constexpr int kBatchesPerProducer = (kTileBatches + kLanesProducers - 1) / kLanesProducers;
 __device__ __forceinline__ int batch_of(int wv, int i)   // tile batch i-th of wave wv, or -1
 {
@@ -297,7 +302,7 @@ struct Lanes {
 //            tile #(it-2)'s results out of result buffer it&1.
 // (tile #n of the backward sweep is tile NT-1-n of the row.)
 template <typename IO, int P, bool VCAP, bool ACC, bool FUSED>
-__global__ __launch_bounds__(kLanesThreads, 2) void k_velocity_lanes(int B, int S, VelConsts<double> c, double start_u, double end_u,
+__global__ __launch_bounds__(kLanesThreads, 3) void k_velocity_lanes(int B, int S, VelConsts<double> c, double start_u, double end_u,
                                                                      const double *__restrict__ meta,
                                                                      const double *__restrict__ curv,
                                                                      const double *__restrict__ dtheta,
@@ -420,7 +425,7 @@ __global__ __launch_bounds__(kLanesThreads, 2) void k_velocity_lanes(int B, int 
             lds_barrier();
         }
         if (stats && lane == 0) {
-            long long *st = stats + (size_t)blockIdx.x * 16;
+            long long *st = stats + (size_t)blockIdx.x * kLanesStats;
             st[0] = NT;
             st[1] = t_chain;                                   // cycles inside the forward chain loops
             st[2] = t_fwd_all;                                 // the forward sweep as the chain wave saw it
@@ -571,16 +576,16 @@ __global__ __launch_bounds__(kLanesThreads, 2) void k_velocity_lanes(int B, int 
 #pragma unroll
     for (int i = 0; i < kBatchesPerProducer; i++)
         if (ctx[i].live && saw_dup[i]) s_pdup[ctx[i].p] = 1;
-    if (stats && tid == 64) stats[(size_t)blockIdx.x * 16 + 5] = t_busy;   // producer 0 (three batches per tile), forward
+    if (stats && tid == 64) stats[(size_t)blockIdx.x * kLanesStats + 5] = t_busy;   // producer 0 (three batches per tile), forward
     // the turn: every forward value this workgroup stored has reached memory before any wave of it reads one back
     __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0) expcnt(0) lgkmcnt(0)
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < kBatchesPerProducer; i++) saw_dup[i] = s_pdup[ctx[i].p] != 0;
     sweep(std::true_type());
-    if (stats && tid == 64) stats[(size_t)blockIdx.x * 16 + 7] = t_busy;   // ... both sweeps
-    if (stats && tid == 64) stats[(size_t)blockIdx.x * 16 + 15] = L.t_take;   // producer 0: of that, waiting for its rows
-    if (stats && lane == 0) stats[(size_t)blockIdx.x * 16 + 8 + pw] = t_busy;   // every producer, both sweeps
+    if (stats && tid == 64) stats[(size_t)blockIdx.x * kLanesStats + 7] = t_busy;   // ... both sweeps
+    if (stats && tid == 64) stats[(size_t)blockIdx.x * kLanesStats + 31] = L.t_take;   // producer 0: of that, waiting for its rows
+    if (stats && lane == 0) stats[(size_t)blockIdx.x * kLanesStats + 8 + pw] = t_busy;   // every producer, both sweeps
     // rows longer than the longest path of the group: zeros past the last tile
     for (int p = 0; p < P; p++) {
         const int b = blockIdx.x * P + p;
@@ -625,8 +630,8 @@ hipError_t launch_lanes_p(hipStream_t st, int B, int S, const double c[6], doubl
     static const bool want_stats = getenv("VAP_LANES_STATS") != nullptr;
     long long *stats = nullptr;
     if (want_stats) {
-        (void)hipMalloc(&stats, (size_t)grid.x * 16 * sizeof(long long));
-        (void)hipMemsetAsync(stats, 0, (size_t)grid.x * 16 * sizeof(long long), st);
+        (void)hipMalloc(&stats, (size_t)grid.x * kLanesStats * sizeof(long long));
+        (void)hipMemsetAsync(stats, 0, (size_t)grid.x * kLanesStats * sizeof(long long), st);
     }
 #define VAP_LANES_LAUNCH(VCAP_, ACC_)                                                                                       \
     do {                                                                                                                    \
@@ -655,17 +660,18 @@ hipError_t launch_lanes_p(hipStream_t st, int B, int S, const double c[6], doubl
     else VAP_LANES_LAUNCH(false, false);
 #undef VAP_LANES_LAUNCH
     if (stats) {
-        std::vector<long long> h((size_t)grid.x * 16);
+        std::vector<long long> h((size_t)grid.x * kLanesStats);
         (void)hipStreamSynchronize(st);
         (void)hipMemcpy(h.data(), stats, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
         (void)hipFree(stats);
-        double sum[16] = {0};
+        double sum[kLanesStats] = {0};
         for (unsigned w = 0; w < grid.x; w++)
-            for (int k = 0; k < 16; k++) sum[k] += (double)h[(size_t)w * 16 + k] / grid.x;
-        fprintf(stderr, "[lanes P=%d, %u workgroups] tiles %.0f | mean ticks: forward chain loops %.0f of sweep %.0f | backward chain loops %.0f | both sweeps %.0f | producer 0 busy forward %.0f, both %.0f | per step: chain %.1f, sweep %.1f | backward tiles with a zero heading difference %.2f\n",
-                P, grid.x, sum[0], sum[1], sum[2], sum[3], sum[4], sum[5], sum[7], sum[1] / (sum[0] * G::TS), sum[2] / (sum[0] * G::TS), sum[6]);
-        fprintf(stderr, "        producers busy, both sweeps: %.0f %.0f %.0f %.0f %.0f %.0f %.0f | producer 0 waiting for its rows: %.0f\n", sum[8], sum[9],
-                sum[10], sum[11], sum[12], sum[13], sum[14], sum[15]);
+            for (int k = 0; k < kLanesStats; k++) sum[k] += (double)h[(size_t)w * kLanesStats + k] / grid.x;
+        fprintf(stderr, "[lanes P=%d, %u workgroups, %d producers] tiles %.0f | mean ticks: forward chain loops %.0f of sweep %.0f | backward chain loops %.0f | both sweeps %.0f | producer 0 busy forward %.0f, both %.0f | per step: chain %.1f, sweep %.1f | backward tiles with a zero heading difference %.2f\n",
+                P, grid.x, kLanesProducers, sum[0], sum[1], sum[2], sum[3], sum[4], sum[5], sum[7], sum[1] / (sum[0] * G::TS), sum[2] / (sum[0] * G::TS), sum[6]);
+        fprintf(stderr, "        producers busy, both sweeps:");
+        for (int k = 0; k < kLanesProducers; k++) fprintf(stderr, " %.0f", sum[8 + k]);
+        fprintf(stderr, " | producer 0 waiting for its rows: %.0f\n", sum[31]);
     }
     return hipGetLastError();
 }
