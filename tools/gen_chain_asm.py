@@ -33,6 +33,7 @@ for _i, _a in enumerate(sys.argv):
 BANK = [64, 64 + 10 * NB]   # first VGPR of bank A / B: NB*8 registers of {rho,g,am,A}, then NB*2 of cap
 RES = 64 + 20 * NB          # NB result pairs
 LAST = RES + 2 * NB - 1
+DUP_GN, DUP_C2 = LAST + 1, LAST + 3   # the sign-aware backward tiles: two more fixed register pairs
 TILES = (16, 32, 64)
 
 
@@ -66,12 +67,32 @@ def stores(first_slot):
     return [f"ds_write_b128 %[oaddr], v[{RES+4*m}:{RES+4*m+3}] offset:{8*(first_slot+2*m)}" for m in range(NB // 2)]
 
 
-def chain(bank, backward):
+def chain(bank, backward, dup=False):
     out = []
     order = range(NB - 1, -1, -1) if backward else range(NB)
+    if dup:
+        # the sign-aware backward step (MPG:52-59; vap_device.h fast_backward_a<true>): a record with g < 0 marks a zero
+        # heading difference, whose penalty is max(t, 0)*|g| instead of |t|*|g|.  With gn = (g < 0 ? 0 : g):
+        #     clamp01(am - max(t, other)*|g|) = clamp01(min(fma(-t, |g|, am), fma(t, gn, am)))    bit for bit
+        # (rounding is monotone; k_velocity_chase's bwd_step_dup2).  The gn of a bank's records do not depend on the
+        # state: they are formed in a block ahead of the dependent steps (three instructions per record, in place in
+        # two fixed registers past the banks, v[DUP_GN:DUP_GN+1]; the second FMA's result in v[DUP_C2:DUP_C2+1]).
+        assert backward
     for k in order:
         r = rec(bank, k)
         u, up = (res(k + 1), res(k + 2)) if backward else (res(k - 1), res(k - 2))
+        if dup:
+            g_lo, g_hi = r['g'][2:-1].split(':')
+            out.append(f"v_cmp_gt_f64 vcc, 0, {r['g']}")
+            out.append(f"v_cndmask_b32_e64 v{DUP_GN}, v{g_lo}, 0, vcc")
+            out.append(f"v_cndmask_b32_e64 v{DUP_GN+1}, v{g_hi}, 0, vcc")
+            out.append(f"v_fma_f64 %[t], -{r['rho']}, {up}, {u}")
+            out.append(f"v_fma_f64 v[{DUP_C2}:{DUP_C2+1}], %[t], v[{DUP_GN}:{DUP_GN+1}], {r['am']}")
+            out.append(f"v_fma_f64 %[t], -%[t], |{r['g']}|, {r['am']}")
+            out.append(f"v_min_f64 %[t], %[t], v[{DUP_C2}:{DUP_C2+1}] clamp")
+            out.append(f"v_fma_f64 %[t], {r['A']}, %[t], {u}")
+            out.append(f"v_min_f64 {res(k)}, %[t], {r['cap']}")
+            continue
         out.append(f"v_fma_f64 %[t], -{r['rho']}, {up}, {u}")
         out.append(f"v_fma_f64 %[t], -|%[t]|, |{r['g']}|, {r['am']} clamp")
         out.append(f"v_fma_f64 %[t], {r['A']}, %[t], {u}")
@@ -79,7 +100,7 @@ def chain(bank, backward):
     return out
 
 
-def tile(ts, backward, split):
+def tile(ts, backward, split, dup=False):
     nb = ts // NB
     slots = [(nb - 1 - n) * NB if backward else n * NB for n in range(nb)]   # first slot of batch n
     u_reg, up_reg = (RES, RES + 2) if backward else (RES + 2 * (NB - 1), RES + 2 * (NB - 2))
@@ -91,7 +112,7 @@ def tile(ts, backward, split):
     for n in range(nb):
         bank = n & 1
         lds = (stores(slots[n - 1]) if n > 0 else []) + (loads(bank ^ 1, slots[n + 1]) if n + 1 < nb else [])
-        ch = chain(bank, backward)
+        ch = chain(bank, backward, dup)
         if split and len(lds) > 15:
             # two LDS blocks of at most 15 operations (the lgkmcnt counter's range), each in front of half the steps
             h = 15 if len(lds) - 15 <= 15 else len(lds) // 2
@@ -105,10 +126,12 @@ def tile(ts, backward, split):
     return a
 
 
-def function(name, ts, backward, split):
-    lines = tile(ts, backward, split)
+def function(name, ts, backward, split, dup=False):
+    lines = tile(ts, backward, split, dup)
     body = "\n".join(f'        "{l}\\n\\t"' for l in lines)
-    clob = ", ".join(f'"v{i}"' for i in range(BANK[0], LAST + 1))
+    clob = ", ".join(f'"v{i}"' for i in range(BANK[0], (DUP_C2 + 2) if dup else (LAST + 1)))
+    if dup:
+        clob = '"vcc", ' + clob
     # wrap the clobber list
     words = clob.split(", ")
     clob = ",\n          ".join(", ".join(words[i:i + 12]) for i in range(0, len(words), 12))
@@ -137,7 +160,7 @@ HEADER = f"""// vap_chain_asm.h — GENERATED by tools/gen_chain_asm.py (edit th
 // slots 2m, 2m+1 are one 80-byte pair {{rho0, g0 | am0, A0 | rho1, g1 | am1, A1 | cap0, cap1}} (lane stride 80, pair stride
 // STRIDE bytes); one double per slot goes to oaddr + 8*slot.  u / up are the last two squared velocities (MPG:188-311
 // in the scaled four-instruction form of vap_device.h step4, bit for bit).  Registers v{BANK[0]}..v{LAST} are the two
-// record banks and the result pairs.
+// record banks and the result pairs; chain_bwd_dup_<TS> (the sign-aware step, MPG:52-59) also uses v{DUP_GN}..v{DUP_C2+1}.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -159,6 +182,8 @@ def main():
         out += "\n"
         out += function(f"chain_bwd_{ts}", ts, True, split)
         out += "\n"
+        out += function(f"chain_bwd_dup_{ts}", ts, True, split, True)
+        out += "\n"
     out += """// dispatch on the tile length
 template <int STRIDE, int TS>
 __device__ __forceinline__ void chain_fwd(uint32_t addr, uint32_t oaddr, double &u, double &up)
@@ -175,6 +200,15 @@ __device__ __forceinline__ void chain_bwd(uint32_t addr, uint32_t oaddr, double 
     if constexpr (TS == 16) chain_bwd_16<STRIDE>(addr, oaddr, u, up);
     else if constexpr (TS == 32) chain_bwd_32<STRIDE>(addr, oaddr, u, up);
     else chain_bwd_64<STRIDE>(addr, oaddr, u, up);
+}
+// ... a tile that holds a sample with a zero heading difference (g < 0): the sign-aware step on every slot
+template <int STRIDE, int TS>
+__device__ __forceinline__ void chain_bwd_dup(uint32_t addr, uint32_t oaddr, double &u, double &up)
+{
+    static_assert(TS == 16 || TS == 32 || TS == 64, "tile lengths the generator wrote");
+    if constexpr (TS == 16) chain_bwd_dup_16<STRIDE>(addr, oaddr, u, up);
+    else if constexpr (TS == 32) chain_bwd_dup_32<STRIDE>(addr, oaddr, u, up);
+    else chain_bwd_dup_64<STRIDE>(addr, oaddr, u, up);
 }
 
 }  // namespace vap

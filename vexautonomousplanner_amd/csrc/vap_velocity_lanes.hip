@@ -392,31 +392,10 @@ __global__ __launch_bounds__(kLanesThreads, 3) void k_velocity_lanes(int B, int 
                 if (!dup) {
                     chain_bwd<G::stride, TS>(rec0 + par * G::rec_bytes, out0 + par * G::out_bytes, u, up);
                 } else {
-                    // a path with a zero heading difference somewhere (dense grids): the sign-aware step, MPG:52-59
-                    const unsigned char *rt = L.rec + (size_t)par * G::rec_bytes;
-                    double *ot = L.out + (size_t)par * (G::out_bytes / 8) + lane * G::out_row;
-                    // (eight steps' records first, then the eight dependent steps, then their results: the loads of a
-                    // step do not wait behind the previous step's store)
-                    constexpr int NBs = 8;
-                    static_assert(TS % NBs == 0, "tile length");
-#pragma unroll 1
-                    for (int s0 = TS - NBs; s0 >= 0; s0 -= NBs) {
-                        double2 a[NBs], b2[NBs];
-                        double cap[NBs], r[NBs];
-#pragma unroll
-                        for (int k = 0; k < NBs; k++) {
-                            a[k] = *reinterpret_cast<const double2 *>(rt + G::rec_off(lane, s0 + k));
-                            b2[k] = *reinterpret_cast<const double2 *>(rt + G::rec_off(lane, s0 + k) + 16);
-                            cap[k] = *reinterpret_cast<const double *>(rt + G::cap_off(lane, s0 + k));
-                        }
-#pragma unroll
-                        for (int k = NBs - 1; k >= 0; k--) {
-                            u = fast_backward_a<true, false>(b2[k].x, a[k].x, a[k].y, b2[k].y, cap[k], u, up, 0.0);
-                            r[k] = u;
-                        }
-#pragma unroll
-                        for (int k = 0; k < NBs; k++) ot[s0 + k] = r[k];
-                    }
+                    // a path with a zero heading difference somewhere (dense grids): the sign-aware step, MPG:52-59, for the
+                    // whole tile — the same batched loop with the step in its two-FMA form (vap_chain_asm.h; on every other
+                    // sample the two steps are the same arithmetic)
+                    chain_bwd_dup<G::stride, TS>(rec0 + par * G::rec_bytes, out0 + par * G::out_bytes, u, up);
                     if (lane == 0) s_tdup[par] = 0;   // (the producers raise it again two steps on, behind a barrier)
                     dup_tiles++;
                 }
