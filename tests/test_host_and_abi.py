@@ -239,3 +239,15 @@ def test_update_routes_header_writes_the_reference_skeleton(tmp_path):
     tio.update_routes_header(str(path), "other", rows[:3])         # a second route goes in front of #endif
     lines = path.read_text().split("\n")
     assert sum(l.startswith("std::vector") for l in lines) == 2 and lines[-2] == "#endif"
+
+
+def test_generated_chain_loops_match_their_generator(tmp_path):
+    """vap_chain_asm.h (the lane-per-path kernel's chain loops, inline assembly) is written by tools/gen_chain_asm.py:
+    the committed header must be exactly what the generator writes, so that the two cannot drift apart."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "vap_chain_asm.h"
+    subprocess.run([sys.executable, os.path.join(root, "tools", "gen_chain_asm.py"), str(out)], check=True, capture_output=True)
+    committed = open(os.path.join(root, "vexautonomousplanner_amd", "csrc", "vap_chain_asm.h")).read()
+    assert out.read_text() == committed
