@@ -40,19 +40,21 @@ constexpr int kLanesProducers = kLanesThreads / 64 - 1;   // wave 0 is the chain
 constexpr int kPairBytes = 80;                            // the records of two consecutive samples of a path (vap_chain_asm.h)
 constexpr int kTileRecords = 1024;                        // (path, sample) slots per tile = 16 producer batches of 64
 constexpr int kTileBatches = kTileRecords / 64;
-// Batches of a tile by producer wave: producer pw takes batches pw and pw + 11 — two for the first five waves, one for the
-// others.  Twelve waves = three per SIMD: the chain loop keeps its records in banks of FOUR steps (vap_chain_asm.h:
+// Twelve waves = three per SIMD: the chain loop keeps its records in banks of FOUR steps (vap_chain_asm.h:
 // v64-v151; banks of eight, v64-v239, allowed two waves per SIMD), so every wave of the workgroup fits 168 registers
 // and a producer step — a chain of reciprocal / Newton latencies and LDS round trips — overlaps with two others on its
 // SIMD instead of one.  Measured (same box, alternating builds): both sweeps 1.31 M -> 1.22 M cycles at config 3, now within
 // 5 % of the chain loops themselves; step 1.005 -> 0.986 ms, config 4 share 1.967 -> 1.924, config 5 share 4.73 -> 4.66.
-// (A SIMD still works through its producers' batches at ~650 cycles each, oldest wave first; 16 batches over four SIMDs,
-// one of which hosts the chain, is 3 + 5 + 4 + 4.)
+// (A SIMD works through its producers' batches at ~650 cycles each, oldest wave first: batch_of below.)
 constexpr int kBatchesPerProducer = (kTileBatches + kLanesProducers - 1) / kLanesProducers;
+// Which batches a wave takes: waves go to the CU's four SIMDs in turn (wave w -> SIMD w % 4), the chain wave is wave 0, and
+// a SIMD works through its producers' batches oldest wave first — so the chain's SIMD gets the fewest: 2 + 5 + 5 + 4.
 __device__ __forceinline__ int batch_of(int wv, int i)   // tile batch i-th of wave wv, or -1
 {
-    const int q = wv - 1 + i * kLanesProducers;
-    return q < kTileBatches ? q : -1;
+    static_assert(kLanesProducers == 11 && kTileBatches == 16 && kBatchesPerProducer == 2, "the table below");
+    //                         wave:  0        1       2       3        4        5       6       7        8        9        10       11
+    constexpr int tab[12][2] = {{-1, -1}, {0, 1}, {2, 3}, {4, 5}, {6, -1}, {7, 8}, {9, 10}, {11, -1}, {12, -1}, {13, -1}, {14, -1}, {15, -1}};
+    return tab[wv][i];
 }
 
 template <int P>
