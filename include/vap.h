@@ -96,7 +96,7 @@ int vap_ctx_synchronize(vap_ctx *ctx);
  * kernel (config 2) are cut into super-chunks whose interface states are handed on by look-back inside one launch per
  * direction; RELAX_ROUNDS forces the earlier form of that kernel (one launch per super-round, convergence checked
  * on the host) — the same rows bit for bit (tests). */
-enum { VAP_OPT_VELOCITY_KERNEL = 0, VAP_OPT_F32_RECURRENCE = 1, VAP_OPT_FUSED_SAMPLING = 2 };
+enum { VAP_OPT_VELOCITY_KERNEL = 0, VAP_OPT_F32_RECURRENCE = 1, VAP_OPT_FUSED_SAMPLING = 2, VAP_OPT_TIME_DOMAIN_RESIDUAL = 3 };
 enum { VAP_VELOCITY_AUTO = 0, VAP_VELOCITY_SEQ_LITERAL = 1, VAP_VELOCITY_SEQ_FAST = 2, VAP_VELOCITY_RELAX = 3,
        VAP_VELOCITY_RELAX_BLOCK = 4 /* workgroup per path */, VAP_VELOCITY_RELAX_WAVE = 5 /* wave per path, fp32 */,
        VAP_VELOCITY_LANES = 6 /* lane per path, fp64 recurrence */, VAP_VELOCITY_LANES_16 = 7, VAP_VELOCITY_LANES_32 = 8,
@@ -114,6 +114,12 @@ enum { VAP_RECURRENCE_F64 = 0, VAP_RECURRENCE_F32 = 1 };
  * the fp64 curvature / heading-difference rows then reach the recurrence without a round trip through HBM.  Same rows,
  * bit for bit, as the separate sampling kernel (tests/test_gpu_fused.py); in its present form slower than the two
  * kernels, hence off. */
+/* VAP_OPT_TIME_DOMAIN_RESIDUAL (1 = on, the default; 0 = off): VAP_F32 calls with the fp64 recurrence also leave, in
+ * context scratch, what each stored fp32 velocity lost of the fp64 value (an fp32 residual row, 4 B per sample-point of
+ * extra writes).  A following vap_time_profile / vap_time_profile_routes that is handed that velocity row integrates
+ * row + residual (MPG:566-584) — the caller's row as it is at that moment plus a term below its own rounding — which
+ * is what keeps fp32 time-domain rows within 1e-5 of the reference.  Callers that never go to the time domain (pure
+ * distance-domain batches, e.g. candidate ranking) switch it off and save the traffic. */
 int vap_ctx_set_option(vap_ctx *ctx, int option, int value);
 /* Enable/disable per-stage hipEvent timing (replaces the reference's time.time() log lines,
  * SM:587-594, MPG:398-411).  Off by default. */
@@ -178,7 +184,7 @@ int vap_sample(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd, const
  * As in the reference, max_dec does not take part: boundary_map always contains sample 0 (MPG:110), so
  * forward_backward_pass replaces it with max_acc before its first step (MPG:194-196) and decelerates
  * with max_acc; max_dec is used by the time loop only (vap_time_profile, vap_route_motion_profile).
- * d_vcap: optional [B][S] (dtype) per-sample initial velocities — the `velocities` list the reference
+ * d_vcap: optional [B][S] (vap_limit_rows_dtype) per-sample initial velocities — the `velocities` list the reference
  * starts from (MPG:121,127,153,172: node / action-point max_velocity, 0.01 at stops); NULL = the
  * plain-node default max_vel with start/end velocities at the ends.  Entry 0 and the end sample are
  * taken from start_vel / end_vel.  Rows that fit the register-resident relaxation kernel (20 480
@@ -208,12 +214,19 @@ int vap_velocity_pass(vap_ctx *ctx, vap_dtype dt, int B, int S, const vap_constr
  *   d_node_stop                                   [B][W]  int32 (NULL: none)              MPG:126-127
  *   d_action_t                                    [B][M]  in route order, > 0; pad with +inf
  *   d_action_max_velocity / _max_acceleration / _stop [B][M]  (NULL arrays: none)         MPG:146-160
- *   d_vcap, d_acc_forward, d_acc_backward [B][S] (dtype) out; the three acceleration outputs are optional
- *                                    as a set (routes that do not change max_acceleration need only d_vcap)
+ *   d_vcap, d_acc_forward, d_acc_backward [B][S], d_dec_backward [B] out, of type vap_limit_rows_dtype(ctx, dt):
+ *                                    the three acceleration outputs are optional as a set (routes that do not
+ *                                    change max_acceleration need only d_vcap)
  *   d_node_sample [B][W], d_action_sample [B][M]  int32 out, optional: the sample at which each takes
  *                                    effect (node 0: 0; INT_MAX: never)
  * d_lut NULL = the table of the last vap_profile_batch.  Reverse / turn nodes are not covered here
  * (vap_route_* is the general single-route path); waits act in the time domain (vap_time_insert_waits). */
+/* Type of the limit rows (d_vcap, d_acc_forward, d_acc_backward, d_dec_backward) for rows of type dt in this context:
+ * the type of the recurrence they enter — VAP_F64 for fp64 rows and for fp32 rows in the default mode
+ * (VAP_RECURRENCE_F64: the fp64 recurrence amplifies an fp32-rounded limit such as 13.9 ft/s^2 past 1e-5, MPG:194-196,
+ * 256-257 / DESIGN.md section 3), VAP_F32 for fp32 rows with VAP_RECURRENCE_F32. */
+int vap_limit_rows_dtype(vap_ctx *ctx, vap_dtype dt);
+
 int vap_route_limits(vap_ctx *ctx, vap_dtype dt, int B, int W, int M, int S, const double *d_lut,
                      const double *d_meta, const double *d_node_max_velocity,
                      const double *d_node_max_acceleration, const int *d_node_stop, const double *d_action_t,

@@ -163,6 +163,10 @@ def run_case(mods, name, wp, dd=DEFAULT_DD, samples=None, node_attrs=None, actio
         n = len(vel)
         sel = np.unique(np.concatenate([np.arange(0, 512), np.arange(0, n, 997),
                                         np.arange(n // 2, n // 2 + 4096), np.arange(n - 512, n)]))
+        if keep == "dense_velocity":
+            # ... and the WHOLE velocity row: the recurrence amplifies, so its worst sample can sit
+            # anywhere; geometry stays strided
+            d["velocity_full"] = vel
     d["grid_idx"] = sel
     d["grid_t"] = ts[sel]
     d["grid_curvature"] = ks[sel]
@@ -364,12 +368,17 @@ def run_table_size_pins(mods):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--c2", action="store_true", help="also run the 1e6-sample single-path case")
+    ap.add_argument("--big", action="store_true", help="also the 2048-waypoint cases big_w2048_p* (~1-2 min of reference each)")
     ap.add_argument("--only", default=None)
+    ap.add_argument("--out", default=None, help="write the fixtures here instead of tests/golden/")
     args = ap.parse_args()
     if not refimport.available():
         print("reference tree absent: nothing to do")
         return
     mods = refimport.load()
+    if args.out:
+        global OUT
+        OUT = args.out
 
     def want(name):
         return args.only is None or args.only in name
@@ -400,6 +409,13 @@ def main():
     # other table entries (quirk: the grid is current_dist += dd, MPG:112-122)
     if want("runsum_w2000"):
         run_case(mods, "runsum_w2000", make_waypoints(1, 2000, 17)[0], dd=0.002, keep="runsum")
+    # the large-W randomized sweep's worst case (tools/fuzz_parity.py big, case 115: 5 paths x 2048 waypoints on the
+    # reference's own grid, dd drawn by the tool): ~4.1e5 samples per path, the 1000-entry arc-length table is sparse
+    # (2 segments per entry) and the recurrence amplifies last-bit differences; the whole velocity row is kept
+    big = make_waypoints(5, 2048, 640273585)
+    for p in range(5):
+        if args.big and want(f"big_w2048_p{p}"):
+            run_case(mods, f"big_w2048_p{p}", big[p], dd=0.0032122917796428277, keep="dense_velocity")
     # a 256-waypoint path on a moderate grid
     c2wp = make_waypoints(1, 256, 2)[0]
     if want("c2_w256_S20000"):

@@ -151,6 +151,83 @@ def test_fuzz_slice_random_shapes_robots_grids(torch_mod, dtype, tol):
     assert not fails, fails
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_large_w_worst_case_vs_reference_fixture(torch_mod, dtype):
+    """big_w2048_p2: the worst case of the large-W randomized sweep (tools/fuzz_parity.py big, case 115, path 2: 2048
+    waypoints, 415 173 samples on the reference's own grid) as the REAL reference computed it — the whole velocity row.
+    On such paths the 1000-entry arc-length table is sparse (2 segments per entry), curvature reaches the amplifying
+    regime and last-bit differences are multiplied up to 1e9 (the oracle itself is 7.9e-8 from the reference here,
+    tests/test_oracle_golden.py), so BOTH row types are held to north_star's 1e-5; geometry to the usual bounds."""
+    import golden_util as gu
+    torch = torch_mod
+    g = gu.load("big_w2048_p2")
+    N = int(g["n_samples"])
+    gen = make_gen(dtype)
+    got = run(torch, gen, g["waypoints"][None], constraints=g["constraints"], dd=float(g["dd"]), capacity=N + 2)
+    assert not got["flags"].any() and int(got["meta"][0, 3]) == N
+    ref_v = g["velocity_full"]
+    ev = np.abs(got["velocity"][0, :N] - ref_v) / ref_v
+    gi = g["grid_idx"]
+    geo = 1e-9 if dtype == "f64" else 1e-5
+    ek = np.max(np.abs(got["curvature"][0][gi] - g["grid_curvature"]) / np.maximum(np.abs(g["grid_curvature"]), 1e-2))
+    eh = np.max(np.abs(got["heading"][0][gi] - g["grid_heading"])) / np.pi
+    ex = np.max(np.abs(got["x"][0][gi] - g["grid_x"]) / np.maximum(np.abs(g["grid_x"]), 1.0))
+    print(f"big_w2048_p2/{dtype} vs the reference: velocity worst {ev.max():.2e} at sample {int(ev.argmax())} "
+          f"({int((ev > 1e-7).sum())} above 1e-7), curvature {ek:.2e} heading {eh:.2e} x {ex:.2e}")
+    assert ev.max() <= 1e-5 and ek <= geo and eh <= geo and ex <= geo
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("W", [113, 513, 2048])
+def test_large_w_slice_vs_oracle(torch_mod, dtype, W):
+    """The gated slice of `tools/fuzz_parity.py big`: paths of 113 / 513 / 2048 waypoints (past the LDS-resident
+    coefficient limit, up to the maximum), fixed-S grids and the reference's own dd grid, against the oracle.
+    Velocity bound 1e-5 for both row types (see test_large_w_worst_case_vs_reference_fixture: the oracle is itself
+    ~1e-7 from the reference on such paths); geometry 1e-5 / 1e-9."""
+    from oracle import oracle
+    from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
+    torch = torch_mod
+    rng = np.random.default_rng(9000 + W)
+    gen = make_gen(dtype)
+    worst = {}
+    for case in range(4):
+        B = int(rng.integers(1, 4))
+        seed = int(rng.integers(0, 1 << 30))
+        wp = make_waypoints(B, W, seed).astype(np.float32).astype(np.float64)
+        cons = list(DEFAULT_CONSTRAINTS)
+        if case % 2:
+            cons[0], cons[1], cons[5] = float(rng.uniform(1.0, 8.0)), float(rng.uniform(2.0, 16.0)), float(rng.uniform(0.5, 2.0))
+        if case < 2:        # the reference's own grid, ragged rows
+            dd = float(rng.uniform(0.003, 0.02))
+            per = []
+            for b in range(B):
+                op = oracle.OraclePath(wp[b])
+                op.rebuild_tables()
+                per.append(op.forward_backward(cons, dd=dd))
+            cap = max(len(p["velocity"]) for p in per) + 3
+            ref = {k: np.zeros((B, cap)) for k in ("x", "y", "heading", "curvature", "velocity")}
+            for b, pth in enumerate(per):
+                for k in ref:
+                    ref[k][b, :len(pth[k])] = pth[k]
+            pad = ref["velocity"] == 0
+            ref["velocity"][pad] = 1.0
+            got = run(torch, gen, wp, constraints=cons, dd=dd, capacity=cap)
+            assert np.array_equal(got["meta"][:, 3].astype(int), np.array([len(p["velocity"]) for p in per]))
+            assert np.all(got["velocity"][pad] == 0)
+            got["velocity"][pad] = 1.0
+        else:
+            S = int(rng.choice([4097, 10000, 30000]))
+            ref = oracle.profile_batch(wp, S, cons, n_threads=8)
+            got = run(torch, gen, wp, constraints=cons, samples=S)
+        assert not got["flags"].any()
+        e = {k: float(v.max()) for k, v in per_path_errors(got, ref).items()}
+        for k, v in e.items():
+            worst[k] = max(worst.get(k, 0.0), v)
+    print(f"large-W slice W={W}/{dtype}: worst " + " ".join(f"{k} {v:.2e}" for k, v in worst.items()))
+    geo = 1e-9 if dtype == "f64" else 1e-5
+    assert worst["velocity"] <= 1e-5 and all(worst[k] <= geo for k in ("curvature", "heading", "x", "y")), worst
+
+
 CONFIGS = {
     "c3": dict(paths=4096, W=32, S=10000, seed=3),          # BASELINE config 3
     "c4_share": dict(paths=8192, W=32, S=10000, seed=4),    # config 4: 65 536 paths over 8 GPUs

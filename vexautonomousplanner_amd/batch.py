@@ -32,12 +32,16 @@ class BatchedTrajectoryGenerator:
     """rebuild_tables + forward_backward_pass (SM:582-594, MPG:70-316) for B independent
     plain-node paths per call, outputs resident in HBM as (B, S) tensors."""
 
-    def __init__(self, device=0, dtype="f32", timing=False, velocity_kernel="auto", recurrence="f64", fused_sampling=False):
+    def __init__(self, device=0, dtype="f32", timing=False, velocity_kernel="auto", recurrence="f64", fused_sampling=False,
+                 time_domain_residual=True):
         """dtype "f32" | "f64": type of inputs and outputs.  recurrence (dtype "f32" only): "f64" (default) carries
         the velocity recurrence and its curvature / heading-difference rows in fp64 behind the fp32 outputs — the
         mode that holds 1e-5 against the reference on every path; "f32" is the all-fp32 recurrence (faster,
         ~1.4 % of config-3-shaped paths have a sample above 1e-5).  fused_sampling (VAP_OPT_FUSED_SAMPLING): the
-        default mode then samples large batches inside the velocity kernel (same rows; measured slower so far: off)."""
+        default mode then samples large batches inside the velocity kernel (same rows; measured slower so far: off).
+        time_domain_residual (VAP_OPT_TIME_DOMAIN_RESIDUAL, dtype "f32" with the fp64 recurrence): keep what every stored
+        fp32 velocity lost of its fp64 value (4 B per sample-point of extra writes) for a following time_profile();
+        False for batches that never go to the time domain."""
         if not torch.cuda.is_available():
             raise RuntimeError("no HIP device visible: vexautonomousplanner_amd has no CPU path")
         self.device = torch.device("cuda", device)
@@ -49,6 +53,9 @@ class BatchedTrajectoryGenerator:
         self.set_velocity_kernel(velocity_kernel)
         self.set_recurrence(recurrence)
         self.ctx.set_option(_lib.OPT_FUSED_SAMPLING, 1 if fused_sampling else 0)
+        self.time_domain_residual = bool(time_domain_residual)
+        self.ctx.set_option(_lib.OPT_TIME_DOMAIN_RESIDUAL, 1 if self.time_domain_residual else 0)
+        self._generation = 0
 
     def set_recurrence(self, which):
         """"f64" | "f32" (VAP_OPT_F32_RECURRENCE; only matters for dtype "f32")."""
@@ -91,7 +98,7 @@ class BatchedTrajectoryGenerator:
             ddv = float(dd)
             S = int(capacity) if capacity is not None else int(np.ceil(64.0 / ddv)) + 2
         c = _lib.make_constraints(constraints)
-        res = ProfileResult() if out is None else (out if isinstance(out, ProfileResult) else ProfileResult(out))
+        res = self._result_for(out)
         for f in FIELDS:
             if f in want or f == "velocity":
                 t = res.get(f)
@@ -115,20 +122,31 @@ class BatchedTrajectoryGenerator:
                                        C.c_void_p(res["flags"].data_ptr()))
         _lib.check(st, "vap_profile_batch")
         self._last_shape = (B, W, S)
-        self._stamp(res)
+        return self._stamp(res, out)
+
+    @staticmethod
+    def _result_for(out):
+        """The dict the tensors of a call go into: a fresh ProfileResult, the caller's ProfileResult, or — for a plain
+        dict passed as out= — a ProfileResult view that starts from its entries (the caller's dict is filled in place
+        as well: _stamp copies the entries back)."""
+        if out is None:
+            return ProfileResult()
+        return out if isinstance(out, ProfileResult) else ProfileResult(out)
+
+    def _stamp(self, res, out=None):
+        """The context keeps rows of the batch it sampled last (tables, fp64 curvature / heading-difference rows, the
+        velocity residual): a result is tied to them by (this generator, generation number), and the follow-up calls
+        refuse a result of another generator or one that a later profile()/profile_routes() call has superseded."""
+        self._generation += 1
+        res.generation = (id(self), self._generation)
+        if out is not None and out is not res:      # a plain dict as out=: it receives every tensor of the call too
+            out.update(res)
         return res
 
-    def _stamp(self, res):
-        """The context keeps rows of the batch it sampled last (tables, fp64 curvature / heading-difference rows, the
-        fp64 velocities): a result dict is tied to them by a generation number, and the follow-up calls refuse a result
-        that another profile()/profile_routes() call of this generator has superseded."""
-        self._generation = getattr(self, "_generation", 0) + 1
-        res.generation = self._generation
-
     def _check_current(self, result, what):
-        if getattr(result, "generation", None) != getattr(self, "_generation", None):
-            raise ValueError(f"{what} needs the result of this generator's LAST profile()/profile_routes() call: the context "
-                             "rows it reads belong to a later batch")
+        if getattr(result, "generation", None) != (id(self), self._generation):
+            raise ValueError(f"{what} needs the ProfileResult of THIS generator's LAST profile()/profile_routes() call: the "
+                             "context rows it reads belong to another batch")
 
     def profile_routes(self, waypoints, node_reverse=None, node_turn=None, node_tangent=None, node_magnitudes=None,
                        constraints=DEFAULT_CONSTRAINTS, samples=None, dd=None, start_vel=START_VEL, end_vel=END_VEL,
@@ -167,7 +185,7 @@ class BatchedTrajectoryGenerator:
             ddv = float(dd)
             S = int(capacity) if capacity is not None else int(np.ceil(64.0 / ddv)) + 2
         c = _lib.make_constraints(constraints)
-        res = ProfileResult() if out is None else (out if isinstance(out, ProfileResult) else ProfileResult(out))
+        res = self._result_for(out)
         for f in FIELDS:
             if f in want or f == "velocity":
                 t = res.get(f)
@@ -188,8 +206,7 @@ class BatchedTrajectoryGenerator:
                                         ptr(res["spline_counts"]))
         _lib.check(st, "vap_profile_routes")
         self._last_shape = (B, W, S)
-        self._stamp(res)
-        return res
+        return self._stamp(res, out)
 
     def time_profile(self, result, constraints=DEFAULT_CONSTRAINTS, dt=0.01, capacity_rows=None, out=None, node_reverse=None):
         """Time-domain resample (the loop of generate_motion_profile, MPG:413-628) of the batch that
@@ -274,10 +291,13 @@ class BatchedTrajectoryGenerator:
         dev = self.device
         d = {k: torch.tensor(v, device=dev) for k, v in dict(mv=mv, ma=ma, stop=stop.astype(np.int32), ap_t=ap_t, ap_mv=ap_mv,
                                                                ap_ma=ap_ma, ap_stop=ap_stop).items()}
-        vcap = torch.empty((B, S), dtype=self.tdtype, device=dev)
-        acc_f = torch.empty((B, S), dtype=self.tdtype, device=dev) if with_acc else None
-        acc_b = torch.empty((B, S), dtype=self.tdtype, device=dev) if with_acc else None
-        dec_b = torch.empty((B,), dtype=self.tdtype, device=dev) if with_acc else None
+        # the limit rows have the type of the recurrence they enter (vap_limit_rows_dtype): fp64 in the default mode — an
+        # fp32-rounded limit (13.9 ft/s^2) is amplified by the recurrence past 1e-5
+        ldt = torch.float64 if self._L.vap_limit_rows_dtype(self.ctx.handle, self.vdtype) == _lib.VAP_F64 else torch.float32
+        vcap = torch.empty((B, S), dtype=ldt, device=dev)
+        acc_f = torch.empty((B, S), dtype=ldt, device=dev) if with_acc else None
+        acc_b = torch.empty((B, S), dtype=ldt, device=dev) if with_acc else None
+        dec_b = torch.empty((B,), dtype=ldt, device=dev) if with_acc else None
         node_k = torch.empty((B, W), dtype=torch.int32, device=dev)
         ap_k = torch.empty((B, max(M, 1)), dtype=torch.int32, device=dev)
         c = _lib.make_constraints(constraints)

@@ -66,14 +66,23 @@ int run_velocity(vap_ctx *ctx, bool f64, bool io64, int B, int S, const double c
                  const void *curv, const void *dth, const void *vcap, const vap::AccRowsV &acc, void *vel, uint32_t *flags)
 {
     int mode = ctx->velocity_kernel;
-    ctx->vhi_for = nullptr;
-    const bool want_hi = f64 && !io64;   // fp32 rows behind the fp64 recurrence: the velocities stay on the context in fp64
-    auto keep_hi = [&](const void *rows, bool is_res = false) {
-        ctx->vhi_ptr = rows;
-        ctx->vhi_is_res = is_res;
-        ctx->vhi_for = vel;
-        ctx->vhi_B = B;
-        ctx->vhi_S = S;
+    ctx->vres_for = nullptr;
+    // fp32 rows behind the fp64 recurrence: what the fp32 row lost of the fp64 velocities stays on the context as an fp32
+    // residual row (VAP_OPT_TIME_DOMAIN_RESIDUAL, on by default) — the lane-per-path kernel writes it itself, the others
+    // leave an fp64 row in scratch, converted here.  Always the residual form: the time domain then integrates the caller's
+    // row AS IT IS at that call plus a term below its rounding, so an edited row is integrated as edited and a reused
+    // address costs at most that rounding.
+    const bool want_hi = f64 && !io64 && ctx->keep_residual;
+    auto keep_res = [&]() {
+        ctx->vres_for = vel;
+        ctx->vres_B = B;
+        ctx->vres_S = S;
+    };
+    auto keep_hi = [&](const void *rows64) -> int {
+        VAP_TRY(ctx->ensure(ctx->vres, (size_t)B * S * sizeof(float)));
+        HIP_TRY(vap::launch_velocity_residual(ctx->stream, (size_t)B * S, (const double *)rows64, (const float *)vel, (float *)ctx->vres.ptr));
+        keep_res();
+        return VAP_OK;
     };
     // per-sample initial velocities: the register-resident relaxation kernel takes them, the two-level one for
     // long rows and the wave-per-path variant do not (the sequential sweep does)
@@ -87,13 +96,15 @@ int run_velocity(vap_ctx *ctx, bool f64, bool io64, int B, int S, const double c
         float *vres = nullptr;
         if (!io64) {
             VAP_TRY(ctx->ensure(ctx->ufwd, (size_t)B * S * 8));
-            VAP_TRY(ctx->ensure(ctx->vhi, (size_t)B * S * sizeof(float)));
             ufwd = ctx->ufwd.ptr;
-            vres = (float *)ctx->vhi.ptr;
+            if (want_hi) {
+                VAP_TRY(ctx->ensure(ctx->vres, (size_t)B * S * sizeof(float)));
+                vres = (float *)ctx->vres.ptr;
+            }
         }
         const int group = mode == VAP_VELOCITY_LANES ? 0 : (mode == VAP_VELOCITY_LANES_16 ? 16 : (mode == VAP_VELOCITY_LANES_32 ? 32 : 64));
         HIP_TRY(vap::launch_velocity_lanes(ctx->stream, io64, B, S, cc, sv, ev, meta, curv, dth, vcap, acc, vel, ufwd, group, vres));
-        if (want_hi) keep_hi(vres, true);
+        if (want_hi) keep_res();
         return VAP_OK;
     }
     if (mode == VAP_VELOCITY_AUTO)
@@ -124,7 +135,7 @@ int run_velocity(vap_ctx *ctx, bool f64, bool io64, int B, int S, const double c
                 vhi = ctx->ufwd.ptr;
             }
             HIP_TRY(vap::launch_velocity_relax(ctx->stream, f64, io64, B, S, cc, sv, ev, meta, curv, dth, vcap, acc, vel, flags, vhi));
-            if (want_hi) keep_hi(vhi);
+            if (want_hi) VAP_TRY(keep_hi(vhi));
         } else {
             // long rows: two-level relaxation; its scratch row holds the forward values until the backward sweep has
             // read them, so the fp64 velocities get a row of their own.  Interfaces between super-chunks are handed on
@@ -144,7 +155,7 @@ int run_velocity(vap_ctx *ctx, bool f64, bool io64, int B, int S, const double c
             else
                 HIP_TRY(vap::launch_velocity_chase(ctx->stream, f64, io64, B, S, cc, sv, ev, meta, curv, dth, vel, flags,
                                                    ctx->ufwd.ptr, ctx->lstate.ptr, (int *)ctx->lcount.ptr, vhi));
-            if (want_hi) keep_hi(vhi);
+            if (want_hi) VAP_TRY(keep_hi(vhi));
         }
     } else {
         void *usq = nullptr;
@@ -154,27 +165,22 @@ int run_velocity(vap_ctx *ctx, bool f64, bool io64, int B, int S, const double c
         }
         HIP_TRY(vap::launch_velocity_seq(ctx->stream, f64, io64, mode == VAP_VELOCITY_SEQ_FAST, B, S, cc, sv, ev, meta, curv,
                                          dth, vcap, acc, vel, usq));
-        if (want_hi) keep_hi(usq);
+        if (want_hi) VAP_TRY(keep_hi(usq));
     }
     return VAP_OK;
 }
 
-// The velocity row a time-domain entry point integrates: the caller's, or — fp32 rows whose velocity pass ran the
-// fp64 recurrence in this context — the fp64 velocities that pass left behind (MPG:566-584 integrates positions
-// from the row; an fp32 row moves a position by ~1e-7 relative, now and then across a boundary of the reference's
-// step lookup, SM:550-580).
+// The velocity row a time-domain entry point integrates: always the caller's, as it is now — plus, for an fp32 row whose
+// velocity pass ran the fp64 recurrence in this context, the fp32 residual that pass left behind (row + residual = the
+// fp64 velocity to 2^-48; MPG:566-584 integrates positions from the row, and an fp32 row alone moves a position by ~1e-7
+// relative, now and then across a boundary of the reference's step lookup, SM:550-580).  The residual is below the
+// row's own rounding, so a row the caller has edited since is integrated as edited.
 const void *time_domain_velocity(vap_ctx *ctx, vap_dtype dt, int B, int S, const void *d_velocity, bool &is64, const float *&vres)
 {
     is64 = dt == VAP_F64;
     vres = nullptr;
-    if (dt == VAP_F32 && ctx->vhi_for == d_velocity && ctx->vhi_ptr && ctx->vhi_B == B && ctx->vhi_S == S) {
-        if (ctx->vhi_is_res) {          // the fp32 row plus what it lost
-            vres = (const float *)ctx->vhi_ptr;
-            return d_velocity;
-        }
-        is64 = true;
-        return ctx->vhi_ptr;
-    }
+    if (dt == VAP_F32 && ctx->vres_for == d_velocity && ctx->vres.ptr && ctx->vres_B == B && ctx->vres_S == S)
+        vres = (const float *)ctx->vres.ptr;
     return d_velocity;
 }
 
@@ -238,7 +244,7 @@ int vap_ctx_destroy(vap_ctx *ctx)
     if (!ctx) return VAP_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    VapBuffer *bufs[] = {&ctx->sptab, &ctx->nspl, &ctx->k64, &ctx->dth64, &ctx->ufwd, &ctx->vhi, &ctx->lstate, &ctx->lcount, &ctx->seg, &ctx->power, &ctx->lut, &ctx->slopes, &ctx->aux, &ctx->runs, &ctx->meta, &ctx->dth, &ctx->flags, &ctx->small_in,
+    VapBuffer *bufs[] = {&ctx->sptab, &ctx->nspl, &ctx->k64, &ctx->dth64, &ctx->ufwd, &ctx->vhi, &ctx->vres, &ctx->lstate, &ctx->lcount, &ctx->seg, &ctx->power, &ctx->lut, &ctx->slopes, &ctx->aux, &ctx->runs, &ctx->meta, &ctx->dth, &ctx->flags, &ctx->small_in,
                       &ctx->small_out, &ctx->small_seg, &ctx->small_lut};
     for (VapBuffer *b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
@@ -274,6 +280,11 @@ int vap_ctx_set_option(vap_ctx *ctx, int option, int value)
     }
     if (option == VAP_OPT_FUSED_SAMPLING && (value == 0 || value == 1)) {
         ctx->fused_sampling = value;
+        return VAP_OK;
+    }
+    if (option == VAP_OPT_TIME_DOMAIN_RESIDUAL && (value == 0 || value == 1)) {
+        ctx->keep_residual = value;
+        ctx->vres_for = nullptr;
         return VAP_OK;
     }
     if (option == VAP_OPT_F32_RECURRENCE && (value == VAP_RECURRENCE_F64 || value == VAP_RECURRENCE_F32)) {
@@ -388,6 +399,12 @@ int vap_velocity_pass_limits(vap_ctx *ctx, vap_dtype dt, int B, int S, const vap
     const bool any_acc = d_acc_forward || d_acc_backward || d_dec_backward;
     if (any_acc && !(d_acc_forward && d_acc_backward && d_dec_backward && d_vcap))
         return vap_fail(VAP_ERR_INVALID, "max_acceleration rows come as a set (forward, backward, dec) together with d_vcap");
+    // The limit rows have the type of the recurrence they enter (vap_limit_rows_dtype): a limit such as 13.9 ft/s^2 rounded
+    // to fp32 and then amplified by the fp64 recurrence left the 1e-5 bound.  An explicit fp32
+    // d_dtheta makes this call an fp32 recurrence, which cannot take the fp64 limit rows of the default mode.
+    if (dt == VAP_F32 && d_dtheta && (d_vcap || any_acc) && ctx->f32_recurrence == VAP_RECURRENCE_F64)
+        return vap_fail(VAP_ERR_INVALID, "VAP_F32 with VAP_RECURRENCE_F64: the limit rows are fp64 and go with the context's fp64 rows "
+                                         "(d_dtheta = NULL); for an fp32 recurrence on caller rows set VAP_OPT_F32_RECURRENCE first");
     bool r64 = dt == VAP_F64;
     if (!d_dtheta) {    // the rows the last sampling call of this shape and dtype left on the context
         if (!ctx->rows_valid || ctx->grid_B != B || ctx->grid_S != S || ctx->rows_dt != (int)dt)
@@ -415,6 +432,12 @@ int vap_velocity_pass_limits(vap_ctx *ctx, vap_dtype dt, int B, int S, const vap
     VAP_TRY(run_velocity(ctx, r64, dt == VAP_F64, B, S, cc, start_vel, end_vel, d_meta, d_curvature, d_dtheta, d_vcap, acc,
                          d_velocity, d_flags));
     return VAP_OK;
+}
+
+int vap_limit_rows_dtype(vap_ctx *ctx, vap_dtype dt)
+{
+    if (!ctx) return (int)dt;
+    return (dt == VAP_F64 || ctx->f32_recurrence == VAP_RECURRENCE_F64) ? (int)VAP_F64 : (int)VAP_F32;
 }
 
 int vap_velocity_pass(vap_ctx *ctx, vap_dtype dt, int B, int S, const vap_constraints *c, double start_vel,
@@ -494,18 +517,16 @@ int vap_profile_batch(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd
     if (fused) {
         tm.mark(VAP_T_SAMPLE);
         VAP_TRY(ctx->ensure(ctx->ufwd, n_pts * sizeof(double)));
-        VAP_TRY(ctx->ensure(ctx->vhi, n_pts * sizeof(float)));
-        ctx->vhi_for = nullptr;
+        VAP_TRY(ctx->ensure(ctx->vres, n_pts * sizeof(float)));
+        ctx->vres_for = nullptr;
         HIP_TRY(vap::launch_sample_velocity_fused(ctx->stream, B, W, S, cc, start_vel, end_vel, meta, (const double *)ctx->power.ptr,
                                                   (const double *)ctx->lut.ptr, (const double *)ctx->aux.ptr,
                                                   (const double *)ctx->runs.ptr, (float *)d_x, (float *)d_y, (float *)d_heading,
                                                   (float *)d_curvature, (double *)ctx->k64.ptr, (double *)ctx->dth64.ptr,
-                                                  (float *)d_velocity, (double *)ctx->ufwd.ptr, (float *)ctx->vhi.ptr));
-        ctx->vhi_ptr = ctx->vhi.ptr;
-        ctx->vhi_is_res = true;
-        ctx->vhi_for = d_velocity;
-        ctx->vhi_B = B;
-        ctx->vhi_S = S;
+                                                  (float *)d_velocity, (double *)ctx->ufwd.ptr, (float *)ctx->vres.ptr));
+        ctx->vres_for = d_velocity;
+        ctx->vres_B = B;
+        ctx->vres_S = S;
     } else {
         HIP_TRY(vap::launch_sample(ctx->stream, f64, B, W, S, (const double *)ctx->power.ptr, (const double *)ctx->lut.ptr, nullptr,
                                    meta, (const double *)ctx->aux.ptr, (const double *)ctx->runs.ptr, d_x, d_y, d_heading,
@@ -683,7 +704,7 @@ int vap_route_limits(vap_ctx *ctx, vap_dtype dt, int B, int W, int M, int S, con
         rt.nspl = (const int *)ctx->nspl.ptr;
         rt.NS = ctx->route_NS;
     }
-    HIP_TRY(vap::launch_route_limits(ctx->stream, dt == VAP_F64, B, W, M, S, lut, d_meta, (const double *)ctx->aux.ptr,
+    HIP_TRY(vap::launch_route_limits(ctx->stream, vap_limit_rows_dtype(ctx, dt) == VAP_F64, B, W, M, S, lut, d_meta, (const double *)ctx->aux.ptr,
                                      (const double *)ctx->runs.ptr, in, node_k, ap_k, ev_k, ev_mv, ev_ma, ev_stop, d_vcap,
                                      d_acc_forward, d_acc_backward, d_dec_backward, rt));
     if (d_node_sample) HIP_TRY(hipMemcpyAsync(d_node_sample, node_k, sizeof(int) * (size_t)B * W, hipMemcpyDeviceToDevice, ctx->stream));

@@ -41,14 +41,14 @@ struct vap_ctx {
     // scratch arena (grow-only, reused across calls)
     VapBuffer seg, power, lut, slopes, aux, runs, meta, dth, flags, io[8], small_in, small_out, small_seg, small_lut;
     VapBuffer ufwd, lstate, lcount;   // long-row velocity pass
-    // VAP_F32 with the fp64 recurrence: the velocity pass also leaves its fp64 velocities for the time-domain entry
-    // points — valid for exactly the fp32 velocity row vhi_for of a [vhi_B][vhi_S] batch — either as an fp64 row in
-    // vhi_ptr (ufwd or vhi), or (vhi_is_res, the lane-per-path kernel) as the fp32 residual row v64 - (double)(float)v64
-    // next to the caller's fp32 row
-    VapBuffer vhi;
-    const void *vhi_ptr = nullptr, *vhi_for = nullptr;
-    int vhi_B = 0, vhi_S = 0;
-    bool vhi_is_res = false;
+    // VAP_F32 with the fp64 recurrence (and VAP_OPT_TIME_DOMAIN_RESIDUAL on): the velocity pass also leaves, for the
+    // time-domain entry points, the fp32 residual row v64 - (double)(float)v64 of the fp32 velocity row vres_for of a
+    // [vres_B][vres_S] batch (the lane-per-path kernel writes it itself; the others leave fp64 velocities in `vhi` /
+    // `ufwd`, converted right after the launch).  Row + residual is the fp64 velocity to 2^-48.
+    VapBuffer vhi, vres;
+    const void *vres_for = nullptr;
+    int vres_B = 0, vres_S = 0;
+    int keep_residual = 1;    // VAP_OPT_TIME_DOMAIN_RESIDUAL
     VapBuffer k64, dth64;             // fp64 curvature / |dtheta| rows behind fp32 outputs (VAP_RECURRENCE_F64)
     VapBuffer sptab, nspl;            // spline tables of the last vap_profile_routes batch
     int route_NS = 0;                 // > 0: seg / lut hold a batch of routes with up to route_NS splines each

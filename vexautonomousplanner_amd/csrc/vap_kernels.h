@@ -95,6 +95,8 @@ size_t velocity_chase_counter_bytes(int B);
 hipError_t launch_velocity_chase(hipStream_t st, bool f64, bool io64, int B, int S, const double c[6], double sv, double ev,
                                  const double *meta, const void *curv, const void *dth, void *vel, uint32_t *flags,
                                  void *ufwd, void *state, int *counters, void *vhi = nullptr);
+// res[i] = (float)(v64[i] - (double)v32[i]): the fp32 residual row the time domain adds back to the caller's fp32 row
+hipError_t launch_velocity_residual(hipStream_t st, size_t n, const double *v64, const float *v32, float *res);
 // K5w (vap_velocity_lanes.hip), fp64 recurrence only: lane per path, `group` paths per workgroup (0 = by batch size).
 // ufwd: [B][S] doubles of scratch for the forward sweep's squared velocities (unused when io64: the rows are used in place)
 // vres (fp32 rows): [B][S] floats, v64 - (double)(float)v64 of every velocity written (what the time domain adds back)

@@ -879,7 +879,7 @@ template <typename R, typename IO, bool FAST>
 __global__ __launch_bounds__(64) void k_velocity_seq(int B, int S, VelConsts<R> c, R start_u, R end_u,
                                                      const double *__restrict__ meta,
                                                      const R *__restrict__ curv, const R *__restrict__ dtheta,
-                                                     const IO *__restrict__ vcap, AccRows<IO> acc, IO *__restrict__ vel,
+                                                     const R *__restrict__ vcap, AccRows<R> acc, IO *__restrict__ vel,
                                                      R *__restrict__ usq)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1129,7 +1129,7 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
                                                                const double *__restrict__ meta,
                                                                const R *__restrict__ curv,
                                                                const R *__restrict__ dtheta,
-                                                               const IO *__restrict__ vcap, AccRows<IO> acc,
+                                                               const R *__restrict__ vcap, AccRows<R> acc,
                                                                IO *__restrict__ vel, uint32_t *__restrict__ flags,
                                                                long long *__restrict__ stats, R *__restrict__ vhi)
 {
@@ -1230,7 +1230,7 @@ __global__ __launch_bounds__(MAXT, MINW) void k_velocity_relax(int S, VelConsts<
     if constexpr (VCAP) {
         // the forward step into sample j (1 <= j <= N-2; the end sample is fixed by the backward sweep) also
         // honours the sample's initial velocity: min(.., cap, vcap^2) — one number per slot
-        const IO *VC = vcap + row;
+        const R *VC = vcap + row;
 #pragma unroll
         for (int s0 = 0; s0 < L; s0 += BK) {    // BK loads in flight, then BK selects (as the phases above)
             R vc[BK];
@@ -2484,12 +2484,12 @@ static void launch_seq_t(hipStream_t st, bool fast, int B, int S, const double c
                          const void *curv, const void *dth, const void *vcap, const AccRowsV &accv, void *vel, void *usq)
 {
     const dim3 grid((B + 63) / 64);
-    AccRows<IO> acc;
-    acc.fwd = (const IO *)accv.fwd; acc.bwd = (const IO *)accv.bwd; acc.dec = (const IO *)accv.dec;
+    AccRows<R> acc;   // (limit rows have the recurrence's arithmetic type)
+    acc.fwd = (const R *)accv.fwd; acc.bwd = (const R *)accv.bwd; acc.dec = (const R *)accv.dec;
     const R s = (R)sv, e = (R)ev;
     auto k = fast ? k_velocity_seq<R, IO, true> : k_velocity_seq<R, IO, false>;
     hipLaunchKernelGGL(k, grid, dim3(64), 0, st, B, S, make_consts<R>(c), s * s, e * e, meta, (const R *)curv,
-                       (const R *)dth, (const IO *)vcap, acc, (IO *)vel, (R *)usq);
+                       (const R *)dth, (const R *)vcap, acc, (IO *)vel, (R *)usq);
 }
 
 // r64: arithmetic (and curvature / dtheta rows) in fp64; io64: the caller's rows (vcap, acc, vel) are fp64.
@@ -2516,10 +2516,10 @@ static void launch_relax_t(hipStream_t st, int B, int S, const double c[6], doub
                            const double *meta, const void *curv, const void *dth, const void *vcap, const AccRowsV &accv,
                            void *vel, uint32_t *flags, void *vhi)
 {
-    AccRows<IO> acc;
-    acc.fwd = (const IO *)accv.fwd;
-    acc.bwd = (const IO *)accv.bwd;
-    acc.dec = (const IO *)accv.dec;
+    AccRows<R> acc;   // (limit rows have the recurrence's arithmetic type)
+    acc.fwd = (const R *)accv.fwd;
+    acc.bwd = (const R *)accv.bwd;
+    acc.dec = (const R *)accv.dec;
     int T = (S + L - 1) / L;
     T = (T + 63) / 64 * 64;
     const R s = (R)sv, e = (R)ev;
@@ -2530,13 +2530,13 @@ static void launch_relax_t(hipStream_t st, int B, int S, const double c[6], doub
     const size_t lds = sizeof(R) * ((size_t)T * L + T + 8);
     if constexpr (ACC)
         hipLaunchKernelGGL((k_velocity_relax<R, IO, L, MAXT, MINW, true, true>), dim3(B), dim3(T), lds, st, S, make_consts<R>(c), s * s,
-                           e * e, meta, (const R *)curv, (const R *)dth, (const IO *)vcap, acc, (IO *)vel, flags, stats, (R *)vhi);
+                           e * e, meta, (const R *)curv, (const R *)dth, (const R *)vcap, acc, (IO *)vel, flags, stats, (R *)vhi);
     else if (vcap)
         hipLaunchKernelGGL((k_velocity_relax<R, IO, L, MAXT, MINW, true, false>), dim3(B), dim3(T), lds, st, S, make_consts<R>(c), s * s,
-                           e * e, meta, (const R *)curv, (const R *)dth, (const IO *)vcap, acc, (IO *)vel, flags, stats, (R *)vhi);
+                           e * e, meta, (const R *)curv, (const R *)dth, (const R *)vcap, acc, (IO *)vel, flags, stats, (R *)vhi);
     else
         hipLaunchKernelGGL((k_velocity_relax<R, IO, L, MAXT, MINW, false, false>), dim3(B), dim3(T), lds, st, S, make_consts<R>(c), s * s,
-                           e * e, meta, (const R *)curv, (const R *)dth, (const IO *)nullptr, acc, (IO *)vel, flags, stats, (R *)vhi);
+                           e * e, meta, (const R *)curv, (const R *)dth, (const R *)nullptr, acc, (IO *)vel, flags, stats, (R *)vhi);
     if (stats) {
         std::vector<long long> h((size_t)B * 8);
         (void)hipStreamSynchronize(st);

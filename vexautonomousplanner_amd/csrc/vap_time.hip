@@ -21,6 +21,23 @@ namespace vap {
 
 constexpr int kRowWidth = 8;   // time, position, velocity, acceleration, heading, angular velocity, x, y
 
+// res = v64 - (double)v32 as an fp32 number: what the caller's fp32 velocity row lost of the fp64 velocities a velocity
+// kernel left on the context.  The time domain integrates row + res (v64 to 2^-48) — the CALLER's row as it is when the
+// time-domain call is made plus a term below its own rounding, so an edited row is integrated as edited.
+__global__ __launch_bounds__(256) void k_velocity_residual(size_t n, const double *__restrict__ v64, const float *__restrict__ v32,
+                                                           float *__restrict__ res)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        res[i] = (float)(v64[i] - (double)v32[i]);
+}
+
+hipError_t launch_velocity_residual(hipStream_t st, size_t n, const double *v64, const float *v32, float *res)
+{
+    const size_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(k_velocity_residual, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, st, n, v64, v32, res);
+    return hipGetLastError();
+}
+
 // One lane per path (the recurrence is scalar and sequential, so a lane is all a path can use; the
 // instruction stream of a step is shared by the 64 paths of a wavefront).  A step is ~240 instructions
 // issued by a single wavefront per SIMD, i.e. bound by instruction count times issue latency (SQ counters,

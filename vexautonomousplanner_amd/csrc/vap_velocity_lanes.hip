@@ -77,10 +77,9 @@ struct LanesGeo {
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // what a producer lane holds for one slot between the load and the arithmetic
-template <typename IO>
 struct SlotIn {
     double k0, k1, dth, uf;
-    IO acc, vc;
+    double acc, vc;   // limit rows: the recurrence's type (fp64), whatever the caller's rows are
 };
 
 // FUSED: the sampling of K3+K4 runs inside the forward producers (vap_sample_lane.h): what that needs
@@ -117,8 +116,8 @@ struct Lanes {
 
     int S;
     const double *K, *DT;
-    const IO *VC;
-    AccRows<IO> acc;
+    const double *VC;
+    AccRows<double> acc;
     IO *V;
     double *UF;
     bool stats_on = false;  // VAP_LANES_STATS: time the producers' wait for their rows
@@ -139,7 +138,7 @@ struct Lanes {
 
     // ---- forward: the step (j-1 -> j) into slot j uses k[j-1], dth[j-1] (and k[j-2] for rho); slot 0 and the slots
     // past the end hold the state (u' = u)
-    __device__ __forceinline__ void load_fwd(const SlotCtx &c, int tile, SlotIn<IO> &in) const
+    __device__ __forceinline__ void load_fwd(const SlotCtx &c, int tile, SlotIn &in) const
     {
         const int j = tile * TS + c.s;
         const size_t i1 = at(c, j - 1);
@@ -149,7 +148,7 @@ struct Lanes {
         if constexpr (ACC) in.acc = acc.fwd[i1];
         if constexpr (VCAP) in.vc = VC[at(c, j)];
     }
-    __device__ __forceinline__ void put_fwd(const SlotCtx &c, int tile, const SlotIn<IO> &in, unsigned char *rt, bool &saw_dup) const
+    __device__ __forceinline__ void put_fwd(const SlotCtx &c, int tile, const SlotIn &in, unsigned char *rt, bool &saw_dup) const
     {
         const int j = tile * TS + c.s;
         const bool valid = j >= 1 && j <= c.N - 1;
@@ -184,7 +183,7 @@ struct Lanes {
 
     // ---- backward: the step (j+1 -> j) into slot j uses k[j+1], dth[j] (and k[j+2] for rho) and the forward value of
     // the sample, folded into the cap; slots at or past the end sample hold end_u (MPG:252-253)
-    __device__ __forceinline__ void load_bwd(const SlotCtx &c, int tile, SlotIn<IO> &in) const
+    __device__ __forceinline__ void load_bwd(const SlotCtx &c, int tile, SlotIn &in) const
     {
         const int j = tile * TS + c.s;
         const size_t i0 = at(c, j), i1 = at(c, j + 1);
@@ -194,7 +193,7 @@ struct Lanes {
         in.uf = UF[i0];
         if constexpr (ACC) in.acc = acc.bwd[i1];
     }
-    __device__ __forceinline__ void put_bwd(const SlotCtx &c, int tile, const SlotIn<IO> &in, unsigned char *rt, int parity, bool path_is_dup) const
+    __device__ __forceinline__ void put_bwd(const SlotCtx &c, int tile, const SlotIn &in, unsigned char *rt, int parity, bool path_is_dup) const
     {
         const int j = tile * TS + c.s;
         const bool valid = j <= c.N - 2;
@@ -248,7 +247,7 @@ struct Lanes {
     // tile `t_flush` out and waits at the barrier — then do that work.  Tiles outside [0, NT) are skipped (fill, drain).
     template <bool BWD>
     __device__ __forceinline__ void producer_step(const SlotCtx (&ctx)[kBatchesPerProducer], bool four, int NT, int t_load, int t_put,
-                                                  int t_flush, int parity, SlotIn<IO> (&rows)[kBatchesPerProducer],
+                                                  int t_flush, int parity, SlotIn (&rows)[kBatchesPerProducer],
                                                   bool (&saw_dup)[kBatchesPerProducer]) const
     {
         if (four) producer_step_n<BWD, kBatchesPerProducer>(ctx, NT, t_load, t_put, t_flush, parity, rows, saw_dup);
@@ -256,10 +255,10 @@ struct Lanes {
     }
     template <bool BWD, int NB>
     __device__ __forceinline__ void producer_step_n(const SlotCtx (&ctx)[kBatchesPerProducer], int NT, int t_load, int t_put, int t_flush,
-                                                    int parity, SlotIn<IO> (&rows)[kBatchesPerProducer],
+                                                    int parity, SlotIn (&rows)[kBatchesPerProducer],
                                                     bool (&saw_dup)[kBatchesPerProducer]) const
     {
-        SlotIn<IO> cur[NB];
+        SlotIn cur[NB];
         const long long tk0 = stats_on ? __builtin_amdgcn_s_memtime() : 0;
 #pragma unroll
         for (int i = 0; i < NB; i++) {
@@ -308,7 +307,7 @@ __global__ __launch_bounds__(kLanesThreads, 3) void k_velocity_lanes(int B, int 
                                                                      const double *__restrict__ meta,
                                                                      const double *__restrict__ curv,
                                                                      const double *__restrict__ dtheta,
-                                                                     const IO *__restrict__ vcap, AccRows<IO> acc,
+                                                                     const double *__restrict__ vcap, AccRows<double> acc,
                                                                      IO *__restrict__ vel, double *__restrict__ ufwd,
                                                                      long long *__restrict__ stats, FusedArgs fz, float *__restrict__ vres)
 {
@@ -452,7 +451,7 @@ __global__ __launch_bounds__(kLanesThreads, 3) void k_velocity_lanes(int B, int 
         constexpr bool BWD = decltype(bwd_tag)::value;
         // pipeline tile #n -> row tile (clamped outside [0, NT): those loads are never used)
         auto rt = [NT](int n) { return BWD ? NT - 1 - n : n; };
-        SlotIn<IO> rows[kBatchesPerProducer] = {};
+        SlotIn rows[kBatchesPerProducer] = {};
         L.template producer_step<BWD>(ctx, four, NT, rt(0), -1, -1, 0, rows, saw_dup);
         for (int it = 0; it <= NT + 1; it++) {
             const long long t0 = stats ? __builtin_amdgcn_s_memtime() : 0;
@@ -524,7 +523,7 @@ __global__ __launch_bounds__(kLanesThreads, 3) void k_velocity_lanes(int B, int 
                         fz.k64[o_j] = in ? o.kap : 0.0;
                         if (j >= 1) fz.dth64[o_j - 1] = o.dth_prev;             // (zero from the end sample on)
                     }
-                    SlotIn<IO> in_;
+                    SlotIn in_;
                     in_.k0 = o.kap_m1;
                     in_.k1 = o.kap_m2;
                     in_.dth = o.dth_prev;
@@ -599,8 +598,8 @@ hipError_t launch_lanes_p(hipStream_t st, int B, int S, const double c[6], doubl
     vc.vmax = c[0]; vc.amax = c[1]; vc.adec = c[2]; vc.tw = c[5];
     vc.wmax = 2.0 * vc.vmax / vc.tw;
     vc.almax = 2.0 * vc.amax / vc.tw;
-    AccRows<IO> acc;
-    acc.fwd = (const IO *)accv.fwd; acc.bwd = (const IO *)accv.bwd; acc.dec = (const IO *)accv.dec;
+    AccRows<double> acc;
+    acc.fwd = (const double *)accv.fwd; acc.bwd = (const double *)accv.bwd; acc.dec = (const double *)accv.dec;
     const dim3 grid((B + P - 1) / P), block(kLanesThreads);
     const size_t lds = G::lds_bytes;
     constexpr int kMaxDevices = 64;
@@ -623,7 +622,7 @@ hipError_t launch_lanes_p(hipStream_t st, int B, int S, const double c[6], doubl
             if (e != hipSuccess) return e;                                                                                  \
             attr_set[dev] = true;                                                                                           \
         }                                                                                                                   \
-        hipLaunchKernelGGL(kern, grid, block, lds, st, B, S, vc, sv * sv, ev * ev, meta, curv, dth, (const IO *)vcap, acc,  \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, B, S, vc, sv * sv, ev * ev, meta, curv, dth, (const double *)vcap, acc,  \
                            (IO *)vel, ufwd, stats, FusedArgs(), vres);                                                      \
     } while (0)
     if constexpr (std::is_same<IO, float>::value && P == 16) {
@@ -631,7 +630,7 @@ hipError_t launch_lanes_p(hipStream_t st, int B, int S, const double c[6], doubl
             auto kern = k_velocity_lanes<float, 16, false, false, true>;
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(kern, grid, block, lds, st, B, S, vc, sv * sv, ev * ev, meta, curv, dth, (const float *)nullptr, acc,
+            hipLaunchKernelGGL(kern, grid, block, lds, st, B, S, vc, sv * sv, ev * ev, meta, curv, dth, (const double *)nullptr, acc,
                                (float *)vel, ufwd, stats, *fused, vres);
         }
     }
