@@ -140,15 +140,20 @@ def committed_profile(workload, dtype, paths, recurrence):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), key=round_of)
     if not files:
         return None, "no PMC profile committed"
-    prof = json.load(open(files[-1]))
-    name = os.path.basename(files[-1])
+    # one file per profiled workload and round (r04_traffic.json = the headline config, r04_c4_traffic.json, ...): the
+    # newest round's file for THIS workload and mode
+    newest = round_of(files[-1])
     want = {"workload": workload, "dtype": dtype, "paths": paths, "recurrence": recurrence if dtype == "f32" else "f64"}
-    have = prof.get("bench", {})
-    if any(have.get(k) != v for k, v in want.items()):
-        return None, f"{name} was taken on another workload / mode"
-    if prof.get("kernel_source_sha") != kernel_source_sha():
-        return None, f"{name} is stale: the kernel sources changed since it was taken"
-    return prof, name
+    for f in reversed([f for f in files if round_of(f) == newest]):
+        prof = json.load(open(f))
+        name = os.path.basename(f)
+        have = prof.get("bench", {})
+        if any(have.get(k) != v for k, v in want.items()):
+            continue
+        if prof.get("kernel_source_sha") != kernel_source_sha():
+            return None, f"{name} is stale: the kernel sources changed since it was taken"
+        return prof, name
+    return None, f"round {newest}'s profiles were taken on other workloads / modes"
 
 
 def profiled_traffic(stage, workload, dtype, paths, recurrence):
@@ -169,6 +174,43 @@ def profiled_pipeline_traffic(workload, dtype, paths, recurrence):
         return None
     vals = [v["hbm_bytes"] for k, v in prof["kernels"].items() if "vap::" in k]
     return sum(vals) if vals else None
+
+
+def dropin_config1(calls=20):
+    """BASELINE config 1 through the drop-in path: the GUI's own call sequence for one 8-waypoint path
+    (gui/path.py:356-390 update_spline -> build_path; gui/path.py:301-354 generate_motion_profile_lists ->
+    Constraints(...) + generate_motion_profile(spline_manager, constraints)) with the drop-in classes, wall time per call
+    (host clock around the whole sequence, Python lists out, as the GUI receives them).  The reference's Python takes
+    267 ms for generate_motion_profile on this path (one Xeon 2.1 GHz core)."""
+    sys.path.insert(0, os.path.join(ROOT, "dropin"))
+    try:
+        from motion_profiling_v2 import motion_profile_generator as mpg
+        from splines.spline_manager import QuinticHermiteSplineManager
+        from vexautonomousplanner_amd.nodes import Node
+        from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
+        wp = make_waypoints(1, 8, 1)[0].astype(np.float64)        # config 1: seed 1 (SURVEY 8(d)), golden c1_w8
+        nodes = [Node() for _ in wp]
+        t_build, t_prof, rows = [], [], 0
+        for i in range(calls + 2):
+            t0 = time.perf_counter()
+            sm = QuinticHermiteSplineManager()
+            ok = sm.build_path(wp, nodes, [])
+            t1 = time.perf_counter()
+            res = mpg.generate_motion_profile(sm, mpg.Constraints(*DEFAULT_CONSTRAINTS))
+            t2 = time.perf_counter()
+            assert ok and len(res) == 9
+            rows = len(res[0])
+            if i >= 2:                                            # two untimed calls: library load, first allocations
+                t_build.append(t1 - t0)
+                t_prof.append(t2 - t1)
+        bp, gp = float(np.mean(t_build)) * 1e3, float(np.mean(t_prof)) * 1e3
+        return {"workload": "c1: one 8-waypoint path, default constraints, dd = 0.005, dt = 0.01", "calls": calls,
+                "build_path_ms": bp, "generate_motion_profile_ms": gp, "ms_per_call": bp + gp, "time_rows": rows,
+                "min_ms": float(np.min(np.add(t_build, t_prof))) * 1e3,
+                "reference_python_ms": {"build_path": 4.9, "generate_motion_profile": 267.0,
+                                        "measured": "build container, 1 Xeon 2.1 GHz core (BASELINE.md section 2)"}}
+    finally:
+        sys.path.remove(os.path.join(ROOT, "dropin"))
 
 
 def launch_ranks(n):
@@ -208,7 +250,15 @@ def main():
     ap.add_argument("--no-other-mode", action="store_true",
                     help="skip the after-the-fact measurement of the other recurrence arithmetic (fp32 rows, N = 1)")
     ap.add_argument("--time-domain", action="store_true",
-                    help="also time the batched time-domain resample (vap_time_profile) after the timed region")
+                    help="also time the batched time-domain resample (vap_time_profile) after the timed region (implies "
+                         "--time-domain-residual: the step then also writes the fp32 residual row that call integrates)")
+    ap.add_argument("--time-domain-residual", action="store_true",
+                    help="VAP_OPT_TIME_DOMAIN_RESIDUAL on in the timed step (the library's default; 4 B/pt of extra writes that only "
+                         "a following time-domain call reads).  The bench's hot path is the distance domain — five output rows "
+                         "per sample-point — so its default is OFF, and `config.time_domain_residual` says which was timed")
+    ap.add_argument("--no-dropin-c1", action="store_true",
+                    help="skip the config-1 leg after the timed region (the GUI's call sequence for one 8-waypoint path "
+                         "through the drop-in classes, wall time per call)")
     ap.add_argument("--tolerance-sweep", action="store_true",
                     help="BASELINE config 5: after the timed region run the same batch in the other precision modes and "
                          "report the per-path distribution of |fp32 - fp64| (relative, velocity) on the device")
@@ -226,7 +276,7 @@ def main():
     import torch.distributed as dist
 
     from vexautonomousplanner_amd.batch import BatchedTrajectoryGenerator
-    from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
+    from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints_block
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -256,14 +306,15 @@ def main():
     from vexautonomousplanner_amd import dist as vdist
     # rank 0 owns the constraints; everyone else receives them over RCCL (setup, untimed)
     constraints = vdist.broadcast_constraints(DEFAULT_CONSTRAINTS if rank == 0 else None, dev)
-    # rank r works on the contiguous block [r*B, (r+1)*B) of the seeded global batch (every rank can
-    # generate its own block, so the waypoint scatter of vdist.scatter_waypoints is not needed here)
-    lo, hi = vdist.shard_bounds(B * world, rank, world)
-    wp_all = make_waypoints(B * world, W, wl["seed"], dtype=np.float32 if args.dtype == "f32" else np.float64)
-    wp = torch.tensor(wp_all[lo:hi], dtype=tdt, device=dev)
-    del wp_all
+    # rank r works on block r — paths [r*B, (r+1)*B) — of the seeded global batch, and generates that block ALONE
+    # (synth.make_waypoints_block: block 0 is the 1-GPU batch; no rank builds another rank's paths, no waypoint scatter)
+    wp = torch.tensor(make_waypoints_block(B, W, wl["seed"], rank, dtype=np.float32 if args.dtype == "f32" else np.float64),
+                      dtype=tdt, device=dev)
+    # what the communicator itself reports (RCCL saw N ranks: world size and an all-reduce of ones), before the timed region
+    comm = vdist.comm_record(dev)
 
-    gen = BatchedTrajectoryGenerator(local_rank, args.dtype, recurrence=args.recurrence)
+    residual = bool(args.time_domain_residual or args.time_domain)
+    gen = BatchedTrajectoryGenerator(local_rank, args.dtype, recurrence=args.recurrence, time_domain_residual=residual)
     out = None
 
     def step():
@@ -332,6 +383,11 @@ def main():
     total_len = float(summ[:, 0].sum().item())
     best_time = float(summ[:, 2].min().item())
 
+    # after the timed region, rank 0, N = 1: BASELINE config 1 through the drop-in path, for the record
+    dropin_c1 = None
+    if rank == 0 and world == 1 and not args.no_dropin_c1:
+        dropin_c1 = dropin_config1()
+
     # parity of the mode just timed: the first paths of rank 0's batch against the oracle (CPU, after the timed region)
     parity = None
     if rank == 0 and args.parity_paths > 0:
@@ -342,7 +398,7 @@ def main():
     other_mode = None
     if world == 1 and args.dtype == "f32" and not args.no_other_mode:
         orec = "f32" if args.recurrence == "f64" else "f64"
-        ogen = BatchedTrajectoryGenerator(local_rank, "f32", recurrence=orec)
+        ogen = BatchedTrajectoryGenerator(local_rank, "f32", recurrence=orec, time_domain_residual=residual)
         oout = None
         for _ in range(2):
             oout = ogen.profile(wp, constraints=constraints, samples=S, out=oout)
@@ -365,7 +421,8 @@ def main():
     pipelined = None
     if world == 1 and args.in_flight > 1 and B * S * 40 * args.in_flight < 64e9:
         n = args.in_flight
-        gens = [gen] + [BatchedTrajectoryGenerator(local_rank, args.dtype, recurrence=args.recurrence) for _ in range(n - 1)]
+        gens = [gen] + [BatchedTrajectoryGenerator(local_rank, args.dtype, recurrence=args.recurrence, time_domain_residual=residual)
+                        for _ in range(n - 1)]
         streams = [torch.cuda.Stream(dev) for _ in range(n)]
         outs = [out] + [None] * (n - 1)
 
@@ -420,12 +477,14 @@ def main():
             "config": {"workload": wl["name"], "paths_per_gpu": B, "waypoints": W, "samples": S,
                        "grid": "dd_p = L_p / (S - 1.5), the reference's running sum from 0 plus its appended end sample",
                        "recurrence": ("f64 behind fp32 rows" if args.recurrence == "f64" else "f32") if args.dtype == "f32" else "f64",
+                       "time_domain_residual": residual,
                        "global_paths": B * world, "parallelism": f"paths sharded x{world}, no data-path collective",
                        "flags_or": flags, "sum_path_length_ft": total_len,
                        "fastest_traversal_s": best_time},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "kernel_ms": dom_ms, "algorithmic_bytes_per_point": stage_bytes[dom]},
+            "comm": comm,
             "kernel_source_sha": kernel_source_sha(),
             "pipeline": {"bytes_per_point": bytes_per_point,
                          "traffic": profiled_pipeline_traffic(args.workload, args.dtype, B, args.recurrence),
@@ -451,6 +510,9 @@ def main():
             line["tolerance_sweep"] = sweep
         if time_domain is not None:
             line["time_domain"] = time_domain
+        if dropin_c1 is not None:
+            line["dropin_c1"] = dropin_c1
+            line["dropin_c1_ms"] = dropin_c1["ms_per_call"]
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(wl)
             # context, not measured here: the reference's own Python cannot travel to this box

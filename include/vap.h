@@ -96,7 +96,8 @@ int vap_ctx_synchronize(vap_ctx *ctx);
  * kernel (config 2) are cut into super-chunks whose interface states are handed on by look-back inside one launch per
  * direction; RELAX_ROUNDS forces the earlier form of that kernel (one launch per super-round, convergence checked
  * on the host) — the same rows bit for bit (tests). */
-enum { VAP_OPT_VELOCITY_KERNEL = 0, VAP_OPT_F32_RECURRENCE = 1, VAP_OPT_FUSED_SAMPLING = 2, VAP_OPT_TIME_DOMAIN_RESIDUAL = 3 };
+enum { VAP_OPT_VELOCITY_KERNEL = 0, VAP_OPT_F32_RECURRENCE = 1, /* 2: retired (sampling inside the velocity kernel, rounds 3-4) */
+       VAP_OPT_TIME_DOMAIN_RESIDUAL = 3 };
 enum { VAP_VELOCITY_AUTO = 0, VAP_VELOCITY_SEQ_LITERAL = 1, VAP_VELOCITY_SEQ_FAST = 2, VAP_VELOCITY_RELAX = 3,
        VAP_VELOCITY_RELAX_BLOCK = 4 /* workgroup per path */, VAP_VELOCITY_RELAX_WAVE = 5 /* wave per path, fp32 */,
        VAP_VELOCITY_LANES = 6 /* lane per path, fp64 recurrence */, VAP_VELOCITY_LANES_16 = 7, VAP_VELOCITY_LANES_32 = 8,
@@ -109,11 +110,6 @@ enum { VAP_VELOCITY_AUTO = 0, VAP_VELOCITY_SEQ_LITERAL = 1, VAP_VELOCITY_SEQ_FAS
  *   VAP_RECURRENCE_F32: rows and recurrence in fp32 — faster, and within 1e-5 on ~98.6 % of config-3-shaped
  *     paths (worst sample 7e-5). */
 enum { VAP_RECURRENCE_F64 = 0, VAP_RECURRENCE_F32 = 1 };
-/* VAP_OPT_FUSED_SAMPLING (0 = off, the default; 1 = on): vap_profile_batch in the default VAP_F32 mode, when the
- * velocity kernel is LANES (AUTO: batches of 2048 paths and more), samples the paths inside that kernel's forward sweep —
- * the fp64 curvature / heading-difference rows then reach the recurrence without a round trip through HBM.  Same rows,
- * bit for bit, as the separate sampling kernel (tests/test_gpu_fused.py); in its present form slower than the two
- * kernels, hence off. */
 /* VAP_OPT_TIME_DOMAIN_RESIDUAL (1 = on, the default; 0 = off): VAP_F32 calls with the fp64 recurrence also leave, in
  * context scratch, what each stored fp32 velocity lost of the fp64 value (an fp32 residual row, 4 B per sample-point of
  * extra writes).  A following vap_time_profile / vap_time_profile_routes that is handed that velocity row integrates

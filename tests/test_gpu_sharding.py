@@ -130,6 +130,8 @@ def test_bench_starts_its_own_ranks(torch_mod):
     assert len(lines) == 1, p.stdout[-2000:]
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["global_paths"] == 512 and rec["value"] > 0
+    # the communicator's own record: the process group saw two ranks and both took part in a collective
+    assert rec["comm"]["world_size"] == 2 and rec["comm"]["ranks_reporting"] == 2 and rec["comm"]["backend"] == "gloo"
     # a rank that fails takes the exit code with it
     bad = subprocess.run(cmd[:-5] + ["--paths-per-gpu", "-5", "--no-cpu-baseline", "--parity-paths", "0"], capture_output=True,
                          text=True, timeout=600, env=env)
@@ -161,3 +163,5 @@ def test_bench_one_rank_over_rccl_under_the_launcher(torch_mod):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 1 and rec["config"]["global_paths"] == 2048 and rec["value"] > 0
     assert rec["config"]["flags_or"] == 0
+    assert rec["comm"]["backend"].startswith("rccl") and rec["comm"]["world_size"] == 1 and rec["comm"]["ranks_reporting"] == 1
+    assert rec["comm"]["rccl"] not in (None, "unknown"), rec["comm"]

@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
-"""Developer tool (GPU box): randomized bit-identity sweep of the lane-per-path velocity kernel and of the fused
-sampling against the kernels they must equal.
+"""Developer tool (GPU box): randomized bit-identity sweep of the lane-per-path velocity kernel against the kernel it
+must equal.
 
 Random batch shapes (B, W, S on the fixed-S grid or the reference's dd grid), random robots, start / end velocities:
   * velocity rows of lanes16 / lanes32 / lanes64 == the sequential sweep's (seq_fast), fp32 and fp64 rows;
-  * every row of the fused kernel (VAP_OPT_FUSED_SAMPLING) == the staged kernels', fp32 rows.
-tests/test_gpu_lanes.py and tests/test_gpu_fused.py hold the curated cases; this looks for rare ones.
+  * the same under random node limits (max_velocity, max_acceleration, stop: the VCAP / ACC instantiations).
+tests/test_gpu_lanes.py holds the curated cases; this looks for rare ones (ragged rows, partial groups, rows with and
+without interior tiles).
   python tools/fuzz_lanes.py [seconds]
 """
 import os
@@ -25,10 +26,10 @@ ROWS = ("x", "y", "heading", "curvature", "velocity")
 gens = {}
 
 
-def gen(dt, kernel, fused=False):
-    key = (dt, kernel, fused)
+def gen(dt, kernel):
+    key = (dt, kernel)
     if key not in gens:
-        gens[key] = BatchedTrajectoryGenerator(0, dt, velocity_kernel=kernel, fused_sampling=fused)
+        gens[key] = BatchedTrajectoryGenerator(0, dt, velocity_kernel=kernel)
     return gens[key]
 
 
@@ -61,16 +62,23 @@ while time.time() - t0 < budget:
                                ref["velocity"].view(torch.int32 if dt == "f32" else torch.int64)):
                 fails += 1
                 print(f"FAIL {dt} {kern} velocity differs from seq_fast: {what}", flush=True)
-        if dt == "f32":
-            fused = gen("f32", "lanes", True).profile(wp, cons, start_vel=sv, end_vel=ev, **kw)
-            staged = gen("f32", "lanes16").profile(wp, cons, start_vel=sv, end_vel=ev, **kw)
-            for k in ROWS + ("meta", "flags"):
-                a, b = fused[k], staged[k]
-                if a.dtype.is_floating_point:
-                    a, b = a.view(torch.int32 if a.dtype == torch.float32 else torch.int64), b.view(torch.int32 if b.dtype == torch.float32 else torch.int64)
-                if not torch.equal(a, b):
+        if W >= 3 and n_cases % 2 == 0:
+            # node limits: the VCAP (max_velocity / stop) and ACC (max_acceleration) instantiations
+            lim = np.random.default_rng(seed)
+            mv = np.where(lim.random((B, W)) < 0.3, lim.uniform(0.5, cons[0], (B, W)), 0.0)
+            stop = lim.random((B, W)) < 0.15
+            stop[:, 0] = stop[:, -1] = False
+            ma = np.where(lim.random((B, W)) < 0.4, lim.uniform(1.0, 20.0, (B, W)), 0.0) if n_cases % 4 == 0 else None
+            rows = {}
+            for kern in ("seq_fast", "lanes16", "lanes32", "lanes64"):
+                g = gen(dt, kern)
+                r = g.profile(wp, cons, start_vel=sv, end_vel=ev, **kw)
+                g.apply_node_limits(r, cons, node_max_velocity=mv, node_stop=stop, node_max_acceleration=ma, start_vel=sv, end_vel=ev)
+                rows[kern] = r["velocity"].clone().view(torch.int32 if dt == "f32" else torch.int64)
+            for kern in ("lanes16", "lanes32", "lanes64"):
+                if not torch.equal(rows[kern], rows["seq_fast"]):
                     fails += 1
-                    print(f"FAIL fused {k} differs from staged: {what}", flush=True)
+                    print(f"FAIL {dt} {kern} velocity under node limits ({'acc' if ma is not None else 'vcap'}) differs from seq_fast: {what}", flush=True)
     torch.cuda.synchronize()
     n_cases += 1
 print(f"{n_cases} cases in {time.time() - t0:.0f} s, {fails} failures")

@@ -25,7 +25,6 @@ FLAG_NOCONVERGE = 4
 FLAG_BAD_ROUTE = 8
 T_FIT, T_LUT, T_SAMPLE, T_VELOCITY, T_TOTAL, T_COUNT = 0, 1, 2, 3, 4, 8
 OPT_VELOCITY_KERNEL = 0
-OPT_FUSED_SAMPLING = 2
 OPT_TIME_DOMAIN_RESIDUAL = 3
 OPT_F32_RECURRENCE = 1
 RECURRENCE_F64, RECURRENCE_F32 = 0, 1

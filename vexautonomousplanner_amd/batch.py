@@ -32,13 +32,11 @@ class BatchedTrajectoryGenerator:
     """rebuild_tables + forward_backward_pass (SM:582-594, MPG:70-316) for B independent
     plain-node paths per call, outputs resident in HBM as (B, S) tensors."""
 
-    def __init__(self, device=0, dtype="f32", timing=False, velocity_kernel="auto", recurrence="f64", fused_sampling=False,
-                 time_domain_residual=True):
+    def __init__(self, device=0, dtype="f32", timing=False, velocity_kernel="auto", recurrence="f64", time_domain_residual=True):
         """dtype "f32" | "f64": type of inputs and outputs.  recurrence (dtype "f32" only): "f64" (default) carries
         the velocity recurrence and its curvature / heading-difference rows in fp64 behind the fp32 outputs — the
         mode that holds 1e-5 against the reference on every path; "f32" is the all-fp32 recurrence (faster,
-        ~1.4 % of config-3-shaped paths have a sample above 1e-5).  fused_sampling (VAP_OPT_FUSED_SAMPLING): the
-        default mode then samples large batches inside the velocity kernel (same rows; measured slower so far: off).
+        ~1.4 % of config-3-shaped paths have a sample above 1e-5).
         time_domain_residual (VAP_OPT_TIME_DOMAIN_RESIDUAL, dtype "f32" with the fp64 recurrence): keep what every stored
         fp32 velocity lost of its fp64 value (4 B per sample-point of extra writes) for a following time_profile();
         False for batches that never go to the time domain."""
@@ -52,7 +50,6 @@ class BatchedTrajectoryGenerator:
         self._L = _lib.lib()
         self.set_velocity_kernel(velocity_kernel)
         self.set_recurrence(recurrence)
-        self.ctx.set_option(_lib.OPT_FUSED_SAMPLING, 1 if fused_sampling else 0)
         self.time_domain_residual = bool(time_domain_residual)
         self.ctx.set_option(_lib.OPT_TIME_DOMAIN_RESIDUAL, 1 if self.time_domain_residual else 0)
         self._generation = 0

@@ -278,10 +278,6 @@ int vap_ctx_set_option(vap_ctx *ctx, int option, int value)
         ctx->velocity_kernel = value;
         return VAP_OK;
     }
-    if (option == VAP_OPT_FUSED_SAMPLING && (value == 0 || value == 1)) {
-        ctx->fused_sampling = value;
-        return VAP_OK;
-    }
     if (option == VAP_OPT_TIME_DOMAIN_RESIDUAL && (value == 0 || value == 1)) {
         ctx->keep_residual = value;
         ctx->vres_for = nullptr;
@@ -509,25 +505,7 @@ int vap_profile_batch(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, double dd
                                 nullptr, meta, flags, grid));   // (the sampling kernel forms the interval slopes itself)
     }
     tm.mark(VAP_T_LUT);
-    // the default mode on a large batch: sampling inside the velocity kernel's forward sweep (one launch; VAP_T_SAMPLE
-    // then reads 0 and VAP_T_VELOCITY is the fused kernel)
-    const int vk = ctx->velocity_kernel;
-    const bool fused = hi && ctx->fused_sampling == 1 &&
-                       ((vk == VAP_VELOCITY_AUTO && B >= kLanesMinPaths) || vk == VAP_VELOCITY_LANES || vk == VAP_VELOCITY_LANES_16);
-    if (fused) {
-        tm.mark(VAP_T_SAMPLE);
-        VAP_TRY(ctx->ensure(ctx->ufwd, n_pts * sizeof(double)));
-        VAP_TRY(ctx->ensure(ctx->vres, n_pts * sizeof(float)));
-        ctx->vres_for = nullptr;
-        HIP_TRY(vap::launch_sample_velocity_fused(ctx->stream, B, W, S, cc, start_vel, end_vel, meta, (const double *)ctx->power.ptr,
-                                                  (const double *)ctx->lut.ptr, (const double *)ctx->aux.ptr,
-                                                  (const double *)ctx->runs.ptr, (float *)d_x, (float *)d_y, (float *)d_heading,
-                                                  (float *)d_curvature, (double *)ctx->k64.ptr, (double *)ctx->dth64.ptr,
-                                                  (float *)d_velocity, (double *)ctx->ufwd.ptr, (float *)ctx->vres.ptr));
-        ctx->vres_for = d_velocity;
-        ctx->vres_B = B;
-        ctx->vres_S = S;
-    } else {
+    {
         HIP_TRY(vap::launch_sample(ctx->stream, f64, B, W, S, (const double *)ctx->power.ptr, (const double *)ctx->lut.ptr, nullptr,
                                    meta, (const double *)ctx->aux.ptr, (const double *)ctx->runs.ptr, d_x, d_y, d_heading,
                                    curv, hi ? nullptr : ctx->dth.ptr, hi ? (double *)ctx->k64.ptr : nullptr,

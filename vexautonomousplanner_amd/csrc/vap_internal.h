@@ -35,7 +35,6 @@ struct vap_ctx {
     bool timing = false;
     int velocity_kernel = 0;  // VAP_OPT_VELOCITY_KERNEL
     int f32_recurrence = 0;   // VAP_OPT_F32_RECURRENCE (VAP_RECURRENCE_F64 = 0: the default)
-    int fused_sampling = 0;   // VAP_OPT_FUSED_SAMPLING (off by default: measured slower)
     hipEvent_t ev[VAP_T_COUNT + 1] = {};
     float ms[VAP_T_COUNT] = {};
     // scratch arena (grow-only, reused across calls)

@@ -104,11 +104,6 @@ int velocity_lanes_group(int B);
 hipError_t launch_velocity_lanes(hipStream_t st, bool io64, int B, int S, const double c[6], double sv, double ev,
                                  const double *meta, const void *curv, const void *dth, const void *vcap, const AccRowsV &acc,
                                  void *vel, void *ufwd, int group = 0, float *vres = nullptr);
-// K3+K4 fused into K5w's forward producers (vap_sample_lane.h): the default mode's step for batches of plain paths
-hipError_t launch_sample_velocity_fused(hipStream_t st, int B, int W, int S, const double c[6], double sv, double ev,
-                                        const double *meta, const double *power, const double *lut, const double *aux,
-                                        const double *runs, float *ox, float *oy, float *oh, float *ok, double *k64, double *dth64,
-                                        float *vel, double *ufwd, float *vres);
 // fp32, one wave per path, one launch per window of 2560 samples and direction (no host synchronisation)
 size_t velocity_windows_state_bytes(int B, int S);
 hipError_t launch_velocity_windows(hipStream_t st, int B, int S, const double c[6], double sv, double ev,

@@ -23,10 +23,10 @@
 #include "vap_chain_asm.h"
 #include "vap_device.h"
 #include "vap_kernels.h"
-#include "vap_sample_lane.h"
 
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 #include <vector>
 
@@ -82,14 +82,6 @@ struct SlotIn {
     double acc, vc;   // limit rows: the recurrence's type (fp64), whatever the caller's rows are
 };
 
-// FUSED: the sampling of K3+K4 runs inside the forward producers (vap_sample_lane.h): what that needs
-struct FusedArgs {
-    const double *power = nullptr, *lut = nullptr, *aux = nullptr, *runs = nullptr;   // coefficient blocks, tables, grid constants, grid runs
-    float *ox = nullptr, *oy = nullptr, *oh = nullptr, *ok = nullptr;                 // the caller's rows (any may be NULL)
-    double *k64 = nullptr, *dth64 = nullptr;                                          // fp64 side rows (written forward, read backward)
-    int W = 0;
-};
-
 struct PathConsts {   // per path (its own sample spacing), in LDS
     double twodd, amaxp, adecp, gk, aangp, adecp_b;
     int N;
@@ -100,7 +92,9 @@ struct PathConsts {   // per path (its own sample spacing), in LDS
 struct SlotCtx {
     FastConsts<double> fc;
     double twodd, adecp_b;
-    size_t row;          // b*S of the path (of the last path for lanes past the batch: their loads stay inside the buffers)
+    uint32_t rowb;       // byte offset of the path's row of doubles from the GROUP's first row (the row of the batch's last
+                         // path for lanes past the batch: their loads stay inside the buffers).  Rows are addressed as a
+                         // wave-uniform base (scalar registers) + a 32-bit lane offset: no 64-bit address arithmetic per load
     int N;               // samples of the path (-1: no such path — nothing of it is stored)
     int s;               // sample within a tile
     int p;               // path within the group
@@ -109,12 +103,19 @@ struct SlotCtx {
     bool live;           // the batch exists for this producer and the path exists
 };
 
+// element at byte offset `off` (32 bits, lane) from a wave-uniform base: global_load ... v_off, s[base:base+1]
+template <typename T>
+__device__ __forceinline__ T ld_off(const T *base, uint32_t off) { return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + off); }
+template <typename T>
+__device__ __forceinline__ T *at_off(T *base, uint32_t off) { return reinterpret_cast<T *>(reinterpret_cast<char *>(base) + off); }
+
 template <typename IO, int P, bool VCAP, bool ACC>
 struct Lanes {
     using G = LanesGeo<P>;
     static constexpr int TS = G::TS;
 
     int S;
+    // (all row pointers point at the GROUP's first row)
     const double *K, *DT;
     const double *VC;
     AccRows<double> acc;
@@ -129,32 +130,37 @@ struct Lanes {
     int *tile_dup;          // LDS [2]: the backward record tile (by parity) holds such a sample
 
     // Row loads are unconditional (sample indices clamped into the row; the values of slots that hold no step are
-    // discarded by put_*): straight-line loads keep the compiler's vmcnt accounting exact.
-    __device__ __forceinline__ size_t at(const SlotCtx &c, int j) const
+    // discarded by put_*): straight-line loads keep the compiler's vmcnt accounting exact.  INT (an interior tile: every
+    // index of every slot is inside every path of the group) needs no clamp.
+    template <bool INT>
+    __device__ __forceinline__ uint32_t at(const SlotCtx &c, int j) const
     {
+        if constexpr (INT) return c.rowb + ((uint32_t)j << 3);
         const int jj = j < 0 ? 0 : (j < S ? j : S - 1);
-        return c.row + jj;
+        return c.rowb + ((uint32_t)jj << 3);
     }
 
     // ---- forward: the step (j-1 -> j) into slot j uses k[j-1], dth[j-1] (and k[j-2] for rho); slot 0 and the slots
     // past the end hold the state (u' = u)
+    template <bool INT>
     __device__ __forceinline__ void load_fwd(const SlotCtx &c, int tile, SlotIn &in) const
     {
         const int j = tile * TS + c.s;
-        const size_t i1 = at(c, j - 1);
-        in.k0 = K[i1];
-        in.k1 = K[at(c, j - 2)];
-        in.dth = DT[i1];
-        if constexpr (ACC) in.acc = acc.fwd[i1];
-        if constexpr (VCAP) in.vc = VC[at(c, j)];
+        const uint32_t i1 = at<INT>(c, j - 1);
+        in.k0 = ld_off(K, i1);
+        in.k1 = ld_off(K, at<INT>(c, j - 2));
+        in.dth = ld_off(DT, i1);
+        if constexpr (ACC) in.acc = ld_off(acc.fwd, i1);
+        if constexpr (VCAP) in.vc = ld_off(VC, at<INT>(c, j));
     }
+    template <bool INT>
     __device__ __forceinline__ void put_fwd(const SlotCtx &c, int tile, const SlotIn &in, unsigned char *rt, bool &saw_dup) const
     {
         const int j = tile * TS + c.s;
-        const bool valid = j >= 1 && j <= c.N - 1;
-        const double kc = fabs(in.k0), kp = j >= 2 ? fabs(in.k1) : 0.0;
+        const bool valid = INT || (j >= 1 && j <= c.N - 1);
+        const double kc = fabs(in.k0), kp = (INT || j >= 2) ? fabs(in.k1) : 0.0;
         double base = c.fc.amaxp;
-        if constexpr (ACC) base = valid ? c.twodd * (double)in.acc : c.fc.amaxp;   // MPG:194-196
+        if constexpr (ACC) base = valid ? c.twodd * in.acc : c.fc.amaxp;   // MPG:194-196
         double rho, q2, A, cap;
         fast_derive_k(c.fc, kc, kp, base, rho, q2, A, cap);
         if constexpr (ACC) A = fast_cap_A(c.fc, kc, A);
@@ -162,42 +168,47 @@ struct Lanes {
         double am, g;
         fast_scale(ACC ? base : c.fc.amaxp, gq, A, am, g);
         if constexpr (VCAP) {   // MPG:121,127,153,172: the sample's own initial velocity also bounds the step into it
-            const double vc = (double)in.vc;
-            if (valid && j <= c.N - 2) cap = vmin(cap, vc * vc);
+            const double vc = in.vc;
+            if (INT || (valid && j <= c.N - 2)) cap = vmin(cap, vc * vc);
         }
         saw_dup |= valid && g < 0.0;
         // a slot that holds no step (sample 0, past the end, no such path): A = 0 and an infinite cap keep the state,
         // whatever the other coefficients are (they are finite: the loads were clamped into the rows)
-        A = valid ? A : 0.0;
-        cap = valid ? cap : Huge<double>::v;
+        if constexpr (!INT) {
+            A = valid ? A : 0.0;
+            cap = valid ? cap : Huge<double>::v;
+        }
         unsigned char *r = rt + c.rec_off;
         *reinterpret_cast<double2 *>(r) = make_double2(rho, g);
         *reinterpret_cast<double2 *>(r + 16) = make_double2(am, A);
         *reinterpret_cast<double *>(rt + c.cap_off) = cap;
     }
+    template <bool INT>
     __device__ __forceinline__ void flush_fwd(const SlotCtx &c, int tile, const double *ot) const
     {
         const int j = tile * TS + c.s;
-        if (j < c.N) UF[c.row + j] = ot[c.out_off];
+        if (INT || j < c.N) *at_off(UF, c.rowb + ((uint32_t)j << 3)) = ot[c.out_off];
     }
 
     // ---- backward: the step (j+1 -> j) into slot j uses k[j+1], dth[j] (and k[j+2] for rho) and the forward value of
     // the sample, folded into the cap; slots at or past the end sample hold end_u (MPG:252-253)
+    template <bool INT>
     __device__ __forceinline__ void load_bwd(const SlotCtx &c, int tile, SlotIn &in) const
     {
         const int j = tile * TS + c.s;
-        const size_t i0 = at(c, j), i1 = at(c, j + 1);
-        in.k0 = K[i1];
-        in.k1 = K[at(c, j + 2)];
-        in.dth = DT[i0];
-        in.uf = UF[i0];
-        if constexpr (ACC) in.acc = acc.bwd[i1];
+        const uint32_t i0 = at<INT>(c, j), i1 = at<INT>(c, j + 1);
+        in.k0 = ld_off(K, i1);
+        in.k1 = ld_off(K, at<INT>(c, j + 2));
+        in.dth = ld_off(DT, i0);
+        in.uf = ld_off(UF, i0);
+        if constexpr (ACC) in.acc = ld_off(acc.bwd, i1);
     }
+    template <bool INT>
     __device__ __forceinline__ void put_bwd(const SlotCtx &c, int tile, const SlotIn &in, unsigned char *rt, int parity, bool path_is_dup) const
     {
         const int j = tile * TS + c.s;
-        const bool valid = j <= c.N - 2;
-        const double kc = fabs(in.k0), kn = (j + 2 <= c.N - 1) ? fabs(in.k1) : 0.0;
+        const bool valid = INT || j <= c.N - 2;
+        const double kc = fabs(in.k0), kn = (INT || j + 2 <= c.N - 1) ? fabs(in.k1) : 0.0;
         double rho, q2, A, cap;
         fast_derive_k(c.fc, kc, kn, ACC ? c.adecp_b : c.fc.adecp, rho, q2, A, cap);
         const double g0 = fast_gq(fast_gg(c.fc, in.dth), q2);
@@ -206,14 +217,16 @@ struct Lanes {
             // the clamp comes from the sweep's max_dec, the wheel limit from the max_acc the sweep has at j+1
             // (MPG:256-257); a straight sample, or one with a zero heading difference, has max_dec alone
             A = fast_cap_A(c.fc, kc, A);
-            am_in = (!(kc < 1e-6) && !(g0 < 0.0)) ? c.twodd * (double)in.acc : A;
+            am_in = (!(kc < 1e-6) && !(g0 < 0.0)) ? c.twodd * in.acc : A;
         }
         cap = vmin(cap, in.uf);
         double am, g;
         fast_scale(am_in, g0, A, am, g);
-        A = valid ? A : 0.0;          // (as in the forward sweep; the slots at or past the end sample hold end_u)
-        cap = valid ? cap : end_u;
-        g = valid ? g : 0.0;
+        if constexpr (!INT) {
+            A = valid ? A : 0.0;          // (as in the forward sweep; the slots at or past the end sample hold end_u)
+            cap = valid ? cap : end_u;
+            g = valid ? g : 0.0;
+        }
         // A zero heading difference (g < 0) needs the sign-aware step (MPG:52-59): the chain takes it for the whole
         // tile (on every other sample it equals the plain step bit for bit).  k_velocity_seq decides per PATH, from the
         // forward sweep's coefficients; the two findings agree (the same dtheta, the same curvature on both sides of
@@ -227,72 +240,99 @@ struct Lanes {
         *reinterpret_cast<double2 *>(r + 16) = make_double2(am, A);
         *reinterpret_cast<double *>(rt + c.cap_off) = cap;
     }
+    template <bool INT>
     __device__ __forceinline__ void flush_bwd(const SlotCtx &c, int tile, const double *ot) const
     {
         const int j = tile * TS + c.s;
-        if (c.N >= 0 && j < S) {
-            const double v = j < c.N ? vel_sqrt(ot[c.out_off]) : 0.0;
+        if (INT || (c.N >= 0 && j < S)) {
+            const double v = (INT || j < c.N) ? vel_sqrt(ot[c.out_off]) : 0.0;
             const IO vs = (IO)v;
-            __builtin_nontemporal_store(vs, &V[c.row + j]);   // (never read again by this kernel: keep it out of the caches)
+            const uint32_t o = (c.rowb >> (std::is_same<IO, double>::value ? 0 : 1)) + (uint32_t)j * (uint32_t)sizeof(IO);
+            __builtin_nontemporal_store(vs, at_off(V, o));   // (never read again by this kernel: keep it out of the caches)
             // fp32 rows: what the rounding dropped goes to a side row, as an fp32 number (row + side row = the fp64
             // velocity to 2^-48: what the time-domain resample integrates, MPG:566-584 — an fp32 row alone moves a
             // position by 1e-7 relative, now and then across a boundary of the reference's step lookup)
-            if constexpr (!std::is_same<IO, double>::value) { if (RES) __builtin_nontemporal_store((float)(v - (double)vs), &RES[c.row + j]); }
+            if constexpr (!std::is_same<IO, double>::value) { if (RES) __builtin_nontemporal_store((float)(v - (double)vs), at_off(RES, o)); }
         }
     }
 
-    // One pipeline step of a producer wave.  `rows` holds the rows of tile `t_put`, loaded during the previous step:
-    // take them (the one wait for memory, exact: nothing younger is in flight), start the loads of tile `t_load` (the
-    // next step's t_put) into the same registers — they fly while this step derives its records, moves the results of
-    // tile `t_flush` out and waits at the barrier — then do that work.  Tiles outside [0, NT) are skipped (fill, drain).
+    // The loads of tile `t_load` into `nxt` (the prologue of a sweep; tiles outside the row load clamped, unused values).
     template <bool BWD>
-    __device__ __forceinline__ void producer_step(const SlotCtx (&ctx)[kBatchesPerProducer], bool four, int NT, int t_load, int t_put,
-                                                  int t_flush, int parity, SlotIn (&rows)[kBatchesPerProducer],
-                                                  bool (&saw_dup)[kBatchesPerProducer]) const
+    __device__ __forceinline__ void producer_prefetch(const SlotCtx (&ctx)[kBatchesPerProducer], int t_load, SlotIn (&nxt)[kBatchesPerProducer]) const
     {
-        if (four) producer_step_n<BWD, kBatchesPerProducer>(ctx, NT, t_load, t_put, t_flush, parity, rows, saw_dup);
-        else producer_step_n<BWD, kBatchesPerProducer - 1>(ctx, NT, t_load, t_put, t_flush, parity, rows, saw_dup);
+#pragma unroll
+        for (int i = 0; i < kBatchesPerProducer; i++) {
+            if constexpr (BWD) load_bwd<false>(ctx[i], t_load, nxt[i]);
+            else load_fwd<false>(ctx[i], t_load, nxt[i]);
+        }
     }
-    template <bool BWD, int NB>
+
+    // One pipeline step of a producer wave.  `cur` holds the rows of tile `t_put`, loaded during the previous step:
+    // take them (the one wait for memory, exact: nothing younger is in flight), start the loads of tile `t_load` (the
+    // next step's t_put) into `nxt` — the two register sets change roles from step to step (the sweep's loop is unrolled
+    // by two), so nothing is copied; the loads fly while this step derives its records, moves the results of tile
+    // `t_flush` out and waits at the barrier.  Tiles outside [0, NT) are skipped (fill, drain).  INT: all three tiles
+    // are interior for every path of the group (no index clamp, every slot holds a step) — 150 of config 3's 157 steps.
+    template <bool BWD, int NB, bool INT>
     __device__ __forceinline__ void producer_step_n(const SlotCtx (&ctx)[kBatchesPerProducer], int NT, int t_load, int t_put, int t_flush,
-                                                    int parity, SlotIn (&rows)[kBatchesPerProducer],
+                                                    int parity, SlotIn (&cur)[kBatchesPerProducer], SlotIn (&nxt)[kBatchesPerProducer],
                                                     bool (&saw_dup)[kBatchesPerProducer]) const
     {
-        SlotIn cur[NB];
         const long long tk0 = stats_on ? __builtin_amdgcn_s_memtime() : 0;
 #pragma unroll
         for (int i = 0; i < NB; i++) {
-            cur[i].k0 = opaque(rows[i].k0);
-            cur[i].k1 = opaque(rows[i].k1);
-            cur[i].dth = opaque(rows[i].dth);
-            if constexpr (BWD) cur[i].uf = opaque(rows[i].uf);
-            if constexpr (ACC) cur[i].acc = opaque(rows[i].acc);
-            if constexpr (VCAP && !BWD) cur[i].vc = opaque(rows[i].vc);
+            cur[i].k0 = opaque(cur[i].k0);
+            cur[i].k1 = opaque(cur[i].k1);
+            cur[i].dth = opaque(cur[i].dth);
+            if constexpr (BWD) cur[i].uf = opaque(cur[i].uf);
+            if constexpr (ACC) cur[i].acc = opaque(cur[i].acc);
+            if constexpr (VCAP && !BWD) cur[i].vc = opaque(cur[i].vc);
         }
         if (stats_on) t_take += __builtin_amdgcn_s_memtime() - tk0;
         __builtin_amdgcn_sched_barrier(0);
         // (unconditional: a tile index outside the row loads clamped, unused values)
 #pragma unroll
         for (int i = 0; i < NB; i++) {
-            if constexpr (BWD) load_bwd(ctx[i], t_load, rows[i]);
-            else load_fwd(ctx[i], t_load, rows[i]);
+            if constexpr (BWD) load_bwd<INT>(ctx[i], t_load, nxt[i]);
+            else load_fwd<INT>(ctx[i], t_load, nxt[i]);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (t_put >= 0 && t_put < NT) {
+        if (INT || (t_put >= 0 && t_put < NT)) {
             unsigned char *rt = rec + (size_t)parity * G::rec_bytes;
 #pragma unroll
             for (int i = 0; i < NB; i++) {
-                if constexpr (BWD) put_bwd(ctx[i], t_put, cur[i], rt, parity, saw_dup[i]);
-                else put_fwd(ctx[i], t_put, cur[i], rt, saw_dup[i]);
+                if constexpr (BWD) put_bwd<INT>(ctx[i], t_put, cur[i], rt, parity, saw_dup[i]);
+                else put_fwd<INT>(ctx[i], t_put, cur[i], rt, saw_dup[i]);
             }
         }
-        if (t_flush >= 0 && t_flush < NT) {
+        if (INT || (t_flush >= 0 && t_flush < NT)) {
             const double *ot = out + (size_t)parity * (G::out_bytes / 8);   // the tile two steps back shares this step's parity
 #pragma unroll
             for (int i = 0; i < NB; i++) {
-                if constexpr (BWD) flush_bwd(ctx[i], t_flush, ot);
-                else flush_fwd(ctx[i], t_flush, ot);
+                if constexpr (BWD) flush_bwd<INT>(ctx[i], t_flush, ot);
+                else flush_fwd<INT>(ctx[i], t_flush, ot);
             }
+        }
+    }
+    // pipeline step `it` of a sweep over NT tiles (tile #n of the backward sweep is row tile NT-1-n); nmin = the fewest
+    // samples of any path slot of the group (-1 when the group is not full)
+    template <bool BWD>
+    __device__ __forceinline__ void producer_step(const SlotCtx (&ctx)[kBatchesPerProducer], bool four, int NT, int nmin, int it,
+                                                  SlotIn (&cur)[kBatchesPerProducer], SlotIn (&nxt)[kBatchesPerProducer],
+                                                  bool (&saw_dup)[kBatchesPerProducer]) const
+    {
+        auto rt = [NT](int n) { return BWD ? NT - 1 - n : n; };
+        // a row tile every index of which — of the loads (j-2 .. j / j .. j+2), the records and the stores — is a sample
+        // that holds a step in every path of the group
+        auto interior = [nmin](int r) { return BWD ? (r + 1) * TS <= nmin - 2 : (r >= 1 && (r + 1) * TS <= nmin - 1); };
+        const int t_load = rt(it + 1), t_put = it < NT ? rt(it) : -1, t_flush = (it >= 2 && it - 2 < NT) ? rt(it - 2) : -1;
+        const bool all_int = it >= 2 && it + 1 < NT && interior(t_load) && interior(t_put) && interior(t_flush);
+        if (all_int) {
+            if (four) producer_step_n<BWD, kBatchesPerProducer, true>(ctx, NT, t_load, t_put, t_flush, it & 1, cur, nxt, saw_dup);
+            else producer_step_n<BWD, kBatchesPerProducer - 1, true>(ctx, NT, t_load, t_put, t_flush, it & 1, cur, nxt, saw_dup);
+        } else {
+            if (four) producer_step_n<BWD, kBatchesPerProducer, false>(ctx, NT, t_load, t_put, t_flush, it & 1, cur, nxt, saw_dup);
+            else producer_step_n<BWD, kBatchesPerProducer - 1, false>(ctx, NT, t_load, t_put, t_flush, it & 1, cur, nxt, saw_dup);
         }
     }
 };
@@ -302,26 +342,22 @@ struct Lanes {
 //            tile #(it+1); the chain walks tile #(it-1) out of buffer (it-1)&1 into result buffer (it-1)&1; producers move
 //            tile #(it-2)'s results out of result buffer it&1.
 // (tile #n of the backward sweep is tile NT-1-n of the row.)
-template <typename IO, int P, bool VCAP, bool ACC, bool FUSED>
+template <typename IO, int P, bool VCAP, bool ACC>
 __global__ __launch_bounds__(kLanesThreads, 3) void k_velocity_lanes(int B, int S, VelConsts<double> c, double start_u, double end_u,
                                                                      const double *__restrict__ meta,
                                                                      const double *__restrict__ curv,
                                                                      const double *__restrict__ dtheta,
                                                                      const double *__restrict__ vcap, AccRows<double> acc,
                                                                      IO *__restrict__ vel, double *__restrict__ ufwd,
-                                                                     long long *__restrict__ stats, FusedArgs fz, float *__restrict__ vres)
+                                                                     long long *__restrict__ stats, float *__restrict__ vres)
 {
     using G = LanesGeo<P>;
     constexpr int TS = G::TS;
-    static_assert(!FUSED || (TS == 64 && std::is_same<IO, float>::value && !VCAP && !ACC),
-                  "fused sampling: a wavefront = 64 consecutive samples of one path, fp32 rows, plain paths");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ PathConsts s_pc[P];
-    __shared__ int s_nmax, s_pdup[P], s_tdup[2];
-    __shared__ double s_win[FUSED ? kLanesProducers * kBatchesPerProducer * kLaneWindow : 1];   // table windows, one per (producer, batch)
-    if constexpr (FUSED) { curv = fz.k64; dtheta = fz.dth64; }
+    __shared__ int s_nmax, s_nmin, s_pdup[P], s_tdup[2];
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-    if (tid == 0) { s_nmax = 0; s_tdup[0] = 0; s_tdup[1] = 0; }
+    if (tid == 0) { s_nmax = 0; s_nmin = 0x7fffffff; s_tdup[0] = 0; s_tdup[1] = 0; }
     if (tid < P) s_pdup[tid] = 0;
     __syncthreads();
     if (tid < P) {
@@ -341,21 +377,27 @@ __global__ __launch_bounds__(kLanesThreads, 3) void k_velocity_lanes(int B, int 
             pc.adecp = fc.adecp;
             pc.gk = fc.gk;
             pc.aangp = fc.aangp;
-            if constexpr (ACC) pc.adecp_b = twodd * (double)acc.dec[b];
+            if constexpr (ACC) pc.adecp_b = twodd * acc.dec[b];
             atomicMax(&s_nmax, N);
         }
+        atomicMin(&s_nmin, pc.N);     // (-1 for a slot without a path: a group that is not full has no interior tiles)
         s_pc[tid] = pc;
     }
     __syncthreads();
     const int NT = (s_nmax + TS - 1) / TS;
+    const int nmin = s_nmin;
 
+    // every row pointer at the group's first row: lanes address their rows by 32-bit offsets from it (SlotCtx::rowb)
+    const size_t gbase = (size_t)blockIdx.x * P * S;
     Lanes<IO, P, VCAP, ACC> L;
     L.S = S;
-    L.K = curv; L.DT = dtheta; L.VC = vcap; L.acc = acc; L.V = vel;
-    L.RES = vres;
+    L.K = curv + gbase; L.DT = dtheta + gbase; L.V = vel + gbase;
+    L.VC = VCAP ? vcap + gbase : nullptr;
+    if constexpr (ACC) { L.acc.fwd = acc.fwd + gbase; L.acc.bwd = acc.bwd + gbase; L.acc.dec = acc.dec; }
+    L.RES = vres ? vres + gbase : nullptr;
     L.stats_on = stats != nullptr;
-    if constexpr (std::is_same<IO, double>::value) L.UF = reinterpret_cast<double *>(vel);   // fp64 rows: in place
-    else L.UF = ufwd;
+    if constexpr (std::is_same<IO, double>::value) L.UF = reinterpret_cast<double *>(vel) + gbase;   // fp64 rows: in place
+    else L.UF = ufwd + gbase;
     L.end_u = end_u;
     L.rec = smem_raw;
     L.out = reinterpret_cast<double *>(smem_raw + 2 * (size_t)G::rec_bytes);
@@ -431,7 +473,7 @@ __global__ __launch_bounds__(kLanesThreads, 3) void k_velocity_lanes(int B, int 
         const PathConsts pc = s_pc[x.p];
         x.live = q >= 0;
         x.N = x.live ? pc.N : -1;
-        x.row = (size_t)(b < B ? b : B - 1) * S;
+        x.rowb = (uint32_t)((b < B ? b : B - 1) - blockIdx.x * P) * (uint32_t)S * 8u;
         x.twodd = pc.twodd;
         x.adecp_b = pc.adecp_b;
         x.fc.vmax = c.vmax;
@@ -449,110 +491,25 @@ __global__ __launch_bounds__(kLanesThreads, 3) void k_velocity_lanes(int B, int 
     long long t_busy = 0;
     auto sweep = [&](auto bwd_tag) {
         constexpr bool BWD = decltype(bwd_tag)::value;
-        // pipeline tile #n -> row tile (clamped outside [0, NT): those loads are never used)
-        auto rt = [NT](int n) { return BWD ? NT - 1 - n : n; };
-        SlotIn rows[kBatchesPerProducer] = {};
-        L.template producer_step<BWD>(ctx, four, NT, rt(0), -1, -1, 0, rows, saw_dup);
-        for (int it = 0; it <= NT + 1; it++) {
-            const long long t0 = stats ? __builtin_amdgcn_s_memtime() : 0;
-            L.template producer_step<BWD>(ctx, four, NT, rt(it + 1), it < NT ? rt(it) : -1, (it >= 2 && it - 2 < NT) ? rt(it - 2) : -1,
-                                          it & 1, rows, saw_dup);
+        // two register sets of rows, taking turns: a step computes from one while the next tile's loads land in the other
+        SlotIn ra[kBatchesPerProducer] = {}, rb[kBatchesPerProducer] = {};
+        L.template producer_prefetch<BWD>(ctx, BWD ? NT - 1 : 0, ra);
+        for (int it = 0; it <= NT + 1; it += 2) {
+            long long t0 = stats ? __builtin_amdgcn_s_memtime() : 0;
+            L.template producer_step<BWD>(ctx, four, NT, nmin, it, ra, rb, saw_dup);
             if (stats) t_busy += __builtin_amdgcn_s_memtime() - t0;
             lds_barrier();
+            if (it + 1 <= NT + 1) {
+                t0 = stats ? __builtin_amdgcn_s_memtime() : 0;
+                L.template producer_step<BWD>(ctx, four, NT, nmin, it + 1, rb, ra, saw_dup);
+                if (stats) t_busy += __builtin_amdgcn_s_memtime() - t0;
+                lds_barrier();
+            }
         }
     };
     // forward: a lane notes whether any of its slots had a zero heading difference; the paths' flags are raised once, at
     // the turn, and read back per slot for the backward sweep (k_velocity_seq's per-path decision)
-    if constexpr (FUSED) {
-        // ---- forward sweep with the sampling inside (vap_sample_lane.h): batch i of this wave is path ctx[i].p, tile after
-        // tile; the rows the forward step needs come out of the sampler's registers, not out of HBM
-        LanePath lp[kBatchesPerProducer];
-        LaneCarry carry[kBatchesPerProducer];
-        int w0[kBatchesPerProducer], runc[kBatchesPerProducer];
-        double wnext[kBatchesPerProducer];
-#pragma unroll
-        for (int i = 0; i < kBatchesPerProducer; i++) {
-            const int b = blockIdx.x * P + __builtin_amdgcn_readfirstlane(ctx[i].p);   // (TS = 64: a batch is one path)
-            const int bb = b < B ? b : B - 1;
-            const double *m = meta + (size_t)bb * kMetaStride, *ax = fz.aux + (size_t)bb * kAuxStride;
-            LanePath &q = lp[i];
-            q.G = fz.W - 1;
-            q.D = fz.lut + (size_t)bb * kLutN;
-            q.coef = fz.power + (size_t)bb * q.G * kCoefDoubles;
-            q.runs = fz.runs + (size_t)bb * kGridRunDoubles;
-            q.t_max = m[0];
-            q.total = m[1];
-            q.lstep = ax[0];
-            q.tstep = ax[1];
-            q.inv_tstep = ax[2];
-            q.n_runs = (int)ax[3];
-            q.end_param = (double)(fz.W - 1);
-            q.tab_n = fz.W * kSamplesPerNode;
-            int n = (int)m[3];
-            q.N = n < S ? n : S;
-            w0[i] = 0;
-            runc[i] = 0;
-            wnext[i] = lane_window_fetch(q, 0, lane);
-        }
-        long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        auto fused_step = [&](auto nb_tag, int it) {
-            constexpr int NB = decltype(nb_tag)::value;
-            const int parity = it & 1;
-            if (it < NT) {
-                unsigned char *rt = L.rec + (size_t)parity * G::rec_bytes;
-#pragma unroll
-                for (int i = 0; i < NB; i++) {
-                    double *win = s_win + ((size_t)pw * kBatchesPerProducer + i) * kLaneWindow;
-                    const double wv_in = opaque(wnext[i]);                      // (the one wait for memory of this batch)
-                    if (lane < kLaneWindow) win[lane] = wv_in;
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's own stores, read back below
-                    const int j = it * TS + lane;
-                    int nw0;
-                    const long long tq0 = stats ? __builtin_amdgcn_s_memtime() : 0;
-                    const LaneSample o = lane_sample(lp[i], j, lane, win, w0[i], runc[i], carry[i], nw0, stats ? phase : nullptr);
-                    w0[i] = nw0;
-                    wnext[i] = lane_window_fetch(lp[i], nw0, lane);             // the next tile's window: in flight for a whole step
-                    const SlotCtx &x = ctx[i];
-                    if (x.N >= 0 && j < S) {
-                        const bool in = j < x.N;
-                        const size_t o_j = x.row + j;
-                        if (fz.ox) __builtin_nontemporal_store(in ? o.x : 0.0f, &fz.ox[o_j]);
-                        if (fz.oy) __builtin_nontemporal_store(in ? o.y : 0.0f, &fz.oy[o_j]);
-                        if (fz.oh) __builtin_nontemporal_store(in ? o.th : 0.0f, &fz.oh[o_j]);
-                        if (fz.ok) __builtin_nontemporal_store(in ? o.kapf : 0.0f, &fz.ok[o_j]);
-                        fz.k64[o_j] = in ? o.kap : 0.0;
-                        if (j >= 1) fz.dth64[o_j - 1] = o.dth_prev;             // (zero from the end sample on)
-                    }
-                    SlotIn in_;
-                    in_.k0 = o.kap_m1;
-                    in_.k1 = o.kap_m2;
-                    in_.dth = o.dth_prev;
-                    const long long tq1 = stats ? __builtin_amdgcn_s_memtime() : 0;
-                    L.put_fwd(x, it, in_, rt, saw_dup[i]);
-                    if (stats) { phase[5] += tq1 - tq0; phase[6] += __builtin_amdgcn_s_memtime() - tq1; }
-                }
-            }
-            if (it >= 2 && it - 2 < NT) {
-                const double *ot = L.out + (size_t)parity * (G::out_bytes / 8);
-#pragma unroll
-                for (int i = 0; i < NB; i++) L.flush_fwd(ctx[i], it - 2, ot);
-            }
-        };
-        for (int it = 0; it <= NT + 1; it++) {
-            const long long t0 = stats ? __builtin_amdgcn_s_memtime() : 0;
-            if (four) fused_step(std::integral_constant<int, kBatchesPerProducer>(), it);
-            else fused_step(std::integral_constant<int, kBatchesPerProducer - 1>(), it);
-            if (stats) t_busy += __builtin_amdgcn_s_memtime() - t0;
-            lds_barrier();
-        }
-        if (stats && tid == 64) {
-            // (developer print: cycles of producer 0 by phase of the fused forward sweep, all its batches)
-            printf("[fused, workgroup %d, producer 0] grid %lld search %lld slope/index %lld evaluate %lld neighbours %lld | sample+stores %lld records %lld\n",
-                   (int)blockIdx.x, phase[0], phase[1], phase[2], phase[3], phase[4], phase[5], phase[6]);
-        }
-    } else {
-        sweep(std::false_type());
-    }
+    sweep(std::false_type());
 #pragma unroll
     for (int i = 0; i < kBatchesPerProducer; i++)
         if (ctx[i].live && saw_dup[i]) s_pdup[ctx[i].p] = 1;
@@ -570,28 +527,14 @@ __global__ __launch_bounds__(kLanesThreads, 3) void k_velocity_lanes(int B, int 
     for (int p = 0; p < P; p++) {
         const int b = blockIdx.x * P + p;
         if (b >= B) break;
-        for (int j = NT * TS + (tid - 64); j < S; j += kLanesThreads - 64) {
-            const size_t o = (size_t)b * S + j;
-            vel[o] = (IO)0;
-            if constexpr (FUSED) {
-                if (fz.ox) fz.ox[o] = 0.0f;
-                if (fz.oy) fz.oy[o] = 0.0f;
-                if (fz.oh) fz.oh[o] = 0.0f;
-                if (fz.ok) fz.ok[o] = 0.0f;
-                fz.k64[o] = 0.0;
-                fz.dth64[o] = 0.0;
-            }
-        }
-        if constexpr (FUSED) {   // (the heading difference of the last tile's last sample has no lane above it to write it)
-            if (tid == 64 && NT * TS - 1 < S && NT > 0) fz.dth64[(size_t)b * S + NT * TS - 1] = 0.0;
-        }
+        for (int j = NT * TS + (tid - 64); j < S; j += kLanesThreads - 64) vel[(size_t)b * S + j] = (IO)0;
     }
 }
 
 template <typename IO, int P>
 hipError_t launch_lanes_p(hipStream_t st, int B, int S, const double c[6], double sv, double ev, const double *meta,
                           const double *curv, const double *dth, const void *vcap, const AccRowsV &accv, void *vel, double *ufwd,
-                          const FusedArgs *fused = nullptr, float *vres = nullptr)
+                          float *vres = nullptr)
 {
     using G = LanesGeo<P>;
     VelConsts<double> vc;
@@ -600,6 +543,8 @@ hipError_t launch_lanes_p(hipStream_t st, int B, int S, const double c[6], doubl
     vc.almax = 2.0 * vc.amax / vc.tw;
     AccRows<double> acc;
     acc.fwd = (const double *)accv.fwd; acc.bwd = (const double *)accv.bwd; acc.dec = (const double *)accv.dec;
+    // rows are addressed by 32-bit byte offsets from the group's first row
+    if ((size_t)P * (size_t)S * 8 >= ((size_t)1 << 32)) return hipErrorInvalidValue;
     const dim3 grid((B + P - 1) / P), block(kLanesThreads);
     const size_t lds = G::lds_bytes;
     constexpr int kMaxDevices = 64;
@@ -615,27 +560,17 @@ hipError_t launch_lanes_p(hipStream_t st, int B, int S, const double c[6], doubl
     }
 #define VAP_LANES_LAUNCH(VCAP_, ACC_)                                                                                       \
     do {                                                                                                                    \
-        auto kern = k_velocity_lanes<IO, P, VCAP_, ACC_, false>;                                                            \
-        static bool attr_set[kMaxDevices] = {};   /* (per instantiation and device: the call costs the host ~10 us) */         \
-        if (!attr_set[dev]) {                                                                                               \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            if (e != hipSuccess) return e;                                                                                  \
-            attr_set[dev] = true;                                                                                           \
-        }                                                                                                                   \
-        hipLaunchKernelGGL(kern, grid, block, lds, st, B, S, vc, sv * sv, ev * ev, meta, curv, dth, (const double *)vcap, acc,  \
-                           (IO *)vel, ufwd, stats, FusedArgs(), vres);                                                      \
+        auto kern = k_velocity_lanes<IO, P, VCAP_, ACC_>;                                                                   \
+        static std::once_flag attr_once[kMaxDevices];   /* (per instantiation and device: the call costs the host ~10 us) */  \
+        hipError_t attr_err = hipSuccess;                                                                                   \
+        std::call_once(attr_once[dev], [&] {                                                                                \
+            attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        });                                                                                                                 \
+        if (attr_err != hipSuccess) return attr_err;                                                                        \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, B, S, vc, sv * sv, ev * ev, meta, curv, dth, (const double *)vcap, acc, \
+                           (IO *)vel, ufwd, stats, vres);                                                                   \
     } while (0)
-    if constexpr (std::is_same<IO, float>::value && P == 16) {
-        if (fused) {
-            auto kern = k_velocity_lanes<float, 16, false, false, true>;
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(kern, grid, block, lds, st, B, S, vc, sv * sv, ev * ev, meta, curv, dth, (const double *)nullptr, acc,
-                               (float *)vel, ufwd, stats, *fused, vres);
-        }
-    }
-    if (fused) { /* launched above */ }
-    else if (acc.fwd) VAP_LANES_LAUNCH(true, true);      // (routes with max_acceleration rows always carry initial velocities too)
+    if (acc.fwd) VAP_LANES_LAUNCH(true, true);      // (routes with max_acceleration rows always carry initial velocities too)
     else if (vcap) VAP_LANES_LAUNCH(true, false);
     else VAP_LANES_LAUNCH(false, false);
 #undef VAP_LANES_LAUNCH
@@ -674,28 +609,12 @@ hipError_t launch_velocity_lanes(hipStream_t st, bool io64, int B, int S, const 
     if (acc.fwd && !vcap) return hipErrorInvalidValue;
     const int P = group > 0 ? group : velocity_lanes_group(B);
 #define VAP_LANES(IO_)                                                                                                          \
-    (P == 16 ? launch_lanes_p<IO_, 16>(st, B, S, c, sv, ev, meta, (const double *)curv, (const double *)dth, vcap, acc, vel, (double *)ufwd, nullptr, vres) \
-     : P == 32 ? launch_lanes_p<IO_, 32>(st, B, S, c, sv, ev, meta, (const double *)curv, (const double *)dth, vcap, acc, vel, (double *)ufwd, nullptr, vres) \
-               : launch_lanes_p<IO_, 64>(st, B, S, c, sv, ev, meta, (const double *)curv, (const double *)dth, vcap, acc, vel, (double *)ufwd, nullptr, vres))
+    (P == 16 ? launch_lanes_p<IO_, 16>(st, B, S, c, sv, ev, meta, (const double *)curv, (const double *)dth, vcap, acc, vel, (double *)ufwd, vres) \
+     : P == 32 ? launch_lanes_p<IO_, 32>(st, B, S, c, sv, ev, meta, (const double *)curv, (const double *)dth, vcap, acc, vel, (double *)ufwd, vres) \
+               : launch_lanes_p<IO_, 64>(st, B, S, c, sv, ev, meta, (const double *)curv, (const double *)dth, vcap, acc, vel, (double *)ufwd, vres))
     if (io64) return VAP_LANES(double);
     return VAP_LANES(float);
 #undef VAP_LANES
-}
-
-// The fused step of the default mode (fp32 rows, fp64 recurrence, plain paths): sampling (K3+K4) inside the forward
-// producers of K5w, 16 paths per workgroup.  Writes the caller's rows (any of ox..ok may be NULL), the fp64 side rows
-// k64 / dth64 (context scratch) and the velocities; ufwd as in launch_velocity_lanes.
-hipError_t launch_sample_velocity_fused(hipStream_t st, int B, int W, int S, const double c[6], double sv, double ev,
-                                        const double *meta, const double *power, const double *lut, const double *aux,
-                                        const double *runs, float *ox, float *oy, float *oh, float *ok, double *k64, double *dth64,
-                                        float *vel, double *ufwd, float *vres)
-{
-    FusedArgs f;
-    f.power = power; f.lut = lut; f.aux = aux; f.runs = runs;
-    f.ox = ox; f.oy = oy; f.oh = oh; f.ok = ok;
-    f.k64 = k64; f.dth64 = dth64;
-    f.W = W;
-    return launch_lanes_p<float, 16>(st, B, S, c, sv, ev, meta, k64, dth64, nullptr, AccRowsV(), vel, ufwd, &f, vres);
 }
 
 }  // namespace vap

@@ -127,3 +127,22 @@ def path_summaries(meta: torch.Tensor, velocity: Optional[torch.Tensor] = None) 
         vm = torch.where(valid, 0.5 * (v + torch.roll(v, -1, dims=1)), torch.ones_like(v))
         out[:, 2] = torch.where(valid, meta[:, 2:3] / vm, torch.zeros_like(v)).sum(dim=1)
     return out
+
+
+def comm_record(device) -> dict:
+    """What the communicator itself says about the run, for bench.py's JSON line: backend, the world size the process
+    group reports, the RCCL version in use, and `ranks_reporting` = an all-reduce (sum) of one 1 per rank over that
+    backend — N on an N-rank run only if every rank really took part in a collective."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"backend": None, "world_size": 1, "rccl": None, "ranks_reporting": 1}
+    backend = dist.get_backend()
+    one = torch.ones(1, dtype=torch.int64, device=torch.device("cpu") if backend == "gloo" else device)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    rccl = None
+    if backend == "nccl":
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:       # (a torch build without the query: the record says so rather than failing the bench)
+            rccl = "unknown"
+    return {"backend": "rccl (torch.distributed 'nccl')" if backend == "nccl" else backend, "world_size": dist.get_world_size(),
+            "rccl": rccl, "ranks_reporting": int(one.item())}

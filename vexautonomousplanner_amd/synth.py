@@ -31,3 +31,13 @@ def make_waypoints(batch: int, n_waypoints: int, seed: int, dtype=np.float32) ->
     pts[:, 1:, 0] = -5.0 + np.cumsum(step * np.cos(psi), axis=1)
     pts[:, 1:, 1] = -5.0 + np.cumsum(step * np.sin(psi), axis=1)
     return np.ascontiguousarray(pts.astype(dtype))
+
+
+def make_waypoints_block(paths_per_block: int, n_waypoints: int, seed: int, block: int, dtype=np.float32) -> np.ndarray:
+    """Block `block` of the seeded GLOBAL batch a multi-GPU run works on: the global batch is the concatenation of
+    blocks of ``paths_per_block`` paths, block 0 being ``make_waypoints(paths_per_block, W, seed)`` (so a 1-GPU run is
+    the batch it always was) and block r > 0 drawn from the stream ``(seed, r)``.  Rank r of a weak-scaling run
+    generates block r alone — nobody builds the other ranks' paths."""
+    if block == 0:
+        return make_waypoints(paths_per_block, n_waypoints, seed, dtype)
+    return make_waypoints(paths_per_block, n_waypoints, [int(seed), int(block)], dtype)
