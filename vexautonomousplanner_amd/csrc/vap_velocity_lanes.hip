@@ -37,6 +37,7 @@ namespace {
 constexpr int kLanesThreads = 768;                        // twelve waves: three per SIMD (the chain loop's banks of four steps leave room)
 constexpr int kLanesStats = 32;                           // long longs per workgroup of VAP_LANES_STATS
 constexpr int kLanesProducers = kLanesThreads / 64 - 1;   // wave 0 is the chain wave
+constexpr int kPrefetchDepth = 1;                         // tiles between a row load and its use
 constexpr int kPairBytes = 80;                            // the records of two consecutive samples of a path (vap_chain_asm.h)
 constexpr int kTileRecords = 1024;                        // (path, sample) slots per tile = 16 producer batches of 64
 constexpr int kTileBatches = kTileRecords / 64;
@@ -60,16 +61,26 @@ __device__ __forceinline__ int batch_of(int wv, int i)   // tile batch i-th of w
 template <int P>
 struct LanesGeo {
     static constexpr int TS = kTileRecords / P;            // samples per tile
+    // 16 paths per workgroup: the ROTATING chain (vap_chain_asm.h) — a path owns a quad of chain lanes, the state travels
+    // round the quad, every lane reads the records of its own four steps of a group of sixteen: the record tile is laid
+    // out by (group, plane, chain lane).  32 / 64 paths: lane = path, records by (pair of samples, path).
+    static constexpr bool ROT = P == 16;
     static constexpr int stride = P * kPairBytes + 64;     // bytes between consecutive sample PAIRS' records (the +64: the
                                                            // producers' 16-byte stores of eight consecutive samples then
                                                            // fall into eight different bank groups)
-    static constexpr int rec_bytes = (TS / 2) * stride;    // one record tile
+    static constexpr int rec_bytes = ROT ? kRotTileBytes : (TS / 2) * stride;    // one record tile
     static constexpr int out_row = TS + 2;                 // doubles per path in a result tile (padded: bank spread)
     static constexpr int out_bytes = P * out_row * 8;
     static constexpr size_t lds_bytes = 2 * (size_t)rec_bytes + 2 * (size_t)out_bytes;
     // byte offsets of sample s of path p inside a record tile: its {rho, g | am, A} half-pair and its cap
-    __host__ __device__ static constexpr int rec_off(int p, int s) { return (s >> 1) * stride + p * kPairBytes + (s & 1) * 32; }
-    __host__ __device__ static constexpr int cap_off(int p, int s) { return (s >> 1) * stride + p * kPairBytes + 64 + (s & 1) * 8; }
+    __host__ __device__ static constexpr int rec_off(int p, int s)
+    {
+        return ROT ? rot_rec_off(p, s) : (s >> 1) * stride + p * kPairBytes + (s & 1) * 32;
+    }
+    __host__ __device__ static constexpr int cap_off(int p, int s)
+    {
+        return ROT ? rot_cap_off(p, s) : (s >> 1) * stride + p * kPairBytes + 64 + (s & 1) * 8;
+    }
 };
 
 // Workgroup barrier for LDS hand-offs only: this wave's LDS operations have completed (they complete in order), global
@@ -122,7 +133,7 @@ struct Lanes {
     IO *V;
     double *UF;
     bool stats_on = false;  // VAP_LANES_STATS: time the producers' wait for their rows
-    mutable long long t_take = 0;
+    mutable long long t_take = 0, t_loads = 0;   // (VAP_LANES_STATS, producer 0: waiting for its rows, issuing the next loads)
     float *RES;             // fp32 rows: what the stored velocity lost, v64 - (double)(float)v64 (for the time domain)
     double end_u;
     unsigned char *rec;     // LDS: two record tiles
@@ -288,7 +299,8 @@ struct Lanes {
             if constexpr (ACC) cur[i].acc = opaque(cur[i].acc);
             if constexpr (VCAP && !BWD) cur[i].vc = opaque(cur[i].vc);
         }
-        if (stats_on) t_take += __builtin_amdgcn_s_memtime() - tk0;
+        const long long tk1 = stats_on ? __builtin_amdgcn_s_memtime() : 0;
+        if (stats_on) t_take += tk1 - tk0;
         __builtin_amdgcn_sched_barrier(0);
         // (unconditional: a tile index outside the row loads clamped, unused values)
 #pragma unroll
@@ -297,6 +309,7 @@ struct Lanes {
             else load_fwd<INT>(ctx[i], t_load, nxt[i]);
         }
         __builtin_amdgcn_sched_barrier(0);
+        const long long tk2 = stats_on ? __builtin_amdgcn_s_memtime() : 0;
         if (INT || (t_put >= 0 && t_put < NT)) {
             unsigned char *rt = rec + (size_t)parity * G::rec_bytes;
 #pragma unroll
@@ -313,6 +326,7 @@ struct Lanes {
                 else flush_fwd<INT>(ctx[i], t_flush, ot);
             }
         }
+        if (stats_on) t_loads += tk2 - tk1;
     }
     // pipeline step `it` of a sweep over NT tiles (tile #n of the backward sweep is row tile NT-1-n); nmin = the fewest
     // samples of any path slot of the group (-1 when the group is not full)
@@ -325,8 +339,8 @@ struct Lanes {
         // a row tile every index of which — of the loads (j-2 .. j / j .. j+2), the records and the stores — is a sample
         // that holds a step in every path of the group
         auto interior = [nmin](int r) { return BWD ? (r + 1) * TS <= nmin - 2 : (r >= 1 && (r + 1) * TS <= nmin - 1); };
-        const int t_load = rt(it + 1), t_put = it < NT ? rt(it) : -1, t_flush = (it >= 2 && it - 2 < NT) ? rt(it - 2) : -1;
-        const bool all_int = it >= 2 && it + 1 < NT && interior(t_load) && interior(t_put) && interior(t_flush);
+        const int t_load = rt(it + kPrefetchDepth), t_put = it < NT ? rt(it) : -1, t_flush = (it >= 2 && it - 2 < NT) ? rt(it - 2) : -1;
+        const bool all_int = it >= 2 && it + kPrefetchDepth < NT && interior(t_load) && interior(t_put) && interior(t_flush);
         if (all_int) {
             if (four) producer_step_n<BWD, kBatchesPerProducer, true>(ctx, NT, t_load, t_put, t_flush, it & 1, cur, nxt, saw_dup);
             else producer_step_n<BWD, kBatchesPerProducer - 1, true>(ctx, NT, t_load, t_put, t_flush, it & 1, cur, nxt, saw_dup);
@@ -353,6 +367,8 @@ __global__ __launch_bounds__(kLanesThreads, 3) void k_velocity_lanes(int B, int 
 {
     using G = LanesGeo<P>;
     constexpr int TS = G::TS;
+    const long long t_entry = stats ? __builtin_amdgcn_s_memtime() : 0;
+    const long long r_entry = stats ? __builtin_amdgcn_s_memrealtime() : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ PathConsts s_pc[P];
     __shared__ int s_nmax, s_nmin, s_pdup[P], s_tdup[2];
@@ -408,15 +424,24 @@ __global__ __launch_bounds__(kLanesThreads, 3) void k_velocity_lanes(int B, int 
         // chain-bound groups (16 paths): the chain wave goes first on its SIMD; larger groups are producer-bound, and the
         // producer wave that shares the SIMD needs the issue slots more than the chain does
         if constexpr (P == 16) __builtin_amdgcn_s_setprio(2);
+        // chain lane -> (records, result row): lane = path, or (rotating chain) lane = 4 * path + quad position
         const uint32_t rec0 = (uint32_t)(uintptr_t)(L.rec + lane * kPairBytes);
-        const uint32_t out0 = (uint32_t)(uintptr_t)(L.out + lane * G::out_row);
+        const uint32_t out0 = G::ROT ? (uint32_t)(uintptr_t)(L.out + (lane >> 2) * G::out_row + 4 * (lane & 3))
+                                     : (uint32_t)(uintptr_t)(L.out + lane * G::out_row);
+        const bool chain_lane = G::ROT || lane < P;
+        constexpr uint64_t kQ0 = 0x1111111111111111ull;   // the quads' lanes 0 (<< r: lanes r)
         double u = start_u, up = 0.0;
         long long t_chain = 0, t_all = stats ? __builtin_amdgcn_s_memtime() : 0;
         for (int it = 0; it <= NT + 1; it++) {
             const long long t0 = stats ? __builtin_amdgcn_s_memtime() : 0;
-            if (it >= 1 && it <= NT && lane < P) {
+            if (it >= 1 && it <= NT) {
                 const int par = (it - 1) & 1;
-                chain_fwd<G::stride, TS>(rec0 + par * G::rec_bytes, out0 + par * G::out_bytes, u, up);
+                if constexpr (G::ROT) {
+                    chain_rot_fwd<kRotGroup, kRotPlane>(rec0 + par * G::rec_bytes, out0 + par * G::out_bytes, u, up, kQ0, kQ0 << 1, kQ0 << 2,
+                                                        kQ0 << 3);
+                } else if (chain_lane) {
+                    chain_fwd<G::stride, TS>(rec0 + par * G::rec_bytes, out0 + par * G::out_bytes, u, up);
+                }
             }
             if (stats) t_chain += __builtin_amdgcn_s_memtime() - t0;
             lds_barrier();
@@ -429,16 +454,24 @@ __global__ __launch_bounds__(kLanesThreads, 3) void k_velocity_lanes(int B, int 
         long long t_chain_b = 0;
         for (int it = 0; it <= NT + 1; it++) {
             const long long t0 = stats ? __builtin_amdgcn_s_memtime() : 0;
-            if (it >= 1 && it <= NT && lane < P) {
+            if (it >= 1 && it <= NT) {
                 const int par = (it - 1) & 1;
-                const bool dup = s_tdup[par] != 0;
-                if (!dup) {
-                    chain_bwd<G::stride, TS>(rec0 + par * G::rec_bytes, out0 + par * G::out_bytes, u, up);
-                } else {
-                    // a path with a zero heading difference somewhere (dense grids): the sign-aware step, MPG:52-59, for the
-                    // whole tile — the same batched loop with the step in its two-FMA form (vap_chain_asm.h; on every other
-                    // sample the two steps are the same arithmetic)
-                    chain_bwd_dup<G::stride, TS>(rec0 + par * G::rec_bytes, out0 + par * G::out_bytes, u, up);
+                const bool dup = s_tdup[par] != 0;      // (wave-uniform)
+                // a tile with a zero heading difference somewhere (dense grids): the sign-aware step, MPG:52-59, for the
+                // whole tile — the same loop with the step in its two-FMA form (vap_chain_asm.h; on every other sample the
+                // two steps are the same arithmetic)
+                if constexpr (G::ROT) {
+                    if (!dup)
+                        chain_rot_bwd<kRotGroup, kRotPlane>(rec0 + par * G::rec_bytes, out0 + par * G::out_bytes, u, up, kQ0, kQ0 << 1,
+                                                            kQ0 << 2, kQ0 << 3);
+                    else
+                        chain_rot_bwd_dup<kRotGroup, kRotPlane>(rec0 + par * G::rec_bytes, out0 + par * G::out_bytes, u, up, kQ0, kQ0 << 1,
+                                                                kQ0 << 2, kQ0 << 3);
+                } else if (chain_lane) {
+                    if (!dup) chain_bwd<G::stride, TS>(rec0 + par * G::rec_bytes, out0 + par * G::out_bytes, u, up);
+                    else chain_bwd_dup<G::stride, TS>(rec0 + par * G::rec_bytes, out0 + par * G::out_bytes, u, up);
+                }
+                if (dup) {
                     if (lane == 0) s_tdup[par] = 0;   // (the producers raise it again two steps on, behind a barrier)
                     dup_tiles++;
                 }
@@ -454,6 +487,8 @@ __global__ __launch_bounds__(kLanesThreads, 3) void k_velocity_lanes(int B, int 
             st[3] = t_chain_b;
             st[4] = __builtin_amdgcn_s_memtime() - t_all;      // both sweeps
             st[6] = dup_tiles;
+            st[20] = __builtin_amdgcn_s_memtime() - t_entry;         // kernel entry to the end of the backward sweep, shader clock
+            st[21] = __builtin_amdgcn_s_memrealtime() - r_entry;     // ... and on the constant 100 MHz clock
         }
         return;
     }
@@ -522,6 +557,9 @@ __global__ __launch_bounds__(kLanesThreads, 3) void k_velocity_lanes(int B, int 
     sweep(std::true_type());
     if (stats && tid == 64) stats[(size_t)blockIdx.x * kLanesStats + 7] = t_busy;   // ... both sweeps
     if (stats && tid == 64) stats[(size_t)blockIdx.x * kLanesStats + 31] = L.t_take;   // producer 0: of that, waiting for its rows
+    if (stats && tid == 64) {                                                           // ... issuing loads, records, moving results out
+        stats[(size_t)blockIdx.x * kLanesStats + 28] = L.t_loads;
+    }
     if (stats && lane == 0) stats[(size_t)blockIdx.x * kLanesStats + 8 + pw] = t_busy;   // every producer, both sweeps
     // rows longer than the longest path of the group: zeros past the last tile
     for (int p = 0; p < P; p++) {
@@ -584,9 +622,26 @@ hipError_t launch_lanes_p(hipStream_t st, int B, int S, const double c[6], doubl
             for (int k = 0; k < kLanesStats; k++) sum[k] += (double)h[(size_t)w * kLanesStats + k] / grid.x;
         fprintf(stderr, "[lanes P=%d, %u workgroups, %d producers] tiles %.0f | mean ticks: forward chain loops %.0f of sweep %.0f | backward chain loops %.0f | both sweeps %.0f | producer 0 busy forward %.0f, both %.0f | per step: chain %.1f, sweep %.1f | backward tiles with a zero heading difference %.2f\n",
                 P, grid.x, kLanesProducers, sum[0], sum[1], sum[2], sum[3], sum[4], sum[5], sum[7], sum[1] / (sum[0] * G::TS), sum[2] / (sum[0] * G::TS), sum[6]);
+        {   // the spread over workgroups of the chain wave's time for both sweeps, and by XCD (workgroup w runs on XCD w % 8)
+            long long mn = h[4], mx = h[4];
+            double xcd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            int nx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (unsigned w = 0; w < grid.x; w++) {
+                const long long v = h[(size_t)w * kLanesStats + 4];
+                mn = v < mn ? v : mn;
+                mx = v > mx ? v : mx;
+                xcd[w % 8] += (double)v;
+                nx[w % 8]++;
+            }
+            fprintf(stderr, "        both sweeps over workgroups: min %lld max %lld | mean by XCD:", mn, mx);
+            for (int x = 0; x < 8; x++) fprintf(stderr, " %.0f", nx[x] ? xcd[x] / nx[x] : 0.0);
+            fprintf(stderr, "\n");
+        }
+        fprintf(stderr, "        entry to end of the backward sweep: %.0f shader cycles in %.1f us (100 MHz clock): %.2f GHz\n", sum[20], sum[21] / 100.0,
+                sum[20] / (sum[21] * 10.0));
         fprintf(stderr, "        producers busy, both sweeps:");
         for (int k = 0; k < kLanesProducers; k++) fprintf(stderr, " %.0f", sum[8 + k]);
-        fprintf(stderr, " | producer 0 waiting for its rows: %.0f\n", sum[31]);
+        fprintf(stderr, " | producer 0: waiting for its rows %.0f, issuing loads %.0f\n", sum[31], sum[28]);
     }
     return hipGetLastError();
 }
