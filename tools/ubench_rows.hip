@@ -47,10 +47,10 @@ constexpr size_t lanes_lds_bytes()   // LanesGeo<P>::lds_bytes of vap_velocity_l
 
 struct Slot { size_t row; int s, p; bool live; };
 
-template <int P, int LAYOUT, bool BARRIER>
+template <int P, int LAYOUT, bool BARRIER, bool STORES_FIRST = false>
 __global__ __launch_bounds__(kThreads, 3) void k_rows(int B, int S, const double *__restrict__ K, const double *__restrict__ DT,
                                                       const double2 *__restrict__ REC, double *__restrict__ UF,
-                                                      float *__restrict__ V, float *__restrict__ RES)
+                                                      float *__restrict__ V, float *__restrict__ RES, int work)
 {
     constexpr int TS = kTileRecords / P;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -91,6 +91,26 @@ __global__ __launch_bounds__(kThreads, 3) void k_rows(int B, int S, const double
             double a0[kBPP], a1[kBPP], a2[kBPP], a3[kBPP];
 #pragma unroll
             for (int i = 0; i < kBPP; i++) { a0[i] = opaque(k0[i]); a1[i] = opaque(k1[i]); a2[i] = opaque(dt[i]); a3[i] = opaque(uf[i]); }
+            const int parity = it & 1;
+            if (STORES_FIRST) {
+            const int tf = it - 2;
+            if (tf >= 0 && tf < NT) {
+                const int tile_f = dir == 0 ? tf : NT - 1 - tf;
+#pragma unroll
+                for (int i = 0; i < kBPP; i++) {
+                    if (i == 1 && !two) continue;
+                    const int j = tile_f * TS + c[i].s;
+                    const double v = ot[(size_t)parity * P * (TS + 2) + c[i].p * (TS + 2) + c[i].s];
+                    if (c[i].live && j < S) {
+                        if (dir == 0) UF[c[i].row + j] = v;
+                        else {
+                            __builtin_nontemporal_store((float)v, &V[c[i].row + j]);
+                            __builtin_nontemporal_store((float)(v - (double)(float)v), &RES[c[i].row + j]);
+                        }
+                    }
+                }
+            }
+            }
             __builtin_amdgcn_sched_barrier(0);
             const int tl = it + 1, tile = dir == 0 ? tl : NT - 1 - tl;
 #pragma unroll
@@ -111,7 +131,9 @@ __global__ __launch_bounds__(kThreads, 3) void k_rows(int B, int S, const double
                 if (dir == 1) uf[i] = UF[at(c[i], j)];
             }
             __builtin_amdgcn_sched_barrier(0);
-            const int parity = it & 1;
+            // `work` dependent fp64 FMAs (8 cycles each) between the loads and the stores: the time K5w's producers spend
+            // deriving records, during which they issue no memory operation
+            for (int w = 0; w < work; w++) a0[0] = fma(a0[0], 1.0000001, 1e-9);
             if (it >= 0 && it < NT) {
 #pragma unroll
                 for (int i = 0; i < kBPP; i++) {
@@ -119,6 +141,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_rows(int B, int S, const double
                     ot[(size_t)parity * P * (TS + 2) + c[i].p * (TS + 2) + c[i].s] = a0[i] + a1[i] * 1e-9 + a2[i] + a3[i] * 1e-9;
                 }
             }
+            if (!STORES_FIRST) {
             const int tf = it - 2;
             if (tf >= 0 && tf < NT) {
                 const int tile_f = dir == 0 ? tf : NT - 1 - tf;
@@ -135,6 +158,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_rows(int B, int S, const double
                         }
                     }
                 }
+            }
             }
             if (BARRIER && it >= 0) lds_barrier();
         }
@@ -160,20 +184,20 @@ __global__ void k_copy4(size_t n4, const float4 *__restrict__ src, float4 *__res
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
-template <int P, int LAYOUT, bool BARRIER>
-double run(int B, int S, const double *K, const double *DT, const double2 *REC, double *UF, float *V, float *RES, int reps)
+template <int P, int LAYOUT, bool BARRIER, bool STORES_FIRST = false>
+double run(int B, int S, const double *K, const double *DT, const double2 *REC, double *UF, float *V, float *RES, int reps, int work = 0)
 {
-    auto kern = k_rows<P, LAYOUT, BARRIER>;
+    auto kern = k_rows<P, LAYOUT, BARRIER, STORES_FIRST>;
     const size_t lds = lanes_lds_bytes<P>();
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const dim3 grid((B + P - 1) / P), block(kThreads);
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; i++) hipLaunchKernelGGL(kern, grid, block, lds, 0, B, S, K, DT, REC, UF, V, RES);
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL(kern, grid, block, lds, 0, B, S, K, DT, REC, UF, V, RES, work);
     CHECK(hipDeviceSynchronize());
     CHECK(hipEventRecord(e0));
-    for (int i = 0; i < reps; i++) hipLaunchKernelGGL(kern, grid, block, lds, 0, B, S, K, DT, REC, UF, V, RES);
+    for (int i = 0; i < reps; i++) hipLaunchKernelGGL(kern, grid, block, lds, 0, B, S, K, DT, REC, UF, V, RES, work);
     CHECK(hipEventRecord(e1));
     CHECK(hipEventSynchronize(e1));
     CHECK(hipGetLastError());
@@ -238,6 +262,22 @@ int main()
         printf("%-52s", c.name);
         for (int i = 0; i < 4; i++) printf(" %5.3f|%4.2f", t[i], bytes / (t[i] * 1e-3) / 1e12);
         printf("\n");
+    }
+    // the same rows with the producers busy between their loads and their stores (no memory operation issued meanwhile)
+    printf("\nproducers busy for `work` loop iterations (~26 cycles each: a dependent FMA + the loop) per tile step between their loads and the barrier,\nrows as K5w reads them; the results of two tiles back stored LAST in the step (after the work) or FIRST (before the loads):\n");
+    for (int work : {0, 25, 50, 75, 100}) {
+        const double t3 = run<16, 0, true>(4096, 10000, K, DT, REC, UF, V, RES, 10, work);
+        const double t4 = run<32, 0, true>(8192, 10000, K, DT, REC, UF, V, RES, 10, work);
+        const double t5 = run<64, 0, true>(131072, 1024, K, DT, REC, UF, V, RES, 10, work);
+        const double u3 = run<16, 0, true, true>(4096, 10000, K, DT, REC, UF, V, RES, 10, work);
+        const double u4 = run<32, 0, true, true>(8192, 10000, K, DT, REC, UF, V, RES, 10, work);
+        const double u5 = run<64, 0, true, true>(131072, 1024, K, DT, REC, UF, V, RES, 10, work);
+        printf("work %3d: stores LAST  c3 %.3f ms %.2f TB/s | c4 %.3f ms %.2f TB/s | c5 %.3f ms %.2f TB/s\n", work, t3,
+               56.0 * 4096 * 10000 / (t3 * 1e-3) / 1e12, t4, 56.0 * 8192 * 10000 / (t4 * 1e-3) / 1e12, t5,
+               56.0 * 131072 * 1024 / (t5 * 1e-3) / 1e12);
+        printf("          stores FIRST c3 %.3f ms %.2f TB/s | c4 %.3f ms %.2f TB/s | c5 %.3f ms %.2f TB/s\n", u3,
+               56.0 * 4096 * 10000 / (u3 * 1e-3) / 1e12, u4, 56.0 * 8192 * 10000 / (u4 * 1e-3) / 1e12, u5,
+               56.0 * 131072 * 1024 / (u5 * 1e-3) / 1e12);
     }
     return 0;
 }

@@ -302,6 +302,20 @@ struct Lanes {
         const long long tk1 = stats_on ? __builtin_amdgcn_s_memtime() : 0;
         if (stats_on) t_take += tk1 - tk0;
         __builtin_amdgcn_sched_barrier(0);
+        // The results of tile `t_flush` go out FIRST, ahead of the next loads: the take of the next step waits for
+        // everything this wave has in flight (vmcnt(0): the compiler cannot count through the loop), and stores issued at
+        // the END of a step would still be on their way to memory then — their whole latency would be exposed once per tile
+        // (tools/ubench_rows.hip: with the stores last, the time the producers spend deriving records ADDS to the memory
+        // time; with the stores first it hides behind it).  Issued here they have the whole step.
+        if (INT || (t_flush >= 0 && t_flush < NT)) {
+            const double *ot = out + (size_t)parity * (G::out_bytes / 8);   // the tile two steps back shares this step's parity
+#pragma unroll
+            for (int i = 0; i < NB; i++) {
+                if constexpr (BWD) flush_bwd<INT>(ctx[i], t_flush, ot);
+                else flush_fwd<INT>(ctx[i], t_flush, ot);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
         // (unconditional: a tile index outside the row loads clamped, unused values)
 #pragma unroll
         for (int i = 0; i < NB; i++) {
@@ -316,14 +330,6 @@ struct Lanes {
             for (int i = 0; i < NB; i++) {
                 if constexpr (BWD) put_bwd<INT>(ctx[i], t_put, cur[i], rt, parity, saw_dup[i]);
                 else put_fwd<INT>(ctx[i], t_put, cur[i], rt, saw_dup[i]);
-            }
-        }
-        if (INT || (t_flush >= 0 && t_flush < NT)) {
-            const double *ot = out + (size_t)parity * (G::out_bytes / 8);   // the tile two steps back shares this step's parity
-#pragma unroll
-            for (int i = 0; i < NB; i++) {
-                if constexpr (BWD) flush_bwd<INT>(ctx[i], t_flush, ot);
-                else flush_fwd<INT>(ctx[i], t_flush, ot);
             }
         }
         if (stats_on) t_loads += tk2 - tk1;
