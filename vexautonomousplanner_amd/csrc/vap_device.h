@@ -41,16 +41,19 @@ __device__ __forceinline__ void normalize_parameter(double t, double t_max, int 
 
 // QHS:324-363 first-derivative basis, in the reference's own association order (no FMA): used where
 // bit-identical arc-length tables matter (SM:447).
-__device__ __forceinline__ void hermite_d1_ref(const double *__restrict__ sg, double t, double &ox, double &oy)
+__device__ __forceinline__ void hermite_d1_basis_ref(double t, double H[6])
 {
     const double t2 = t * t, t3 = t2 * t, t4 = t3 * t;
-    double H[6];
     H[0] = -30 * t2 + 60 * t3 - 30 * t4;
     H[1] = 30 * t2 - 60 * t3 + 30 * t4;
     H[2] = 1 - 18 * t2 + 32 * t3 - 15 * t4;
     H[3] = -12 * t2 + 28 * t3 - 15 * t4;
     H[4] = t - 4.5 * t2 + 6 * t3 - 2.5 * t4;
     H[5] = 1.5 * t2 - 4 * t3 + 2.5 * t4;
+}
+// ... and the sum over the segment's rows, accumulated from zero in row order (QHS:482-484)
+__device__ __forceinline__ void hermite_combine_ref(const double *__restrict__ sg, const double H[6], double &ox, double &oy)
+{
     double ax = 0.0, ay = 0.0;
 #pragma unroll
     for (int i = 0; i < 6; i++) {
@@ -59,6 +62,12 @@ __device__ __forceinline__ void hermite_d1_ref(const double *__restrict__ sg, do
     }
     ox = ax;
     oy = ay;
+}
+__device__ __forceinline__ void hermite_d1_ref(const double *__restrict__ sg, double t, double &ox, double &oy)
+{
+    double H[6];
+    hermite_d1_basis_ref(t, H);
+    hermite_combine_ref(sg, H, ox, oy);
 }
 
 // QHS:288-322 / 324-363 / 365-416 / 418-469 the position, first-, second- and third-derivative bases in the reference's
@@ -555,6 +564,18 @@ __device__ __forceinline__ double fast_rcp(double x)
     r = fma(r, fma(-x, r, 1.0), r);
     r = fma(r, fma(-x, r, 1.0), r);
     return r;
+}
+// a / b for operands and quotient well inside the normal range (the arc-length table's interval slopes): the core of the
+// IEEE division sequence — reciprocal estimate, two Newton steps, quotient, one residual correction — without its
+// scaling and fix-up instructions (9 instead of 15).  The same quotient as `/` on such operands; every place that forms
+// the interval slopes (SM:311-317) goes through this one function, so they agree with each other whatever the case.
+__device__ __forceinline__ double div_inrange(double a, double b)
+{
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(fma(-b, r, 1.0), r, r);
+    r = fma(fma(-b, r, 1.0), r, r);
+    const double q = a * r;
+    return fma(fma(-b, q, a), r, q);
 }
 __device__ __forceinline__ float vmin(float a, float b) { return fminf(a, b); }
 __device__ __forceinline__ double vmin(double a, double b) { return fmin(a, b); }

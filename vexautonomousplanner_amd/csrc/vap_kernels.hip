@@ -305,7 +305,7 @@ __device__ __forceinline__ void lut_path(int W, const double *__restrict__ segme
             double w = 0.0;
             if (j > 0) {
                 const double t0 = (double)(j - 1) * lstep, t1 = (j == kLutN - 1) ? t_max : (double)j * lstep;
-                w = (t1 - t0) / (cum[j] - cum[j - 1]);
+                w = div_inrange(t1 - t0, cum[j] - cum[j - 1]);
             }
             slopes[row * kLutN + j] = w;
         }
@@ -372,8 +372,31 @@ __global__ __launch_bounds__(kLutManyThreads) void k_lut_many(int B, int W, cons
     extern __shared__ __attribute__((aligned(16))) double s_seg[];     // the 64 paths' segment rows: P * G * 12
     __shared__ double s_mag[P * ST], s_inc[P * ST];
     __shared__ double s_prev_mag[P], s_carry[P], s_prev_cum[P], s_tmax[P], s_step[P];
+    // Paths whose parameters[-1] is exactly W-1 (most: 78 % of config 5's — the rest are an ulp off, QHS:719-736) share
+    // their table parameters linspace(0, W-1, 1000), hence segment index, local parameter and the six basis values of
+    // every entry: those are evaluated ONCE per entry and workgroup (the reference's expressions, so the same bits), one
+    // tile ahead, and a path of that class reads them instead of repeating ~40 of its ~130 operations per entry.
+    // (one buffer, rewritten for the next tile right after the barrier that ends a tile's magnitude phase; bytes where
+    // bytes do: two of these workgroups share a CU's 160 KB only while each stays under 80 KB)
+    __shared__ double s_H[TE][6];
+    __shared__ unsigned char s_hidx[TE], s_std[P];
     const int tid = threadIdx.x, b0 = blockIdx.x * P;
     const int G = W - 1;
+    auto shared_basis = [&](int tile) {      // threads 0..TE-1: the class's entries of `tile`
+        const int j = tile * TE + tid;
+        if (tid < TE && j < kLutN) {
+            const double t_max = (double)G;
+            const double step = t_max / (double)(kLutN - 1);
+            const double t = (j == kLutN - 1) ? t_max : (double)j * step;
+            double lt, H[6];
+            int idx;
+            normalize_parameter(t, t_max, G, lt, idx);
+            hermite_d1_basis_ref(lt, H);
+#pragma unroll
+            for (int i = 0; i < 6; i++) s_H[tid][i] = H[i];
+            s_hidx[tid] = (unsigned char)idx;    // (W <= 64 in both group sizes)
+        }
+    };
     const int n_paths = B - b0 < P ? B - b0 : P;
     lds_fill<4>(s_seg, segments + (size_t)b0 * G * 12, n_paths * G * 12, tid, kLutManyThreads);
     if (tid < P) {
@@ -384,7 +407,9 @@ __global__ __launch_bounds__(kLutManyThreads) void k_lut_many(int B, int W, cons
         // and its twin in dt and in the slope — for every one of the 1000 entries (five IEEE divisions per entry
         // where one is needed)
         s_step[tid] = tm / (double)(kLutN - 1);
+        s_std[tid] = tm == (double)G;
     }
+    shared_basis(0);
     __syncthreads();
     constexpr int kTiles = (kLutN + TE - 1) / TE;
 #pragma unroll 1
@@ -396,18 +421,27 @@ __global__ __launch_bounds__(kLutManyThreads) void k_lut_many(int B, int W, cons
             const int it = tid + r * kLutManyThreads, p = it / TE, e = it % TE, j = j0 + e, b = b0 + p;
             double m = 0.0;
             if (b < B && j < kLutN) {
-                const double t_max = s_tmax[p];
-                const double t = (j == kLutN - 1) ? t_max : (double)j * s_step[p];   // linspace_at(t_max, kLutN, j)
-                double lt;
+                double H[6];
                 int idx;
-                normalize_parameter(t, t_max, G, lt, idx);
+                if (s_std[p]) {
+#pragma unroll
+                    for (int i = 0; i < 6; i++) H[i] = s_H[e][i];
+                    idx = s_hidx[e];
+                } else {
+                    const double t_max = s_tmax[p];
+                    const double t = (j == kLutN - 1) ? t_max : (double)j * s_step[p];   // linspace_at(t_max, kLutN, j)
+                    double lt;
+                    normalize_parameter(t, t_max, G, lt, idx);
+                    hermite_d1_basis_ref(lt, H);
+                }
                 double dx, dy;
-                hermite_d1_ref(s_seg + ((size_t)p * G + idx) * 12, lt, dx, dy);
+                hermite_combine_ref(s_seg + ((size_t)p * G + idx) * 12, H, dx, dy);
                 m = sqrt(dx * dx + dy * dy);
             }
             s_mag[p * ST + e] = m;
         }
         __syncthreads();
+        if (tl + 1 < kTiles) shared_basis(tl + 1);     // (this tile's readers are past the barrier; the next tile's come after two more)
         // trapezoid increments (SM:452-454: (m[j-1] + m[j]) * 0.5 * dt, that association)
 #pragma unroll
         for (int r = 0; r < P * TE / kLutManyThreads; r++) {
@@ -456,7 +490,7 @@ __global__ __launch_bounds__(kLutManyThreads) void k_lut_many(int B, int W, cons
                         const double lstep = s_step[p];
                         const double t0 = (double)(j - 1) * lstep, t1 = (j == kLutN - 1) ? t_max : (double)j * lstep;
                         const double cp = e > 0 ? s_mag[p * ST + e - 1] : s_prev_cum[p];
-                        w = (t1 - t0) / (c - cp);
+                        w = div_inrange(t1 - t0, c - cp);
                     }
                     slopes[(size_t)b * kLutN + j] = w;
                 }
@@ -487,7 +521,7 @@ __global__ void k_lut_slopes(int B, const double *__restrict__ lut, const double
     double w = 0.0;
     if (j > 0) {
         const double t0 = (double)(j - 1) * lstep, t1 = (j == kLutN - 1) ? t_max : (double)j * lstep;
-        w = (t1 - t0) / (lut[i] - lut[i - 1]);
+        w = div_inrange(t1 - t0, lut[i] - lut[i - 1]);
     }
     slopes[i] = w;
 }
@@ -639,7 +673,7 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int B, int W, int 
                     double w = 0.0;
                     if (j > 0) {
                         const double t0 = (double)(j - 1) * p_lstep[pp], t1 = (j == kLutN - 1) ? p_tmax[pp] : (double)j * p_lstep[pp];
-                        w = (t1 - t0) / (sDp[j] - sDp[j - 1]);
+                        w = div_inrange(t1 - t0, sDp[j] - sDp[j - 1]);
                     }
                     sWt_all[pp * kLutN + j] = w;
                 }

@@ -71,8 +71,62 @@ __global__ __launch_bounds__(64) void k_time_integrate(int B, int S, const doubl
     double current_time = 0, current_pos = 0, current_vel = N > 0 ? at(0) : 0.0;   // MPG:413-418
     int T = 0;
     bool full = false;
+    // The loop is bound by instruction ISSUE (one wavefront per SIMD, a few hundred instructions per time step), so the
+    // common step is written straight-line: no fall-back loops, no early returns, the three IEEE divisions as reciprocal +
+    // residual correction (div_inrange: the same quotients), rows stored in 16-byte pairs.  A step whose grid indices are
+    // not settled by one correction up and one down (never for finite input) leaves this loop before it has changed
+    // anything, and the general loop below — the statement-by-statement form — takes the path on from there.
+    {
+        double rdt = __builtin_amdgcn_rcp(dt);       // 1/dt to the last bit but one: the divisor of MPG:572 is the same every step
+        rdt = fma(fma(-dt, rdt, 1.0), rdt, rdt);
+        rdt = fma(fma(-dt, rdt, 1.0), rdt, rdt);
+        const double n1 = (double)(N - 1);
+        while (total > 0 && N > 1 && current_pos < total) {   // MPG:523
+            if (T >= cap) { full = true; break; }
+            const double ahead = current_pos + dd;
+            // grid_index(current_pos): floor, one step up, one step down (vap_device.h), selects only
+            double e = floor(current_pos * inv_dd);
+            e = !(e >= -1.0) ? -1.0 : e;
+            e = e > n1 ? n1 : e;
+            int i0 = (int)e;
+            i0 += ((i0 + 1 < N) & ((double)(i0 + 1) * dd <= current_pos)) ? 1 : 0;
+            i0 -= ((i0 >= 0) & !((double)i0 * dd <= current_pos)) ? 1 : 0;
+            const double x0 = (double)i0 * dd, x1 = (double)(i0 + 1) * dd;
+            const bool ok0 = ((i0 + 1 >= N) | !(x1 <= current_pos)) & ((i0 < 0) | (x0 <= current_pos));
+            // grid_index_from(ahead, i0 + 1): one grid step ahead lands one sample further
+            int i1 = i0 + 1 > N - 1 ? N - 1 : i0 + 1;
+            i1 += ((i1 + 1 < N) & ((double)(i1 + 1) * dd <= ahead)) ? 1 : 0;
+            i1 -= ((i1 >= 0) & !((double)i1 * dd <= ahead)) ? 1 : 0;
+            const double z0 = (double)i1 * dd, z1 = (double)(i1 + 1) * dd;
+            const bool ok1 = ((i1 + 1 >= N) | !(z1 <= ahead)) & ((i1 < 0) | (z0 <= ahead));
+            if (__builtin_expect(!(ok0 & ok1), 0)) break;      // (to the general loop, state untouched)
+            const double a0 = at(clamp_index(i0, N)), a1 = at(clamp_index(i0 + 1, N));
+            const double c0 = at(clamp_index(i1, N)), c1 = at(clamp_index(i1 + 1, N));
+            // MPG:349-386 lerp, twice (MPG:566-570): y0 + (x - x0) * (y1 - y0) / (x1 - x0), the end values outside the grid
+            const double l0 = a0 + div_inrange((current_pos - x0) * (a1 - a0), x1 - x0);
+            const double l1 = c0 + div_inrange((ahead - z0) * (c1 - c0), z1 - z0);
+            double target_vel = (i0 < 0 || i0 >= N - 1) ? a0 : l0;
+            const double next_target_vel = (i1 < 0 || i1 >= N - 1) ? c0 : l1;
+            target_vel = (target_vel + next_target_vel) / 2;
+            if (!(target_vel > 0.001)) target_vel = 0.001;
+            // (target_vel - current_vel) / dt with the loop-invariant reciprocal: quotient, residual, correction
+            const double dv = target_vel - current_vel;
+            const double q0 = dv * rdt;
+            const double accel = clip(fma(fma(-dt, q0, dv), rdt, q0), -max_dec, max_acc);     // MPG:572-573
+            current_vel = clip(current_vel + accel * dt, 0, target_vel);                        // MPG:578
+            double delta_pos = current_vel * dt + 0.5 * accel * dt * dt;                        // MPG:580
+            if (current_vel <= 0.1) delta_pos = 0.1 * dt + 0.5 * accel * dt * dt;               // MPG:581-582
+            current_pos += delta_pos;
+            double *q = out + (size_t)T * kRowWidth;
+            *reinterpret_cast<double2 *>(q) = make_double2(current_time, current_pos);
+            *reinterpret_cast<double2 *>(q + 2) = make_double2(current_vel, accel);
+            q[5] = target_vel;   // scratch: k_time_geometry turns it into the angular velocity
+            T += 1;
+            current_time += dt;
+        }
+    }
     // `total > 0` also keeps degenerate paths (NaN / zero length) out of the loop
-    while (total > 0 && N > 1 && current_pos < total) {   // MPG:523
+    while (!full && total > 0 && N > 1 && current_pos < total) {   // MPG:523
         if (T >= cap) { full = true; break; }
         // MPG:566-570: mean of the profile at the current position and one grid step ahead.  The four
         // samples are fetched together: one memory round trip per step instead of two.
