@@ -134,6 +134,20 @@ class DevicePath:
                                        _ptr(outs["dtheta"]), None, _ptr(outs["velocity"]), _ptr(d["flags"])),
                    "vap_velocity_pass")
         n = int(d["meta"][0, 3].item())
+        if int(d["flags"][0].item()) & _lib.FLAG_NOCONVERGE:
+            # the long-row kernel bounds every wait by wall time (a grid must drain); on a GPU that is time-sliced or
+            # profiled with serialising counters such a wait can expire and leave rows that are flagged, not right.  This
+            # call is synchronous anyway: take the path once more through the one-lane sequential sweep (the same rows,
+            # bit for bit, when nothing times out).
+            d["flags"].bitwise_and_(~_lib.FLAG_NOCONVERGE)
+            self.ctx.set_option(_lib.OPT_VELOCITY_KERNEL, _lib.VELOCITY_SEQ_FAST)
+            try:
+                _lib.check(L.vap_velocity_pass(self.ctx.handle, _lib.VAP_F64, 1, cap, C.byref(c), float(start_vel),
+                                               float(end_vel), _ptr(d["meta"]), _ptr(outs["curvature"]),
+                                               _ptr(outs["dtheta"]), None, _ptr(outs["velocity"]), _ptr(d["flags"])),
+                           "vap_velocity_pass (sequential sweep after a timed-out wait)")
+            finally:
+                self.ctx.set_option(_lib.OPT_VELOCITY_KERNEL, _lib.VELOCITY_AUTO)
         return {k: outs[k][0, :n].cpu().numpy() for k in want}, n
 
 

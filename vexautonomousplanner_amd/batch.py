@@ -145,6 +145,21 @@ class BatchedTrajectoryGenerator:
             raise ValueError(f"{what} needs the ProfileResult of THIS generator's LAST profile()/profile_routes() call: the "
                              "context rows it reads belong to another batch")
 
+    @staticmethod
+    def check_flags(result):
+        """Synchronises, then raises RuntimeError if any path of ``result`` carries a flag that makes its rows unusable:
+        VAP_FLAG_NOCONVERGE (a bounded wait of the long-row velocity kernel expired — a time-sliced or counter-profiled
+        GPU; re-run the batch, or with velocity_kernel="seq_fast") or VAP_FLAG_BAD_ROUTE.  Degenerate / truncated paths
+        are reported by their flags only, as the reference reports them by value.  profile() itself never synchronises:
+        call this where the rows are consumed."""
+        f = result["flags"]
+        bad = (f & (_lib.FLAG_NOCONVERGE | _lib.FLAG_BAD_ROUTE)) != 0
+        if bool(bad.any().item()):
+            idx = torch.nonzero(bad).flatten()[:8].tolist()
+            raise RuntimeError(f"{int(bad.sum().item())} paths are flagged no-converge / bad-route (first: {idx}); flags "
+                               f"{[int(f[i].item()) for i in idx]}")
+        return result
+
     def profile_routes(self, waypoints, node_reverse=None, node_turn=None, node_tangent=None, node_magnitudes=None,
                        constraints=DEFAULT_CONSTRAINTS, samples=None, dd=None, start_vel=START_VEL, end_vel=END_VEL,
                        want=FIELDS, out=None, capacity=None):

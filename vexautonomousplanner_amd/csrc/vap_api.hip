@@ -89,7 +89,8 @@ int run_velocity(vap_ctx *ctx, bool f64, bool io64, int B, int S, const double c
     const int relax_limit = acc.fwd ? vap::velocity_relax_acc_max_samples(f64) : vap::velocity_relax_max_samples(f64, vcap != nullptr);
     // fp64 recurrence, many paths: a wavefront of paths (K5w) — its time does not grow with the batch up to 256
     // workgroups, the relaxation kernel's does (one path per CU at a time for rows of ~10^4 samples)
-    if (mode == VAP_VELOCITY_AUTO && f64 && B >= kLanesMinPaths) mode = VAP_VELOCITY_LANES;
+    const bool lanes_by_auto = mode == VAP_VELOCITY_AUTO && f64 && B >= kLanesMinPaths;
+    if (lanes_by_auto) mode = VAP_VELOCITY_LANES;
     if (mode >= VAP_VELOCITY_LANES && mode <= VAP_VELOCITY_LANES_64) {
         if (!f64) return vap_fail(VAP_ERR_UNSUPPORTED, "the lane-per-path velocity kernel runs the fp64 recurrence only");
         void *ufwd = nullptr;
@@ -103,9 +104,16 @@ int run_velocity(vap_ctx *ctx, bool f64, bool io64, int B, int S, const double c
             }
         }
         const int group = mode == VAP_VELOCITY_LANES ? 0 : (mode == VAP_VELOCITY_LANES_16 ? 16 : (mode == VAP_VELOCITY_LANES_32 ? 32 : 64));
-        HIP_TRY(vap::launch_velocity_lanes(ctx->stream, io64, B, S, cc, sv, ev, meta, curv, dth, vcap, acc, vel, ufwd, group, vres));
-        if (want_hi) keep_res();
-        return VAP_OK;
+        const hipError_t le = vap::launch_velocity_lanes(ctx->stream, io64, B, S, cc, sv, ev, meta, curv, dth, vcap, acc, vel, ufwd, group, vres);
+        if (le == hipSuccess) {
+            if (want_hi) keep_res();
+            return VAP_OK;
+        }
+        // AUTO chose the kernel (it needs ~100 KB of dynamic LDS and rows addressable by 32-bit offsets): if it cannot be
+        // launched here, the kernels that served such batches before it take the call; a kernel the caller asked for fails
+        if (!lanes_by_auto) return vap_fail(VAP_ERR_HIP, "the lane-per-path velocity kernel could not be launched: %s", hipGetErrorString(le));
+        (void)hipGetLastError();
+        mode = VAP_VELOCITY_AUTO;
     }
     if (mode == VAP_VELOCITY_AUTO)
         mode = (vcap && S > relax_limit) ? VAP_VELOCITY_SEQ_FAST : VAP_VELOCITY_RELAX;
