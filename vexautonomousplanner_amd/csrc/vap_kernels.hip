@@ -363,7 +363,7 @@ constexpr int kLutManyMinPaths = 32768;   // P = 64: batches from here on (and W
 constexpr int kLutGroupMinPaths = 8192;   // P = 8: batches from here on (and W <= 64); measured at 4096 x 32: 59 us against
                                           // k_lut's 57 (two workgroups per CU are too few to hide the barriers), at 8192: 75 against 93
 template <int kLutManyPaths, int kLutManyThreads>
-__global__ __launch_bounds__(kLutManyThreads) void k_lut_many(int B, int W, const double *__restrict__ segments,
+__global__ __launch_bounds__(kLutManyThreads, kLutManyThreads == 512 ? 4 : 1) void k_lut_many(int B, int W, const double *__restrict__ segments,
                                                                double *__restrict__ lut, double *__restrict__ slopes,
                                                                double *__restrict__ meta, uint32_t *__restrict__ flags,
                                                                GridArgs grid)
@@ -2412,7 +2412,8 @@ hipError_t launch_lut(hipStream_t st, int B, int W, const double *seg, double *l
     // (the 64 paths' segment rows are staged in LDS: 6 KB per segment column, so short paths only)
     if (!want_stats && !rt.sptab && W <= 9 && B >= kLutManyMinPaths) {
         // very many paths: 64 per workgroup, the sequential sums of 64 paths in the lanes of one wavefront
-        hipLaunchKernelGGL((k_lut_many<64, 256>), dim3((B + 63) / 64), dim3(256), sizeof(double) * 64 * (W - 1) * 12, st, B, W, seg, lut,
+        // (512 threads: two of these workgroups share a CU — LDS: 80 KB each — and eight waves each give its SIMDs four)
+        hipLaunchKernelGGL((k_lut_many<64, 512>), dim3((B + 63) / 64), dim3(512), sizeof(double) * 64 * (W - 1) * 12, st, B, W, seg, lut,
                            slopes, meta, flags, grid);
         return hipGetLastError();
     }
