@@ -133,7 +133,14 @@ struct Lanes {
     IO *V;
     double *UF;
     bool stats_on = false;  // VAP_LANES_STATS: time the producers' wait for their rows
-    mutable long long t_take = 0, t_loads = 0;   // (VAP_LANES_STATS, producer 0: waiting for its rows, issuing the next loads)
+    mutable long long t_take = 0, tm_flush = 0, t_loads = 0, tm_put = 0;   // (VAP_LANES_STATS: a producer's step by phase)
+    // a time stamp the compiler keeps in place: volatile, ordered against memory operations, the counter read back at once
+    __device__ __forceinline__ long long stamp() const
+    {
+        long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        return t;
+    }
     float *RES;             // fp32 rows: what the stored velocity lost, v64 - (double)(float)v64 (for the time domain)
     double end_u;
     unsigned char *rec;     // LDS: two record tiles
@@ -289,7 +296,7 @@ struct Lanes {
                                                     int parity, SlotIn (&cur)[kBatchesPerProducer], SlotIn (&nxt)[kBatchesPerProducer],
                                                     bool (&saw_dup)[kBatchesPerProducer]) const
     {
-        const long long tk0 = stats_on ? __builtin_amdgcn_s_memtime() : 0;
+        const long long tk0 = stats_on ? stamp() : 0;
 #pragma unroll
         for (int i = 0; i < NB; i++) {
             cur[i].k0 = opaque(cur[i].k0);
@@ -299,8 +306,7 @@ struct Lanes {
             if constexpr (ACC) cur[i].acc = opaque(cur[i].acc);
             if constexpr (VCAP && !BWD) cur[i].vc = opaque(cur[i].vc);
         }
-        const long long tk1 = stats_on ? __builtin_amdgcn_s_memtime() : 0;
-        if (stats_on) t_take += tk1 - tk0;
+        const long long tk1 = stats_on ? stamp() : 0;
         __builtin_amdgcn_sched_barrier(0);
         // The results of tile `t_flush` go out FIRST, ahead of the next loads: the take of the next step waits for
         // everything this wave has in flight (vmcnt(0): the compiler cannot count through the loop), and stores issued at
@@ -316,6 +322,7 @@ struct Lanes {
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        const long long tk1b = stats_on ? stamp() : 0;
         // (unconditional: a tile index outside the row loads clamped, unused values)
 #pragma unroll
         for (int i = 0; i < NB; i++) {
@@ -323,7 +330,7 @@ struct Lanes {
             else load_fwd<INT>(ctx[i], t_load, nxt[i]);
         }
         __builtin_amdgcn_sched_barrier(0);
-        const long long tk2 = stats_on ? __builtin_amdgcn_s_memtime() : 0;
+        const long long tk2 = stats_on ? stamp() : 0;
         if (INT || (t_put >= 0 && t_put < NT)) {
             unsigned char *rt = rec + (size_t)parity * G::rec_bytes;
 #pragma unroll
@@ -332,7 +339,13 @@ struct Lanes {
                 else put_fwd<INT>(ctx[i], t_put, cur[i], rt, saw_dup[i]);
             }
         }
-        if (stats_on) t_loads += tk2 - tk1;
+        if (stats_on) {
+            const long long tk3 = stamp();
+            t_take += tk1 - tk0;
+            tm_flush += tk1b - tk1;
+            t_loads += tk2 - tk1b;
+            tm_put += tk3 - tk2;
+        }
     }
     // pipeline step `it` of a sweep over NT tiles (tile #n of the backward sweep is row tile NT-1-n); nmin = the fewest
     // samples of any path slot of the group (-1 when the group is not full)
@@ -565,6 +578,8 @@ __global__ __launch_bounds__(kLanesThreads, 3) void k_velocity_lanes(int B, int 
     if (stats && tid == 64) stats[(size_t)blockIdx.x * kLanesStats + 31] = L.t_take;   // producer 0: of that, waiting for its rows
     if (stats && tid == 64) {                                                           // ... issuing loads, records, moving results out
         stats[(size_t)blockIdx.x * kLanesStats + 28] = L.t_loads;
+        stats[(size_t)blockIdx.x * kLanesStats + 29] = L.tm_put;
+        stats[(size_t)blockIdx.x * kLanesStats + 30] = L.tm_flush;
     }
     if (stats && lane == 0) stats[(size_t)blockIdx.x * kLanesStats + 8 + pw] = t_busy;   // every producer, both sweeps
     // rows longer than the longest path of the group: zeros past the last tile
@@ -647,7 +662,7 @@ hipError_t launch_lanes_p(hipStream_t st, int B, int S, const double c[6], doubl
                 sum[20] / (sum[21] * 10.0));
         fprintf(stderr, "        producers busy, both sweeps:");
         for (int k = 0; k < kLanesProducers; k++) fprintf(stderr, " %.0f", sum[8 + k]);
-        fprintf(stderr, " | producer 0: waiting for its rows %.0f, issuing loads %.0f\n", sum[31], sum[28]);
+        fprintf(stderr, " | producer 0 by phase: waiting for its rows %.0f, results out %.0f, issuing loads %.0f, records %.0f\n", sum[31], sum[30], sum[28], sum[29]);
     }
     return hipGetLastError();
 }
