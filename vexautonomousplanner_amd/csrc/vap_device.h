@@ -403,6 +403,32 @@ __device__ __forceinline__ double dtheta_f64(double ax, double ay, double bx, do
     return fabs(fma(n, 6.283185307179586, dl));
 }
 
+// dtheta_f64 in two halves, for callers that evaluate several samples side by side without a branch per sample: the
+// series part for every sample (`general` says whether the sample is outside its range and needs dtheta_f64_general),
+// then the 2*pi multiple.  The same operations in the same order as dtheta_f64.
+__device__ __forceinline__ double dtheta_f64_series(double ax, double ay, double bx, double by, bool &general)
+{
+    const double cr = fma(ax, by, -(ay * bx));
+    const double dt = fma(ax, bx, ay * by);
+    double r = __builtin_amdgcn_rcp(dt);
+    r = fma(r, fma(-dt, r, 1.0), r);
+    r = fma(r, fma(-dt, r, 1.0), r);
+    const double z = cr * r;
+    general = !(dt > 0.0 && fabs(z) < 0.06);
+    const double z2 = z * z;
+    const double p = fma(fma(fma(fma(fma(-1.0 / 11.0, z2, 1.0 / 9.0), z2, -1.0 / 7.0), z2, 1.0 / 5.0), z2, -1.0 / 3.0), z2, 1.0);
+    return z * p;
+}
+__device__ __forceinline__ double dtheta_f64_general(double ax, double ay, double bx, double by)
+{
+    return atan2_out_of_line(fma(ax, by, -(ay * bx)), fma(ax, bx, ay * by));
+}
+__device__ __forceinline__ double dtheta_f64_wrap(double dl, float tha, float thb)
+{
+    const double n = rint(((double)(thb - tha) - dl) * 0.15915494309189535);
+    return fabs(fma(n, 6.283185307179586, dl));
+}
+
 // Python's min(a, b): keeps a unless b < a (a NaN in b is skipped).
 template <typename R>
 __device__ __forceinline__ R pymin(R a, R b) { return b < a ? b : a; }

@@ -771,31 +771,48 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int B, int W, int 
         double d1x[kSPT], d1y[kSPT];
         int jjv[kSPT];
         int idx = 0;
+        // Phase A, the four samples' parameters and table entries side by side; the redo of a sample that sits a few ulps
+        // from a decision point (rare) is ONE block after them instead of a divergent branch inside every sample
+        double tA[kSPT], sA[kSPT];
+        int idxA[kSPT];
+        bool redo[kSPT], any_redo = false;
 #pragma unroll
         for (int i = 0; i < kSPT; i++) {
-            // samples past the end of the grid (last tile only) are evaluated at the end sample and
-            // blanked on store: the body stays straight-line
             const int k = INTERIOR ? kbase + i : (kbase + i < N - 1 ? kbase + i : N - 1);
             if (i > 0) sk = sk + dd;
             const double s = INTERIOR ? sk : ((k == N - 1) ? total : sk);
-            // SM:291-318 distance_to_time.  s = 0 lands on entry 1 with t = 0 exactly; s = total is the
-            // reference's early return of len(nodes)-1.
             if (i == 0) idx = lut_search_left(sD, s);
             else while (idx < kLutN - 1 && sD[idx] < s) idx++;
             if constexpr (!INTERIOR) idx = idx < 1 ? 1 : idx;
             const double d0 = sD[idx - 1];
             const double t0 = (double)(idx - 1) * lstep;
-            const bool exact = INTERIOR ? false : (s <= 0.0 || s >= total);      // the reference's early returns: t is exact
+            const bool exact = INTERIOR ? false : (s <= 0.0 || s >= total);
             double t = fma(sWt[idx], s - d0, t0);
             if constexpr (!INTERIOR) t = s >= total ? end_param : t;
-            // SM:340-346 / 550-580: the table entry the reference's step lookup selects
             bool near;
-            int jj = table_index_fast(t, tab_n, inv_tstep, near);
-            if (near && !exact) {   // a few ulps from a decision point: redo with the reference's own rounding
-                const double t1 = (idx == kLutN - 1) ? t_max : (double)idx * lstep;
-                t = t0 + (t1 - t0) * (s - d0) / (sD[idx] - d0);
-                jj = table_index(t, tab_n, end_param);
+            jjv[i] = table_index_fast(t, tab_n, inv_tstep, near);
+            tA[i] = t;
+            sA[i] = s;
+            idxA[i] = idx;
+            redo[i] = near && !exact;
+            any_redo |= redo[i];
+        }
+        if (__builtin_expect(any_redo, 0)) {
+#pragma unroll
+            for (int i = 0; i < kSPT; i++) {
+                if (redo[i]) {   // the reference's own rounding (SM:311-317)
+                    const int ix = idxA[i];
+                    const double d0 = sD[ix - 1], t0 = (double)(ix - 1) * lstep;
+                    const double t1 = (ix == kLutN - 1) ? t_max : (double)ix * lstep;
+                    tA[i] = t0 + (t1 - t0) * (sA[i] - d0) / (sD[ix] - d0);
+                    jjv[i] = table_index(tA[i], tab_n, end_param);
+                }
             }
+        }
+#pragma unroll
+        for (int i = 0; i < kSPT; i++) {
+            const double t = tA[i];
+            const int jj = jjv[i];
             const double tp = (jj == tab_n - 1) ? end_param : (double)jj * tstep;
             double lt;
             int sg;
@@ -849,6 +866,38 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int B, int W, int 
         __syncthreads();
         if (writer) {
             // |heading[k+1] - heading[k]| of the reference's raw (un-unwrapped) atan2 values
+            if constexpr (HI && sizeof(OT) == 4) {
+                // the four samples side by side, no branch per sample: the series for all of them, ONE rarely taken block
+                // for samples outside its range, then the 2*pi multiples (the same operations as dtheta_f64)
+                double dl[kSPT];
+                bool act[kSPT], gen[kSPT];
+                double nxv[kSPT], nyv[kSPT];
+                OT nthv[kSPT];
+                bool any_gen = false;
+#pragma unroll
+                for (int i = 0; i < kSPT; i++) {
+                    const int k = kbase + i;
+                    nxv[i] = (i + 1 < kSPT) ? d1x[(i + 1) % kSPT] : s_dx[pb][tid + 1];
+                    nyv[i] = (i + 1 < kSPT) ? d1y[(i + 1) % kSPT] : s_dy[pb][tid + 1];
+                    const int nj = (i + 1 < kSPT) ? jjv[(i + 1) % kSPT] : s_j[pb][tid + 1];
+                    nthv[i] = (i + 1 < kSPT) ? vh[(i + 1) % kSPT] : s_th[pb][tid + 1];
+                    act[i] = (INTERIOR || k < N - 1) && nj != jjv[i];
+                    dl[i] = dtheta_f64_series(d1x[i], d1y[i], nxv[i], nyv[i], gen[i]);
+                    gen[i] = gen[i] && act[i];
+                    any_gen |= gen[i];
+                }
+                if (__builtin_expect(any_gen, 0)) {
+#pragma unroll
+                    for (int i = 0; i < kSPT; i++)
+                        if (gen[i]) dl[i] = dtheta_f64_general(d1x[i], d1y[i], nxv[i], nyv[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < kSPT; i++) {
+                    const double v = dtheta_f64_wrap(dl[i], vh[i], nthv[i]);
+                    vd64[i] = act[i] ? v : vd64[i];
+                    vd[i] = (INTERIOR || kbase + i < N - 1) ? (OT)vd64[i] : vd[i];
+                }
+            } else {
 #pragma unroll
             for (int i = 0; i < kSPT; i++) {
                 const int k = kbase + i;
@@ -866,6 +915,7 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int B, int W, int 
                         if (nj != jjv[i]) vd[i] = dtheta_f32(d1x[i], d1y[i], nx, ny, vh[i], nth);
                     }
                 }
+            }
             }
             if (!INTERIOR && k0 + kSampleChunk > N) {   // only the path's last tile has samples to blank
 #pragma unroll
