@@ -164,7 +164,7 @@ __device__ __forceinline__ void {name}(uint32_t addr, uint32_t oaddr, double &u,
 # their own results — stay as they are), the hand-over under full EXEC.
 #   records: group m (16 steps), plane k (the lane's first / second pair), lane L: m*GROUP + k*PLANE + L*80, the 80-byte
 #   pair record as above; results: lane L's four doubles at oaddr + 8*(16m + 4r) (oaddr = the path's row + 32*r).
-ROT0 = 40                                   # first fixed register
+ROT0 = 24                                   # first fixed register
 ROT_BANK = [ROT0, ROT0 + 40]                # two banks of two pair records (20 registers each)
 ROT_R = ROT0 + 80                           # R0..R3: the lane's four results (8 registers)
 ROT_U, ROT_UP = ROT0 + 88, ROT0 + 90

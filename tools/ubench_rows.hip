@@ -28,7 +28,15 @@
     } while (0)
 
 constexpr int kThreads = 768, kProducers = 11, kTileRecords = 1024, kBPP = 2;
+// HALF: tiles of 512 slots, six waves (wave 0 + five producers), half the LDS: TWO workgroups share a CU and drift apart in
+// phase, so that one's memory phase can fall into the other's work phase
+constexpr int kThreadsHalf = 384, kTileHalf = 512;
 
+__device__ __forceinline__ int batch_of_half(int wv, int i)
+{
+    constexpr int tab[6][2] = {{-1, -1}, {0, 1}, {2, 3}, {4, 5}, {6, -1}, {7, -1}};
+    return tab[wv][i];
+}
 __device__ __forceinline__ int batch_of(int wv, int i)
 {
     constexpr int tab[12][2] = {{-1, -1}, {0, 1}, {2, 3}, {4, 5}, {6, -1}, {7, 8}, {9, 10}, {11, -1}, {12, -1}, {13, -1}, {14, -1}, {15, -1}};
@@ -38,21 +46,21 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 template <typename T>
 __device__ __forceinline__ T opaque(T x) { asm volatile("" : "+v"(x)); return x; }
 
-template <int P>
+template <int P, int TILE = kTileRecords>
 constexpr size_t lanes_lds_bytes()   // LanesGeo<P>::lds_bytes of vap_velocity_lanes.hip
 {
-    constexpr int TS = kTileRecords / P, stride = P * 80 + 64;
+    constexpr int TS = TILE / P, stride = P * 80 + 64;
     return 2 * (size_t)((TS / 2) * stride) + 2 * (size_t)(P * (TS + 2) * 8);
 }
 
 struct Slot { size_t row; int s, p; bool live; };
 
-template <int P, int LAYOUT, bool BARRIER, bool STORES_FIRST = false>
-__global__ __launch_bounds__(kThreads, 3) void k_rows(int B, int S, const double *__restrict__ K, const double *__restrict__ DT,
+template <int P, int LAYOUT, bool BARRIER, bool STORES_FIRST = false, bool HALF = false>
+__global__ __launch_bounds__(HALF ? kThreadsHalf : kThreads, 3) void k_rows(int B, int S, const double *__restrict__ K, const double *__restrict__ DT,
                                                       const double2 *__restrict__ REC, double *__restrict__ UF,
                                                       float *__restrict__ V, float *__restrict__ RES, int work)
 {
-    constexpr int TS = kTileRecords / P;
+    constexpr int TS = (HALF ? kTileHalf : kTileRecords) / P;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *ot = reinterpret_cast<double *>(smem);
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
@@ -69,7 +77,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_rows(int B, int S, const double
     Slot c[kBPP];
 #pragma unroll
     for (int i = 0; i < kBPP; i++) {
-        const int q = batch_of(wvu, i);
+        const int q = HALF ? batch_of_half(wvu, i) : batch_of(wvu, i);
         const int f = (q >= 0 ? q : 0) * 64 + lane;
         c[i].p = f / TS;
         c[i].s = f % TS;
@@ -77,7 +85,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_rows(int B, int S, const double
         c[i].row = (size_t)(b < B ? b : B - 1) * S;
         c[i].live = q >= 0 && b < B;
     }
-    const bool two = batch_of(wvu, 1) >= 0;
+    const bool two = (HALF ? batch_of_half(wvu, 1) : batch_of(wvu, 1)) >= 0;
     auto at = [&](const Slot &x, int j) { return x.row + (size_t)(j < 0 ? 0 : (j < S ? j : S - 1)); };
     // LAYOUT 2: record of (group g, tile t, path p, sample s) at ((g * NT + t) * P + p) * TS + s
     auto blk = [&](const Slot &x, int j) {
@@ -184,13 +192,13 @@ __global__ void k_copy4(size_t n4, const float4 *__restrict__ src, float4 *__res
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
-template <int P, int LAYOUT, bool BARRIER, bool STORES_FIRST = false>
+template <int P, int LAYOUT, bool BARRIER, bool STORES_FIRST = false, bool HALF = false>
 double run(int B, int S, const double *K, const double *DT, const double2 *REC, double *UF, float *V, float *RES, int reps, int work = 0)
 {
-    auto kern = k_rows<P, LAYOUT, BARRIER, STORES_FIRST>;
-    const size_t lds = lanes_lds_bytes<P>();
+    auto kern = k_rows<P, LAYOUT, BARRIER, STORES_FIRST, HALF>;
+    const size_t lds = lanes_lds_bytes<P, HALF ? kTileHalf : kTileRecords>();
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const dim3 grid((B + P - 1) / P), block(kThreads);
+    const dim3 grid((B + P - 1) / P), block(HALF ? kThreadsHalf : kThreads);
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
@@ -278,6 +286,14 @@ int main()
         printf("          stores FIRST c3 %.3f ms %.2f TB/s | c4 %.3f ms %.2f TB/s | c5 %.3f ms %.2f TB/s\n", u3,
                56.0 * 4096 * 10000 / (u3 * 1e-3) / 1e12, u4, 56.0 * 8192 * 10000 / (u4 * 1e-3) / 1e12, u5,
                56.0 * 131072 * 1024 / (u5 * 1e-3) / 1e12);
+    }
+    // two half-size workgroups per CU (8 paths, 512-slot tiles, six waves each) against one (16 paths, 1024 slots, twelve waves)
+    printf("\nconfig 3's rows, results stored first: one 16-path workgroup per CU against two 8-path workgroups per CU:\n");
+    for (int work : {0, 25, 50, 75}) {
+        const double t1 = run<16, 0, true, true, false>(4096, 10000, K, DT, REC, UF, V, RES, 10, work);
+        const double t2 = run<8, 0, true, true, true>(4096, 10000, K, DT, REC, UF, V, RES, 10, work);
+        printf("work %3d: 16 paths x 256 workgroups %.3f ms %.2f TB/s | 8 paths x 512 workgroups %.3f ms %.2f TB/s\n", work, t1,
+               56.0 * 4096 * 10000 / (t1 * 1e-3) / 1e12, t2, 56.0 * 4096 * 10000 / (t2 * 1e-3) / 1e12);
     }
     return 0;
 }

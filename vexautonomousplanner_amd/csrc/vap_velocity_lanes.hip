@@ -35,6 +35,12 @@ namespace vap {
 namespace {
 
 constexpr int kLanesThreads = 768;                        // twelve waves: three per SIMD (the chain loop's banks of four steps leave room)
+// 16 paths per workgroup: SIXTEEN waves, four per SIMD.  The rotating chain's register banks end at v119 (32- / 64-path groups
+// keep the lane-per-path loops, v64-v155, and twelve waves), the producers fit 121 registers, and with one batch per producer
+// (wave 1 takes the sixteenth) no SIMD carries more than four of a tile's batches besides the chain: config 3 velocity
+// 0.450 -> 0.443 ms in a same-box A/B.  (The instantiation with max_acceleration rows spills 26 registers at this size.)
+constexpr int kLanesThreads16 = 1024;
+template <int P> constexpr int lanes_threads() { return P == 16 ? kLanesThreads16 : kLanesThreads; }
 constexpr int kLanesStats = 32;                           // long longs per workgroup of VAP_LANES_STATS
 constexpr int kLanesProducers = kLanesThreads / 64 - 1;   // wave 0 is the chain wave
 constexpr int kPrefetchDepth = 1;                         // tiles between a row load and its use
@@ -50,6 +56,10 @@ constexpr int kTileBatches = kTileRecords / 64;
 constexpr int kBatchesPerProducer = (kTileBatches + kLanesProducers - 1) / kLanesProducers;
 // Which batches a wave takes: waves go to the CU's four SIMDs in turn (wave w -> SIMD w % 4), the chain wave is wave 0, and
 // a SIMD works through its producers' batches oldest wave first — so the chain's SIMD gets the fewest: 2 + 5 + 5 + 4.
+__device__ __forceinline__ int batch_of16(int wv, int i)   // sixteen waves: one batch per producer, wave 1 takes the sixteenth
+{
+    return i == 0 ? wv - 1 : (wv == 1 ? 15 : -1);
+}
 __device__ __forceinline__ int batch_of(int wv, int i)   // tile batch i-th of wave wv, or -1
 {
     static_assert(kLanesProducers == 11 && kTileBatches == 16 && kBatchesPerProducer == 2, "the table below");
@@ -376,7 +386,7 @@ struct Lanes {
 //            tile #(it-2)'s results out of result buffer it&1.
 // (tile #n of the backward sweep is tile NT-1-n of the row.)
 template <typename IO, int P, bool VCAP, bool ACC>
-__global__ __launch_bounds__(kLanesThreads, 3) void k_velocity_lanes(int B, int S, VelConsts<double> c, double start_u, double end_u,
+__global__ __launch_bounds__(lanes_threads<P>(), lanes_threads<P>() == 1024 ? 4 : 3) void k_velocity_lanes(int B, int S, VelConsts<double> c, double start_u, double end_u,
                                                                      const double *__restrict__ meta,
                                                                      const double *__restrict__ curv,
                                                                      const double *__restrict__ dtheta,
@@ -518,7 +528,7 @@ __global__ __launch_bounds__(kLanesThreads, 3) void k_velocity_lanes(int B, int 
     SlotCtx ctx[kBatchesPerProducer];
 #pragma unroll
     for (int i = 0; i < kBatchesPerProducer; i++) {
-        const int q = batch_of(wvu, i);                    // this wave's i-th batch of a tile
+        const int q = lanes_threads<P>() == 1024 ? batch_of16(wvu, i) : batch_of(wvu, i);   // this wave's i-th batch of a tile
         const int f = (q >= 0 ? q : 0) * 64 + lane;
         SlotCtx &x = ctx[i];
         x.p = f / TS;
@@ -540,7 +550,7 @@ __global__ __launch_bounds__(kLanesThreads, 3) void k_velocity_lanes(int B, int 
         x.cap_off = G::cap_off(x.p, x.s);
         x.out_off = x.p * G::out_row + x.s;
     }
-    const bool four = batch_of(wvu, kBatchesPerProducer - 1) >= 0;   // (this wave has the full count of batches)
+    const bool four = (lanes_threads<P>() == 1024 ? batch_of16(wvu, kBatchesPerProducer - 1) : batch_of(wvu, kBatchesPerProducer - 1)) >= 0;   // (this wave has the full count of batches)
     bool saw_dup[kBatchesPerProducer] = {};
     long long t_busy = 0;
     auto sweep = [&](auto bwd_tag) {
@@ -586,7 +596,7 @@ __global__ __launch_bounds__(kLanesThreads, 3) void k_velocity_lanes(int B, int 
     for (int p = 0; p < P; p++) {
         const int b = blockIdx.x * P + p;
         if (b >= B) break;
-        for (int j = NT * TS + (tid - 64); j < S; j += kLanesThreads - 64) vel[(size_t)b * S + j] = (IO)0;
+        for (int j = NT * TS + (tid - 64); j < S; j += lanes_threads<P>() - 64) vel[(size_t)b * S + j] = (IO)0;
     }
 }
 
@@ -604,7 +614,7 @@ hipError_t launch_lanes_p(hipStream_t st, int B, int S, const double c[6], doubl
     acc.fwd = (const double *)accv.fwd; acc.bwd = (const double *)accv.bwd; acc.dec = (const double *)accv.dec;
     // rows are addressed by 32-bit byte offsets from the group's first row
     if ((size_t)P * (size_t)S * 8 >= ((size_t)1 << 32)) return hipErrorInvalidValue;
-    const dim3 grid((B + P - 1) / P), block(kLanesThreads);
+    const dim3 grid((B + P - 1) / P), block(lanes_threads<P>());
     const size_t lds = G::lds_bytes;
     constexpr int kMaxDevices = 64;
     int dev = 0;
