@@ -30,8 +30,9 @@ NB = 4                      # steps per batch (register bank = NB records): bank
 for _i, _a in enumerate(sys.argv):
     if _a == "--nb":
         NB = int(sys.argv[_i + 1])
-BANK = [64, 64 + 10 * NB]   # first VGPR of bank A / B: NB*8 registers of {rho,g,am,A}, then NB*2 of cap
-RES = 64 + 20 * NB          # NB result pairs
+FIRST = 36                  # first fixed register (banks of four: v36-v123, v127 with the sign-aware pairs: the kernel's waves fit 128)
+BANK = [FIRST, FIRST + 10 * NB]   # first VGPR of bank A / B: NB*8 registers of {rho,g,am,A}, then NB*2 of cap
+RES = FIRST + 20 * NB       # NB result pairs
 LAST = RES + 2 * NB - 1
 DUP_GN, DUP_C2 = LAST + 1, LAST + 3   # the sign-aware backward tiles: two more fixed register pairs
 TILES = (16, 32, 64)

@@ -2,24 +2,24 @@
 //
 // The recurrence is sequential along a path and has no closed-form scan, but paths are independent:
 // here a LANE is a path.  One workgroup takes P paths (16 / 32 / 64, so that a batch still spreads over the chip):
-//   * wave 0, the CHAIN wave, walks all P recurrences in lock step, one sample per step — forward over every tile of
-//     the rows, then backward — with the hand-scheduled loops of vap_chain_asm.h (four dependent fp64 instructions
-//     per step; the step's five coefficients come out of LDS in blocks of eight steps, because an LDS instruction
-//     between two dependent VALU instructions costs the wave ~15 cycles and ~4-7 back to back — tools/ubench_chain_lds.hip);
-//   * waves 1..7, the PRODUCERS, stream the curvature / heading-difference rows from HBM (coalesced along a row, one
-//     tile ahead of the chain, loads in flight across the tile barrier), derive the step coefficients of vap_device.h
-//     for tiles of 1024 (path, sample) slots and write them into a double-buffered LDS tile as 80-byte records per
-//     (path, pair of samples) in [pair][path] order (the chain's 16-byte reads are conflict-free, the producers' stores
-//     too: the pair stride is P*80+64 bytes); they also move the chain's results (one double per slot, LDS) to HBM: the
-//     forward sweep's squared velocities to a scratch row, which the backward sweep's producers fold into its caps
-//     (commit mode of k_velocity_relax), the backward sweep's as velocities in the caller's type — plus, behind fp32
-//     rows, what that rounding dropped, as an fp32 residual row for the time domain.
+//   * wave 0, the CHAIN wave, walks all P recurrences tile by tile — forward over every tile of the rows, then backward —
+//     with the hand-scheduled loops of vap_chain_asm.h (four dependent fp64 instructions per step out of 40-byte LDS
+//     records).  16 paths per workgroup: a path owns a QUAD of chain lanes and the state travels round the quad by DPP,
+//     each lane reading the records of its own four steps — 0.75 LDS instructions and 36 cycles per step; 32 / 64 paths:
+//     lane = path, records read in blocks of four steps — 57-61 cycles per step (an LDS instruction between two dependent
+//     VALU instructions costs the wave ~15 cycles, ~4-7 back to back: tools/ubench_chain_lds.hip, ubench_chain_rot.hip);
+//   * waves 1..15, the PRODUCERS, stream the curvature / heading-difference rows from HBM (coalesced along a row, one
+//     tile ahead of the chain, scalar base + 32-bit lane offset, loads in flight across the tile barrier), derive the step
+//     coefficients of vap_device.h for tiles of 1024 (path, sample) slots — one batch of 64 slots per producer — and write
+//     them into a double-buffered LDS record tile; they also move the chain's results (one double per slot, LDS) to HBM,
+//     FIRST thing in a step: the forward sweep's squared velocities to a scratch row, which the backward sweep's producers
+//     fold into its caps (commit mode of k_velocity_relax), the backward sweep's as velocities in the caller's type —
+//     plus, on request (VAP_OPT_TIME_DOMAIN_RESIDUAL), what that rounding dropped as an fp32 residual row.
 // No speculation and no convergence test: every sample is evaluated exactly once per direction, in order, so the
 // result IS the sequential sweep's — the coefficient expressions are k_velocity_relax's, the step is step4 — bit for
-// bit (tests/test_gpu_lanes.py holds every instantiation to k_velocity_seq<FAST>).
-// Cost: the chain's ~56 cycles per sample and direction whatever the batch size up to 256 workgroups, against
-// k_velocity_relax's one path per CU at a time; HBM: 8+8 B/pt read per direction, 8 B/pt scratch write + read, the
-// velocity row and its 4 B/pt residual — 56 B/pt.
+// bit (tests/test_gpu_lanes.py and tools/fuzz_lanes.py hold every instantiation to k_velocity_seq<FAST>).
+// Cost: HBM, 8+8 B/pt read per direction, 8 B/pt scratch write + read, the velocity row (and 4 B/pt
+// of residual) — 52 (56) B/pt at 4.3-4.7 TB/s; the chain is no longer the bound at any batch shape.
 #include "vap_chain_asm.h"
 #include "vap_device.h"
 #include "vap_kernels.h"
@@ -34,38 +34,25 @@ namespace vap {
 
 namespace {
 
-constexpr int kLanesThreads = 768;                        // twelve waves: three per SIMD (the chain loop's banks of four steps leave room)
-// 16 paths per workgroup: SIXTEEN waves, four per SIMD.  The rotating chain's register banks end at v119 (32- / 64-path groups
-// keep the lane-per-path loops, v64-v155, and twelve waves), the producers fit 121 registers, and with one batch per producer
-// (wave 1 takes the sixteenth) no SIMD carries more than four of a tile's batches besides the chain: config 3 velocity
-// 0.450 -> 0.443 ms in a same-box A/B.  (The instantiation with max_acceleration rows spills 26 registers at this size.)
-constexpr int kLanesThreads16 = 1024;
-template <int P> constexpr int lanes_threads() { return P == 16 ? kLanesThreads16 : kLanesThreads; }
+constexpr int kLanesThreads = 1024;                       // sixteen waves: four per SIMD (every wave fits 128 registers)
 constexpr int kLanesStats = 32;                           // long longs per workgroup of VAP_LANES_STATS
 constexpr int kLanesProducers = kLanesThreads / 64 - 1;   // wave 0 is the chain wave
 constexpr int kPrefetchDepth = 1;                         // tiles between a row load and its use
 constexpr int kPairBytes = 80;                            // the records of two consecutive samples of a path (vap_chain_asm.h)
 constexpr int kTileRecords = 1024;                        // (path, sample) slots per tile = 16 producer batches of 64
 constexpr int kTileBatches = kTileRecords / 64;
-// Twelve waves = three per SIMD: the chain loop keeps its records in banks of FOUR steps (vap_chain_asm.h:
-// v64-v151; banks of eight, v64-v239, allowed two waves per SIMD), so every wave of the workgroup fits 168 registers
-// and a producer step — a chain of reciprocal / Newton latencies and LDS round trips — overlaps with two others on its
-// SIMD instead of one.  Measured (same box, alternating builds): both sweeps 1.31 M -> 1.22 M cycles at config 3, now within
-// 5 % of the chain loops themselves; step 1.005 -> 0.986 ms, config 4 share 1.967 -> 1.924, config 5 share 4.73 -> 4.66.
-// (A SIMD works through its producers' batches at ~650 cycles each, oldest wave first: batch_of below.)
+// Sixteen waves = four per SIMD.  History: eight waves (chain banks of eight steps, 240 registers) -> twelve (banks of four:
+// 156 registers; both sweeps 1.31 M -> 1.22 M cycles at config 3, round 3) -> sixteen (round 4): the chain loops' fixed banks
+// sit in v24-v119 (rotating chain, 16 paths) / v36-v127 (lane-per-path loops, 32 and 64 paths), the producers fit 121-128
+// registers without spills (the instantiation with max_acceleration rows spills 26-29), and a tile's sixteen batches are one
+// per producer with the sixteenth on wave 1 — no SIMD carries more than four besides the chain (twelve waves: 2 + 5 + 5 + 4).
+// Same-box A/Bs: config 3 velocity 0.450 -> 0.443 ms, config 4's share 0.93-0.98 -> 0.89-0.93, config 5's 1.62-1.65 -> 1.55.
 constexpr int kBatchesPerProducer = (kTileBatches + kLanesProducers - 1) / kLanesProducers;
-// Which batches a wave takes: waves go to the CU's four SIMDs in turn (wave w -> SIMD w % 4), the chain wave is wave 0, and
-// a SIMD works through its producers' batches oldest wave first — so the chain's SIMD gets the fewest: 2 + 5 + 5 + 4.
-__device__ __forceinline__ int batch_of16(int wv, int i)   // sixteen waves: one batch per producer, wave 1 takes the sixteenth
-{
-    return i == 0 ? wv - 1 : (wv == 1 ? 15 : -1);
-}
+// Which batches a wave takes (waves go to the CU's four SIMDs in turn, wave w -> SIMD w % 4; the chain wave is wave 0)
 __device__ __forceinline__ int batch_of(int wv, int i)   // tile batch i-th of wave wv, or -1
 {
-    static_assert(kLanesProducers == 11 && kTileBatches == 16 && kBatchesPerProducer == 2, "the table below");
-    //                         wave:  0        1       2       3        4        5       6       7        8        9        10       11
-    constexpr int tab[12][2] = {{-1, -1}, {0, 1}, {2, 3}, {4, 5}, {6, -1}, {7, 8}, {9, 10}, {11, -1}, {12, -1}, {13, -1}, {14, -1}, {15, -1}};
-    return tab[wv][i];
+    static_assert(kLanesProducers == 15 && kTileBatches == 16 && kBatchesPerProducer == 2, "one batch per producer, wave 1 takes the sixteenth");
+    return i == 0 ? wv - 1 : (wv == 1 ? 15 : -1);
 }
 
 template <int P>
@@ -386,7 +373,7 @@ struct Lanes {
 //            tile #(it-2)'s results out of result buffer it&1.
 // (tile #n of the backward sweep is tile NT-1-n of the row.)
 template <typename IO, int P, bool VCAP, bool ACC>
-__global__ __launch_bounds__(lanes_threads<P>(), lanes_threads<P>() == 1024 ? 4 : 3) void k_velocity_lanes(int B, int S, VelConsts<double> c, double start_u, double end_u,
+__global__ __launch_bounds__(kLanesThreads, 4) void k_velocity_lanes(int B, int S, VelConsts<double> c, double start_u, double end_u,
                                                                      const double *__restrict__ meta,
                                                                      const double *__restrict__ curv,
                                                                      const double *__restrict__ dtheta,
@@ -528,7 +515,7 @@ __global__ __launch_bounds__(lanes_threads<P>(), lanes_threads<P>() == 1024 ? 4 
     SlotCtx ctx[kBatchesPerProducer];
 #pragma unroll
     for (int i = 0; i < kBatchesPerProducer; i++) {
-        const int q = lanes_threads<P>() == 1024 ? batch_of16(wvu, i) : batch_of(wvu, i);   // this wave's i-th batch of a tile
+        const int q = batch_of(wvu, i);                    // this wave's i-th batch of a tile
         const int f = (q >= 0 ? q : 0) * 64 + lane;
         SlotCtx &x = ctx[i];
         x.p = f / TS;
@@ -550,7 +537,7 @@ __global__ __launch_bounds__(lanes_threads<P>(), lanes_threads<P>() == 1024 ? 4 
         x.cap_off = G::cap_off(x.p, x.s);
         x.out_off = x.p * G::out_row + x.s;
     }
-    const bool four = (lanes_threads<P>() == 1024 ? batch_of16(wvu, kBatchesPerProducer - 1) : batch_of(wvu, kBatchesPerProducer - 1)) >= 0;   // (this wave has the full count of batches)
+    const bool four = batch_of(wvu, kBatchesPerProducer - 1) >= 0;   // (this wave has the full count of batches)
     bool saw_dup[kBatchesPerProducer] = {};
     long long t_busy = 0;
     auto sweep = [&](auto bwd_tag) {
@@ -596,7 +583,7 @@ __global__ __launch_bounds__(lanes_threads<P>(), lanes_threads<P>() == 1024 ? 4 
     for (int p = 0; p < P; p++) {
         const int b = blockIdx.x * P + p;
         if (b >= B) break;
-        for (int j = NT * TS + (tid - 64); j < S; j += lanes_threads<P>() - 64) vel[(size_t)b * S + j] = (IO)0;
+        for (int j = NT * TS + (tid - 64); j < S; j += kLanesThreads - 64) vel[(size_t)b * S + j] = (IO)0;
     }
 }
 
@@ -614,7 +601,7 @@ hipError_t launch_lanes_p(hipStream_t st, int B, int S, const double c[6], doubl
     acc.fwd = (const double *)accv.fwd; acc.bwd = (const double *)accv.bwd; acc.dec = (const double *)accv.dec;
     // rows are addressed by 32-bit byte offsets from the group's first row
     if ((size_t)P * (size_t)S * 8 >= ((size_t)1 << 32)) return hipErrorInvalidValue;
-    const dim3 grid((B + P - 1) / P), block(lanes_threads<P>());
+    const dim3 grid((B + P - 1) / P), block(kLanesThreads);
     const size_t lds = G::lds_bytes;
     constexpr int kMaxDevices = 64;
     int dev = 0;
