@@ -604,7 +604,9 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int B, int W, int 
         double vD[PPB][ITER], vW[PPB][ITER];
 #pragma unroll
         for (int pp = 0; pp < PPB; pp++) {
-            const bool go = p_live[pp] && tile0 * tile < p_N[pp];
+            // (not a function of the path's sample count: the table loads then leave with the meta loads instead of a memory
+            // round trip after them — the row is in bounds either way, p_b is clamped)
+            const bool go = p_live[pp];
 #pragma unroll
             for (int it = 0; it < ITER; it++) {
                 const int i = tid + it * kSampleThreads;
@@ -616,7 +618,7 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int B, int W, int 
         if constexpr (COEF_LDS) {
 #pragma unroll
             for (int pp = 0; pp < PPB; pp++)
-                if (p_live[pp] && tile0 * tile < p_N[pp])
+                if (p_live[pp])     // (as the tables: not behind the meta loads)
                     lds_fill<4>(s_coef + (size_t)pp * G * kCoefDoubles, power + (size_t)p_b[pp] * G * kCoefDoubles, G * kCoefDoubles, tid,
                                 kSampleThreads);
         }
@@ -661,7 +663,11 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int B, int W, int 
         p_sk[pp] = (p_live[pp] && tile0 * tile < p_N[pp])
                        ? grid_first_of(runs + (size_t)p_b[pp] * kGridRunDoubles, p_dd[pp], p_N[pp], p_nruns[pp], tile0 * tile + tid * kSPT)
                        : 0.0;
-    if (!slopes) {
+    // Rows of one tile (PPB == 2 serves only those): a path's 1000 interval slopes would serve ~1000 samples once each, so a
+    // sample forms the slope of ITS interval on the spot — the same expression, the same bits — and the slope array, its
+    // 1000 divisions per path and a workgroup barrier go (config 5: staging is 45 % of a workgroup's life).
+    constexpr bool kSlopeOnDemand = PPB == 2;
+    if (!slopes && !kSlopeOnDemand) {
         // the interval slopes (t1 - t0)/(d1 - d0) of SM:311-317 from the staged distances — the expression k_lut uses, so
         // the same numbers, without 8 KB per path going to HBM and back (config 5: a fifth of the step's traffic)
         __syncthreads();
@@ -787,7 +793,14 @@ __global__ __launch_bounds__(kSampleThreads, 3) void k_sample(int B, int W, int 
             const double d0 = sD[idx - 1];
             const double t0 = (double)(idx - 1) * lstep;
             const bool exact = INTERIOR ? false : (s <= 0.0 || s >= total);
-            double t = fma(sWt[idx], s - d0, t0);
+            double wslope;
+            if (kSlopeOnDemand && !slopes) {
+                const double t1 = (idx == kLutN - 1) ? t_max : (double)idx * lstep;
+                wslope = div_inrange(t1 - t0, sD[idx] - d0);
+            } else {
+                wslope = sWt[idx];
+            }
+            double t = fma(wslope, s - d0, t0);
             if constexpr (!INTERIOR) t = s >= total ? end_param : t;
             bool near;
             jjv[i] = table_index_fast(t, tab_n, inv_tstep, near);
