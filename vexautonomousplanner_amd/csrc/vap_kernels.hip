@@ -40,15 +40,18 @@ template <typename IT>
 __device__ __forceinline__ void fit_path(int b, int W, const IT *__restrict__ waypoints, const double *__restrict__ tan_in,
                                          const double *__restrict__ tan_out, const FitExtras &ex, double *__restrict__ segments,
                                          double *__restrict__ power, double *__restrict__ seglen, double *__restrict__ meta,
-                                         uint32_t *__restrict__ flags, double *sh)
+                                         uint32_t *__restrict__ flags, double *sh, int tid = threadIdx.x, int nt = blockDim.x,
+                                         uint32_t *flag_word = nullptr)
 {
-    const int tid = threadIdx.x, nt = blockDim.x;
+    // (tid, nt: the threads that work on THIS path — the whole workgroup, or a sub-group of it when k_fit_many packs
+    // several short paths into one; every __syncthreads below is reached by all threads of the workgroup either way)
     const int G = W - 1;
     double *pts = sh;             // 2W
     double *dist = pts + 2 * W;   // G (W slots)
     double *fd = dist + W;        // 2W
     double *sd = fd + 2 * W;      // 2W
-    __shared__ uint32_t s_flag;
+    __shared__ uint32_t s_flag_one;
+    uint32_t &s_flag = flag_word ? *flag_word : s_flag_one;
     if (tid == 0) s_flag = 0;
     const IT *wp = waypoints + (size_t)b * W * 2;
     for (int i = tid; i < 2 * W; i += nt) pts[i] = (double)wp[i];
@@ -173,6 +176,23 @@ __global__ __launch_bounds__(256) void k_fit(int W, const IT *__restrict__ waypo
 {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     fit_path<IT>(blockIdx.x, W, waypoints, tan_in, tan_out, ex, segments, power, seglen, meta, flags, sh);
+}
+
+// K1 for very many short paths (config 5: 131 072 paths of 8 waypoints): k_fit gives a path a workgroup of 64 threads of
+// which W work; here a workgroup of 256 threads takes 256 / L paths, L = the power of two >= W lanes each — the same
+// fit_path, the same rows.
+template <typename IT>
+__global__ __launch_bounds__(256) void k_fit_many(int B, int W, int L, const IT *__restrict__ waypoints, double *__restrict__ segments,
+                                                  double *__restrict__ power, double *__restrict__ meta, uint32_t *__restrict__ flags)
+{
+    extern __shared__ __attribute__((aligned(16))) double sh[];   // (256 / L) paths x 7W doubles
+    __shared__ uint32_t s_flags[64];
+    const int per = 256 / L, sub = threadIdx.x / L, lane = threadIdx.x % L;
+    int b = blockIdx.x * per + sub;
+    // (paths past the batch: the last path once more — same values into the same places, so every thread reaches the barriers)
+    b = b < B ? b : B - 1;
+    fit_path<IT>(b, W, waypoints, nullptr, nullptr, FitExtras(), segments, power, nullptr, meta, flags, sh + (size_t)sub * 7 * W, lane, L,
+                 &s_flags[sub]);
 }
 
 __global__ void k_grid(int B, int W, int S, double dd_in, double *__restrict__ meta, double *__restrict__ aux,
@@ -2416,6 +2436,15 @@ static hipError_t launch_fit_t(hipStream_t st, int B, int W, const void *wp, con
                                uint32_t *flags)
 {
     const size_t lds = sizeof(double) * (size_t)(7 * W);
+    const bool plain = !tin && !tout && !seglen && !ex.first && !ex.second && !ex.start_tan && !ex.end_tan && !ex.out_first && !ex.out_second;
+    if (plain && W <= 16 && B >= 8192) {
+        // very many short paths: 256 / L paths per workgroup, L lanes each (k_fit would leave 56 of its 64 lanes idle at W = 8)
+        int L = 4;
+        while (L < W) L *= 2;
+        const int per = 256 / L;
+        hipLaunchKernelGGL(k_fit_many<IT>, dim3((B + per - 1) / per), dim3(256), lds * per, st, B, W, L, (const IT *)wp, seg, pw, meta, flags);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_fit<IT>, dim3(B), dim3(W <= 64 ? 64 : 256), lds, st, W, (const IT *)wp, tin, tout, ex,
                        seg, pw, seglen, meta, flags);
     return hipGetLastError();
