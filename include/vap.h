@@ -105,7 +105,7 @@ int vap_ctx_synchronize(vap_ctx *ctx);
  * direction; RELAX_ROUNDS forces the earlier form of that kernel (one launch per super-round, convergence checked
  * on the host) — the same rows bit for bit (tests). */
 enum { VAP_OPT_VELOCITY_KERNEL = 0, VAP_OPT_F32_RECURRENCE = 1, /* 2: retired (sampling inside the velocity kernel, rounds 3-4) */
-       VAP_OPT_TIME_DOMAIN_RESIDUAL = 3 };
+       VAP_OPT_TIME_DOMAIN_RESIDUAL = 3, VAP_OPT_TIME_KERNEL = 4 };
 enum { VAP_VELOCITY_AUTO = 0, VAP_VELOCITY_SEQ_LITERAL = 1, VAP_VELOCITY_SEQ_FAST = 2, VAP_VELOCITY_RELAX = 3,
        VAP_VELOCITY_RELAX_BLOCK = 4 /* workgroup per path */, VAP_VELOCITY_RELAX_WAVE = 5 /* wave per path, fp32 */,
        VAP_VELOCITY_LANES = 6 /* lane per path, fp64 recurrence */, VAP_VELOCITY_LANES_16 = 7, VAP_VELOCITY_LANES_32 = 8,
@@ -124,6 +124,11 @@ enum { VAP_RECURRENCE_F64 = 0, VAP_RECURRENCE_F32 = 1 };
  * row + residual (MPG:566-584) — the caller's row as it is at that moment plus a term below its own rounding — which
  * is what keeps fp32 time-domain rows within 1e-5 of the reference.  Callers that never go to the time domain (pure
  * distance-domain batches, e.g. candidate ranking) switch it off and save the traffic. */
+/* VAP_OPT_TIME_KERNEL: the kinematic recurrence of vap_time_profile[_routes] (MPG:566-584).  LANE walks a path with one
+ * lane; QUAD with four (one grid index, one velocity sample and one interpolation per lane instead of two, four and two,
+ * the 64-byte row stored as four 16-byte pieces) — the same rows bit for bit, a shorter step.  AUTO (default) takes
+ * QUAD while four lanes per path still leave at most one wavefront per SIMD (B <= 16384) and LANE above that. */
+enum { VAP_TIME_KERNEL_AUTO = 0, VAP_TIME_KERNEL_LANE = 1, VAP_TIME_KERNEL_QUAD = 2 };
 int vap_ctx_set_option(vap_ctx *ctx, int option, int value);
 /* Enable/disable per-stage hipEvent timing (replaces the reference's time.time() log lines,
  * SM:587-594, MPG:398-411).  Off by default. */

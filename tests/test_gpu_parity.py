@@ -979,6 +979,38 @@ def test_time_profile_integrates_the_row_as_the_caller_left_it(torch_mod, B):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype,resid", [("f32", True), ("f32", False), ("f64", False)])
+def test_time_profile_quad_kernel_is_bit_identical(torch_mod, dtype, resid):
+    """VAP_OPT_TIME_KERNEL: four lanes per path (what AUTO takes up to 16384 paths) and one lane per path walk the same
+    recurrence (MPG:566-584) — same counts, maps and row bits, for batch sizes that leave quads and wavefronts partly
+    empty, a capacity that truncates, and a batch above AUTO's switch."""
+    from vexautonomousplanner_amd.batch import BatchedTrajectoryGenerator
+    from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
+    torch = torch_mod
+    td = torch.float64 if dtype == "f64" else torch.float32
+    gen = BatchedTrajectoryGenerator(0, dtype, time_domain_residual=resid)
+    for B, W, S, cap in ((1, 4, 900, 1024), (17, 8, 1500, 2048), (67, 6, 700, 60), (16500, 5, 300, 768)):
+        wp = torch.tensor(make_waypoints(B, W, 77 + B), device="cuda:0", dtype=td)
+        res = gen.profile(wp, DEFAULT_CONSTRAINTS, samples=S)
+        got = {}
+        for k in ("lane", "quad", "auto"):
+            gen.set_time_kernel(k)
+            got[k] = {n: v.clone() for n, v in gen.time_profile(res, DEFAULT_CONSTRAINTS, capacity_rows=cap).items()}
+        torch.cuda.synchronize()
+        counts = got["lane"]["counts"].cpu().numpy()
+        assert counts[:, 0].min() >= 60
+        if cap == 60:
+            assert (counts[:, 0] == 60).all()
+        for k in ("quad", "auto"):
+            assert torch.equal(got[k]["counts"], got["lane"]["counts"]), (B, k)
+            rows_a, rows_b = got["lane"]["rows"].cpu().numpy(), got[k]["rows"].cpu().numpy()
+            nm_a, nm_b = got["lane"]["nodes_map"].cpu().numpy(), got[k]["nodes_map"].cpu().numpy()
+            for b in range(0, B, max(1, B // 300)):
+                assert rows_a[b, :counts[b, 0]].tobytes() == rows_b[b, :counts[b, 0]].tobytes(), (B, k, b)
+                assert np.array_equal(nm_a[b, :counts[b, 1]], nm_b[b, :counts[b, 1]]), (B, k, b)
+
+
+@pytest.mark.gpu
 def test_time_profile_argument_errors(torch_mod):
     """vap_time_profile through the C-ABI: status codes for a context without tables, a shape that does not
     match the last batch, and null / non-positive arguments."""

@@ -291,6 +291,10 @@ int vap_ctx_set_option(vap_ctx *ctx, int option, int value)
         ctx->vres_for = nullptr;
         return VAP_OK;
     }
+    if (option == VAP_OPT_TIME_KERNEL && value >= VAP_TIME_KERNEL_AUTO && value <= VAP_TIME_KERNEL_QUAD) {
+        ctx->time_kernel = value;
+        return VAP_OK;
+    }
     if (option == VAP_OPT_F32_RECURRENCE && (value == VAP_RECURRENCE_F64 || value == VAP_RECURRENCE_F32)) {
         ctx->f32_recurrence = value;
         ctx->rows_valid = false;   // rows left by an earlier call belong to the other mode
@@ -723,7 +727,7 @@ int vap_time_profile(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, const doub
     const void *vrow = time_domain_velocity(ctx, dt, B, S, d_velocity, v64, vres);
     HIP_TRY(vap::launch_time_profile(ctx->stream, v64, B, W, S, d_segments, d_lut, d_meta, vrow, c->max_acc,
                                      c->max_dec, time_step, capacity_rows, d_rows, d_counts, d_nodes_map, d_flags, vap::RouteTables(),
-                                     nullptr, vres));
+                                     nullptr, vres, ctx->time_kernel));
     return VAP_OK;
 }
 
@@ -779,7 +783,7 @@ int vap_time_profile_routes(vap_ctx *ctx, vap_dtype dt, int B, int W, int S, con
     const void *vrow = time_domain_velocity(ctx, dt, B, S, d_velocity, v64, vres);
     HIP_TRY(vap::launch_time_profile(ctx->stream, v64, B, W, S, (const double *)ctx->seg.ptr, (const double *)ctx->lut.ptr,
                                      d_meta, vrow, c->max_acc, c->max_dec, time_step, capacity_rows, d_rows, d_counts,
-                                     d_nodes_map, d_flags, rt, d_node_reverse, vres));
+                                     d_nodes_map, d_flags, rt, d_node_reverse, vres, ctx->time_kernel));
     return VAP_OK;
 }
 

@@ -48,6 +48,7 @@ struct vap_ctx {
     const void *vres_for = nullptr;
     int vres_B = 0, vres_S = 0;
     int keep_residual = 1;    // VAP_OPT_TIME_DOMAIN_RESIDUAL
+    int time_kernel = 0;      // VAP_OPT_TIME_KERNEL
     VapBuffer k64, dth64;             // fp64 curvature / |dtheta| rows behind fp32 outputs (VAP_RECURRENCE_F64)
     VapBuffer sptab, nspl;            // spline tables of the last vap_profile_routes batch
     int route_NS = 0;                 // > 0: seg / lut hold a batch of routes with up to route_NS splines each

@@ -113,7 +113,8 @@ hipError_t launch_power(hipStream_t st, int n_seg, const double *seg, double *pw
 hipError_t launch_time_profile(hipStream_t st, bool f64, int B, int W, int S, const double *segments, const double *lut,
                                const double *meta, const void *vel, double max_acc, double max_dec, double dt, int cap,
                                double *rows, int *counts, int *nodes_map, uint32_t *flags, RouteTables rt = RouteTables(),
-                               const int *node_reverse = nullptr, const float *vres = nullptr);   // vres: fp32 rows only, see k_time_integrate
+                               const int *node_reverse = nullptr, const float *vres = nullptr,
+                               int time_kernel = 0);   // vres: fp32 rows only, see k_time_integrate
 // vap_limits.hip: sample of every event (node / action point), then the per-sample limit rows
 struct LimitInputs {
     const double *node_mv = nullptr, *node_ma = nullptr;   // [B][W] per-node max_velocity / max_acceleration (<= 0: none)

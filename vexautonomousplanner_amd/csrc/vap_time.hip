@@ -156,6 +156,189 @@ __global__ __launch_bounds__(64) void k_time_integrate(int B, int S, const doubl
     if (full && flags) atomicOr(&flags[b], VAP_FLAG_TRUNCATED_BIT);
 }
 
+// quad_perm of a double: lane r of every aligned group of four reads lane SEL[r] of the same group (two v_mov_b32_dpp)
+template <int CTRL>
+__device__ __forceinline__ double quad_perm_f64(double x)
+{
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+constexpr int kQuad1133 = 1 | (1 << 2) | (3 << 4) | (3 << 6), kQuad0000 = 0, kQuad2222 = 2 | (2 << 2) | (2 << 4) | (2 << 6),
+              kQuad2301 = 2 | (3 << 2) | (0 << 4) | (1 << 6);
+
+// One step's memory operations of k_time_integrate_quad, in issue order: the lane's velocity sample (+ residual), the
+// 16-byte piece of the previous step's row, one touch per velocity row further along — then wait for the sample alone
+// (vmcnt counts in issue order: the store and the touches stay in flight).  Written as one asm statement because the
+// compiler's own wait counts know nothing of loads whose results are never used, and would wait for the store instead.
+// `off` / `off_next`: byte offsets from the rows' bases (scalar base + 32-bit offset addressing).
+constexpr int kPrefetchBytes = 512;
+typedef double vap_f64x2 __attribute__((ext_vector_type(2)));
+template <typename R, bool RES>
+__device__ __forceinline__ double quad_step_memory(const R *__restrict__ vel, const float *__restrict__ vres, uint32_t off,
+                                                   uint32_t off_next, double *q, double sa, double sb, uint32_t &touch0,
+                                                   uint32_t &touch1)
+{
+    vap_f64x2 row;
+    row.x = sa;
+    row.y = sb;
+    if constexpr (sizeof(R) == 8) {
+        double y;
+        asm volatile("global_load_dwordx2 %[y], %[off], %[vel]\n\t"
+                     "global_store_dwordx4 %[q], %[row], off\n\t"
+                     "global_load_dword %[t0], %[nxt], %[vel]\n\t"
+                     "s_waitcnt vmcnt(2)"
+                     : [y] "=&v"(y), [t0] "+v"(touch0)
+                     : [off] "v"(off), [nxt] "v"(off_next), [vel] "s"(vel), [q] "v"(q), [row] "v"(row)
+                     : "memory");
+        return y;
+    } else if constexpr (RES) {
+        float y, yr;
+        asm volatile("global_load_dword %[y], %[off], %[vel]\n\t"
+                     "global_load_dword %[yr], %[off], %[res]\n\t"
+                     "global_store_dwordx4 %[q], %[row], off\n\t"
+                     "global_load_dword %[t0], %[nxt], %[vel]\n\t"
+                     "global_load_dword %[t1], %[nxt], %[res]\n\t"
+                     "s_waitcnt vmcnt(3)"
+                     : [y] "=&v"(y), [yr] "=&v"(yr), [t0] "+v"(touch0), [t1] "+v"(touch1)
+                     : [off] "v"(off), [nxt] "v"(off_next), [vel] "s"(vel), [res] "s"(vres), [q] "v"(q), [row] "v"(row)
+                     : "memory");
+        return (double)y + (double)yr;
+    } else {
+        float y;
+        asm volatile("global_load_dword %[y], %[off], %[vel]\n\t"
+                     "global_store_dwordx4 %[q], %[row], off\n\t"
+                     "global_load_dword %[t0], %[nxt], %[vel]\n\t"
+                     "s_waitcnt vmcnt(2)"
+                     : [y] "=&v"(y), [t0] "+v"(touch0)
+                     : [off] "v"(off), [nxt] "v"(off_next), [vel] "s"(vel), [q] "v"(q), [row] "v"(row)
+                     : "memory");
+        return (double)y;
+    }
+}
+
+// The same recurrence with FOUR lanes per path, for batches that leave most of the chip idle (B <= 16384: at config 3 the
+// lane-per-path kernel is 64 wavefronts on 1024 SIMDs, and a step is a chain of ~230 mostly dependent instructions).
+// The four velocity samples of a step are the same code on different data — sample i0 / i0 + 1 of the row where the
+// position stands, i1 / i1 + 1 one grid step ahead — so lane r of a path's quad computes the grid index of ITS position
+// (lanes 0, 1: current_pos, lanes 2, 3: ahead — the unique i with i*dd <= x < (i+1)*dd, which is what grid_index_from
+// finds from its guess), loads and rebuilds ITS sample, and the even lanes do the two lerps after one quad_perm; both
+// results are broadcast and every lane carries the (identical) state forward, so nothing is sent back.  One index, one
+// sample, one lerp per lane instead of two, four, two; the 64-byte row leaves as one 16-byte store per lane (the pieces
+// k_time_geometry overwrites — heading, x, y — are scratch until then).  Sixteen paths per wavefront: 256 workgroups
+// at config 3, each on its own CU, and a wavefront's loads touch 16 rows instead of 64.  Bit-identical to the
+// lane-per-path kernel (tools/fuzz_time_profile.py runs both).
+template <typename R, bool RES>
+__global__ __launch_bounds__(64) void k_time_integrate_quad(int B, int S, const double *__restrict__ meta,
+                                                            const R *__restrict__ vel, const float *__restrict__ vres,
+                                                            double max_acc, double max_dec, double dt, int cap,
+                                                            double *__restrict__ rows, int *__restrict__ counts,
+                                                            uint32_t *__restrict__ flags)
+{
+    const int r = threadIdx.x & 3;
+    const int b = blockIdx.x * 16 + (threadIdx.x >> 2);
+    if (b >= B) return;                        // (whole quads)
+    const double *m = meta + (size_t)b * kMetaStride;
+    const double total = m[1], dd = m[2], inv_dd = 1.0 / dd;
+    const int N = (int)m[3];
+    const uint32_t row0 = (uint32_t)b * (uint32_t)S;        // (the launcher keeps B * S under 2^30)
+    auto at = [&](int i) {
+        const uint32_t o = row0 + (uint32_t)i;
+        if constexpr (RES) return (double)vel[o] + (double)vres[o];
+        else return (double)vel[o];
+    };
+    const bool odd = (r & 1) != 0, hi = (r & 2) != 0;
+    double *q = rows + (size_t)b * cap * kRowWidth + 2 * r;   // this lane's 16 bytes of the row
+    double current_time = 0, current_pos = 0, current_vel = N > 0 ? at(0) : 0.0;   // MPG:413-418
+    int T = 0;
+    bool full = false;
+    {
+        double rdt = __builtin_amdgcn_rcp(dt);
+        rdt = fma(fma(-dt, rdt, 1.0), rdt, rdt);
+        rdt = fma(fma(-dt, rdt, 1.0), rdt, rdt);
+        const double n1 = (double)(N - 1);
+        double sa = 0, sb = 0;          // this lane's piece of the row of the step before
+        uint32_t touch0 = 0, touch1 = 0;   // where the touches land: live across the loop, since they arrive a step later
+        while (total > 0 && N > 1 && current_pos < total) {   // MPG:523
+            if (T >= cap) { full = true; break; }
+            const double x = hi ? current_pos + dd : current_pos;
+            double e = floor(x * inv_dd);
+            e = !(e >= -1.0) ? -1.0 : e;
+            e = e > n1 ? n1 : e;
+            int g = (int)e;
+            g += ((g + 1 < N) & ((double)(g + 1) * dd <= x)) ? 1 : 0;
+            g -= ((g >= 0) & !((double)g * dd <= x)) ? 1 : 0;
+            const double x0 = (double)g * dd, x1 = (double)(g + 1) * dd;
+            const int ok = (((g + 1 >= N) | !(x1 <= x)) & ((g < 0) | (x0 <= x))) ? 1 : 0;
+            if (__builtin_expect(!(ok & __builtin_amdgcn_mov_dpp(ok, kQuad2301, 0xF, 0xF, true)), 0)) break;   // (state untouched)
+            // The step's memory operations, by hand (quad_step_memory): this lane's sample (row and residual), THEN the row
+            // of the step before, THEN a touch of the velocity rows kPrefetchBytes further on — and a wait that leaves
+            // the store and the touches in flight.  A step moves up to ~20 samples, each of a wavefront's 16 paths
+            // crosses into a new cache line every other step or so, and the wavefront waits for its slowest lane: without
+            // the touch every step pays an L2 / HBM round trip (half the kernel's time, tools/ab_time_quad.py history).
+            const int gi = g + (odd ? 1 : 0);
+            const uint32_t o = (row0 + (uint32_t)clamp_index(gi, N)) * (uint32_t)sizeof(R);
+            const uint32_t o_next = (row0 + (uint32_t)min(gi + kPrefetchBytes / (int)sizeof(R), N - 1)) * (uint32_t)sizeof(R);
+            const double y = quad_step_memory<R, RES>(vel, vres, o, o_next, q, sa, sb, touch0, touch1);
+            const double xm = odd ? x1 : x0;
+            const double yn = quad_perm_f64<kQuad1133>(y), xn = quad_perm_f64<kQuad1133>(xm);   // even lanes: the odd neighbour's
+            // MPG:349-386 lerp on the even lanes (the odd lanes' quotient is 0/0 and goes nowhere)
+            const double l = y + div_inrange((x - xm) * (yn - y), xn - xm);
+            const double tv = (g < 0 || g >= N - 1) ? y : l;
+            double target_vel = (quad_perm_f64<kQuad0000>(tv) + quad_perm_f64<kQuad2222>(tv)) / 2;      // MPG:566-570
+            if (!(target_vel > 0.001)) target_vel = 0.001;
+            const double dv = target_vel - current_vel;
+            const double q0 = dv * rdt;
+            const double accel = clip(fma(fma(-dt, q0, dv), rdt, q0), -max_dec, max_acc);     // MPG:572-573
+            current_vel = clip(current_vel + accel * dt, 0, target_vel);                        // MPG:578
+            double delta_pos = current_vel * dt + 0.5 * accel * dt * dt;                        // MPG:580
+            if (current_vel <= 0.1) delta_pos = 0.1 * dt + 0.5 * accel * dt * dt;               // MPG:581-582
+            current_pos += delta_pos;
+            // lane 0: time, position; lane 1: velocity, acceleration; lane 2: (scratch), target velocity; lane 3: scratch
+            sa = odd ? current_vel : current_time;
+            sb = hi ? target_vel : (odd ? accel : current_pos);
+            q += T > 0 ? kRowWidth : 0;       // q: the row of the step before (row 0 at step 0)
+            T += 1;
+            current_time += dt;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(touch0), "+v"(touch1) : : "memory");   // (the last touches have landed)
+        if (T > 0) *reinterpret_cast<double2 *>(q) = make_double2(sa, sb);
+        q += T > 0 ? kRowWidth : 0;           // row T again
+    }
+    // the statement-by-statement loop (see k_time_integrate): every lane of the quad walks it with the same state
+    q -= 2 * r;
+    while (!full && total > 0 && N > 1 && current_pos < total) {   // MPG:523
+        if (T >= cap) { full = true; break; }
+        const double ahead = current_pos + dd;
+        const int i0 = grid_index(current_pos, dd, inv_dd, N), i1 = grid_index_from(ahead, dd, inv_dd, N, i0 + 1);
+        const double a0 = at(clamp_index(i0, N)), a1 = at(clamp_index(i0 + 1, N));
+        const double c0 = at(clamp_index(i1, N)), c1 = at(clamp_index(i1 + 1, N));
+        double target_vel = lerp_at(current_pos, dd, i0, N, a0, a1);
+        const double next_target_vel = lerp_at(ahead, dd, i1, N, c0, c1);
+        target_vel = (target_vel + next_target_vel) / 2;
+        if (!(target_vel > 0.001)) target_vel = 0.001;
+        const double accel = clip((target_vel - current_vel) / dt, -max_dec, max_acc);   // MPG:572-573
+        current_vel = clip(current_vel + accel * dt, 0, target_vel);                      // MPG:578
+        double delta_pos = current_vel * dt + 0.5 * accel * dt * dt;                      // MPG:580
+        if (current_vel <= 0.1) delta_pos = 0.1 * dt + 0.5 * accel * dt * dt;             // MPG:581-582
+        current_pos += delta_pos;
+        if (r == 0) {
+            q[0] = current_time;
+            q[1] = current_pos;
+            q[2] = current_vel;
+            q[3] = accel;
+            q[5] = target_vel;
+        }
+        q += kRowWidth;
+        T += 1;
+        current_time += dt;
+    }
+    if (r == 0) {
+        counts[2 * b] = T;
+        if (full && flags) atomicOr(&flags[b], VAP_FLAG_TRUNCATED_BIT);
+    }
+}
+
 // point / derivative / second derivative on ONE segment at its local parameter (the sum of QHS:221-251 / 473-504)
 __device__ __forceinline__ void hermite_eval_seg(const double *__restrict__ sg, int order, double lt, double &ox, double &oy)
 {
@@ -282,10 +465,23 @@ __global__ __launch_bounds__(256) void k_time_geometry(int W, int cap, const dou
 hipError_t launch_time_profile(hipStream_t st, bool f64, int B, int W, int S, const double *segments, const double *lut,
                                const double *meta, const void *vel, double max_acc, double max_dec, double dt, int cap,
                                double *rows, int *counts, int *nodes_map, uint32_t *flags, RouteTables rt, const int *node_reverse,
-                               const float *vres)
+                               const float *vres, int time_kernel)
 {
     const int nblk = (B + 63) / 64;
-    if (f64)
+    // four lanes per path while that still leaves at most one wavefront per SIMD (k_time_integrate_quad)
+    // (time_kernel: VAP_OPT_TIME_KERNEL — 0 by batch size, 1 lane per path, 2 four lanes per path wherever the row offsets fit)
+    const bool quad = (size_t)B * (size_t)S < ((size_t)1 << 30) && (time_kernel == 2 || (time_kernel == 0 && B <= 16384));
+    const int nq = (B + 15) / 16;
+    if (quad && f64)
+        hipLaunchKernelGGL((k_time_integrate_quad<double, false>), dim3(nq), dim3(64), 0, st, B, S, meta, (const double *)vel,
+                           (const float *)nullptr, max_acc, max_dec, dt, cap, rows, counts, flags);
+    else if (quad && vres)
+        hipLaunchKernelGGL((k_time_integrate_quad<float, true>), dim3(nq), dim3(64), 0, st, B, S, meta, (const float *)vel, vres,
+                           max_acc, max_dec, dt, cap, rows, counts, flags);
+    else if (quad)
+        hipLaunchKernelGGL((k_time_integrate_quad<float, false>), dim3(nq), dim3(64), 0, st, B, S, meta, (const float *)vel,
+                           (const float *)nullptr, max_acc, max_dec, dt, cap, rows, counts, flags);
+    else if (f64)
         hipLaunchKernelGGL((k_time_integrate<double, false>), dim3(nblk), dim3(64), 0, st, B, S, meta, (const double *)vel,
                            (const float *)nullptr, max_acc, max_dec, dt, cap, rows, counts, flags);
     else if (vres)
