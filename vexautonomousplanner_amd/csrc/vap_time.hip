@@ -370,6 +370,7 @@ __global__ __launch_bounds__(256) void k_time_geometry(int W, int cap, const dou
     extern __shared__ __attribute__((aligned(16))) double s_seg[];   // G * 12 when SEG_LDS
     __shared__ double sD[ROUTES ? 1 : kLutN];
     __shared__ int s_wave[4], s_base;
+    __shared__ double s_t[256], s_t_carry;     // this chunk's parameters, and the last one of the chunk before
     const int b = blockIdx.x, tid = threadIdx.x;
     const int G = W - 1;
     const double *m = meta + (size_t)b * kMetaStride;
@@ -416,8 +417,13 @@ __global__ __launch_bounds__(256) void k_time_geometry(int W, int cap, const dou
             // the row was produced from the position BEFORE its own update: the previous row's
             const double pos = i == 0 ? 0.0 : q[1 - kRowWidth];
             t = d2t(pos);                                                                     // MPG:525
-            double prev_t = 0.0;                                                              // MPG:521
-            if (i > 0) prev_t = d2t(i == 1 ? 0.0 : q[1 - 2 * kRowWidth]);
+        }
+        // prev_t (MPG:521) is the parameter of the row before — the same function of the same position, so it is taken
+        // from the neighbouring thread instead of a second search of the table
+        s_t[tid] = t;
+        __syncthreads();
+        if (i < T) {
+            const double prev_t = i == 0 ? 0.0 : (tid > 0 ? s_t[tid - 1] : s_t_carry);
             crossing = mod1(t) < mod1(prev_t) && t < end_param;                               // MPG:527
         }
         // ordered compaction of the crossings of these 256 rows into nodes_map (MPG:528-529)
@@ -459,6 +465,7 @@ __global__ __launch_bounds__(256) void k_time_geometry(int W, int cap, const dou
         }
         __syncthreads();
         if (tid == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        if (tid == 255) s_t_carry = t;
         __syncthreads();
     }
     if (tid == 0) counts[2 * b + 1] = s_base < W ? s_base : W;
