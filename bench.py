@@ -188,27 +188,41 @@ def dropin_config1(calls=20):
         from splines.spline_manager import QuinticHermiteSplineManager
         from vexautonomousplanner_amd.nodes import Node
         from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
+        from vexautonomousplanner_amd._device_path import DeviceRoute
         wp = make_waypoints(1, 8, 1)[0].astype(np.float64)        # config 1: seed 1, golden c1_w8
         nodes = [Node() for _ in wp]
-        t_build, t_prof, rows = [], [], 0
-        for i in range(calls + 2):
-            t0 = time.perf_counter()
-            sm = QuinticHermiteSplineManager()
-            ok = sm.build_path(wp, nodes, [])
-            t1 = time.perf_counter()
-            res = mpg.generate_motion_profile(sm, mpg.Constraints(*DEFAULT_CONSTRAINTS))
-            t2 = time.perf_counter()
-            assert ok and len(res) == 9
-            rows = len(res[0])
-            if i >= 2:                                            # two untimed calls: library load, first allocations
-                t_build.append(t1 - t0)
-                t_prof.append(t2 - t1)
-        bp, gp = float(np.mean(t_build)) * 1e3, float(np.mean(t_prof)) * 1e3
-        return {"workload": "c1: one 8-waypoint path, default constraints, dd = 0.005, dt = 0.01", "calls": calls,
-                "build_path_ms": bp, "generate_motion_profile_ms": gp, "ms_per_call": bp + gp, "time_rows": rows,
-                "min_ms": float(np.min(np.add(t_build, t_prof))) * 1e3,
-                "reference_python_ms": {"build_path": 4.9, "generate_motion_profile": 267.0,
-                                        "measured": "build container, 1 Xeon 2.1 GHz core (BASELINE.md section 2)"}}
+
+        def leg(batch_kernels):
+            DeviceRoute.use_batch_kernels = batch_kernels
+            t_build, t_prof, rows = [], [], 0
+            try:
+                for i in range(calls + 2):
+                    t0 = time.perf_counter()
+                    sm = QuinticHermiteSplineManager()
+                    ok = sm.build_path(wp, nodes, [])
+                    t1 = time.perf_counter()
+                    res = mpg.generate_motion_profile(sm, mpg.Constraints(*DEFAULT_CONSTRAINTS))
+                    t2 = time.perf_counter()
+                    assert ok and len(res) == 9
+                    rows = len(res[0])
+                    if i >= 2:                                    # two untimed calls: library load, first allocations
+                        t_build.append(t1 - t0)
+                        t_prof.append(t2 - t1)
+            finally:
+                DeviceRoute.use_batch_kernels = False
+            per_call = np.add(t_build, t_prof) * 1e3
+            return {"build_path_ms": float(np.mean(t_build)) * 1e3, "generate_motion_profile_ms": float(np.mean(t_prof)) * 1e3,
+                    "ms_per_call": float(per_call.mean()), "min_ms": float(per_call.min()),
+                    "median_ms": float(np.median(per_call)), "max_ms": float(per_call.max()), "time_rows": rows}
+
+        out = {"workload": "c1: one 8-waypoint path, default constraints, dd = 0.005, dt = 0.01", "calls": calls,
+               "layer": "one-lane vap_route_* kernels, the reference's statement order (the drop-in's default)"}
+        out.update(leg(False))
+        # the opt-in layer (DeviceRoute.use_batch_kernels = True): the batch kernels with B = 1
+        out["batch_kernels"] = leg(True)
+        out["reference_python_ms"] = {"build_path": 4.9, "generate_motion_profile": 267.0,
+                                      "measured": "build container, 1 Xeon 2.1 GHz core (BASELINE.md section 2)"}
+        return out
     finally:
         sys.path.remove(os.path.join(ROOT, "dropin"))
 
@@ -512,7 +526,7 @@ def main():
             line["time_domain"] = time_domain
         if dropin_c1 is not None:
             line["dropin_c1"] = dropin_c1
-            line["dropin_c1_ms"] = dropin_c1["ms_per_call"]
+            line["dropin_c1_ms"] = dropin_c1["median_ms"]   # (mean, min and max are in the object: a full Python GC pass — ~40 ms with torch imported — lands in one call of a few dozen)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(wl)
             # context, not measured here: the reference's own Python cannot travel to this box

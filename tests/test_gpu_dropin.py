@@ -230,6 +230,33 @@ def test_generate_motion_profile_nine_tuple(mods, name):
     np.testing.assert_allclose(np.array(coords), g["profile_coords"], rtol=1e-10, atol=1e-10)
 
 
+@pytest.mark.parametrize("name", PROFILES)
+def test_one_lane_layer_and_batch_kernels_give_the_same_profile(mods, name):
+    """DeviceRoute.use_batch_kernels: generate_motion_profile / forward_backward_pass through the batch kernels with
+    B = 1 (opt-in) and through the one-lane vap_route_* layer (the default: the reference's statement order) — the same row
+    count and maps, rows within 1e-8 of each other (both are pinned to the same goldens above), and the switch does
+    select the layer (the one-lane velocities are not the batch kernels' bits on every route)."""
+    _, mpg, _, _ = mods
+    from vexautonomousplanner_amd._device_path import DeviceRoute
+    g = gu.load(name)
+    c = mpg.Constraints(*g["constraints"])
+    got = {}
+    try:
+        for layer in (True, False):
+            DeviceRoute.use_batch_kernels = layer
+            m = build_route(mods, g)
+            m.rebuild_tables()
+            got[layer] = (mpg.generate_motion_profile(m, c), np.array(mpg.forward_backward_pass(m, c, float(g["dd"]))))
+    finally:
+        DeviceRoute.use_batch_kernels = False
+    (ra, va), (rb, vb) = got[True], got[False]
+    assert len(ra[0]) == len(rb[0]) and ra[6] == rb[6] and ra[7] == rb[7]
+    for k in range(6):
+        np.testing.assert_allclose(ra[k], rb[k], rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(np.array(ra[8]), np.array(rb[8]), rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(va, vb, rtol=1e-9)
+
+
 # ---- the call surface off the hot path, against values recorded from the real reference -----------------
 # (tests/golden/api/pin_spline_api.npz, oracle/gen_golden.py::run_api_pins): SURVEY 8(a) a2, a6, a10, a18
 @pytest.fixture(scope="module")

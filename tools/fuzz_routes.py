@@ -2,7 +2,7 @@
 """Developer tool (GPU box): randomised check of the drop-in classes (general routes: stops, limits, tangent
 overrides, reverse / turn nodes, waits, action points; random robots) against the oracle, which
 oracle/fuzz_vs_reference.py holds to the real reference on the same kind of routes.
-  python tools/fuzz_routes.py [seconds] [seed]
+  python tools/fuzz_routes.py [seconds] [seed] [--batch-kernels]     (DeviceRoute.use_batch_kernels = True)
 """
 import os
 import sys
@@ -22,8 +22,13 @@ from splines.spline_manager import QuinticHermiteSplineManager
 from vexautonomousplanner_amd.nodes import ActionPoint, Node
 from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 11)
+one_lane = "--batch-kernels" not in sys.argv
+argv = [a for a in sys.argv if a != "--batch-kernels"]
+budget = float(argv[1]) if len(argv) > 1 else 60.0
+rng = np.random.default_rng(int(argv[2]) if len(argv) > 2 else 11)
+if not one_lane:
+    from vexautonomousplanner_amd._device_path import DeviceRoute
+    DeviceRoute.use_batch_kernels = True
 n = fails = 0
 worst_v = worst_p = 0.0
 t0 = time.time()
@@ -83,5 +88,5 @@ while time.time() - t0 < budget:
     if not (ok and ev <= 1e-9 and ep <= 1e-7):
         fails += 1
         print(f"MISMATCH velocity {ev:.2e} profile {ep:.2e} rows {T} vs {rows.shape[0]} | {tag}", flush=True)
-print(f"{n} routes in {time.time() - t0:.0f} s, {fails} mismatches; worst velocity {worst_v:.2e}, worst profile {worst_p:.2e}")
+print(f"{'one-lane layer' if one_lane else 'batch kernels'}: {n} routes in {time.time() - t0:.0f} s, {fails} mismatches; worst velocity {worst_v:.2e}, worst profile {worst_p:.2e}")
 sys.exit(1 if fails else 0)

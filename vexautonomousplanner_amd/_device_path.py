@@ -151,8 +151,28 @@ class DevicePath:
         return {k: outs[k][0, :n].cpu().numpy() for k in want}, n
 
 
+_ROUTE_BATCH = {}
+
+
+def _route_batch(device):
+    """The fp64 batch generator the single-route calls share on a device (its own context: scratch rows, tables)."""
+    gen = _ROUTE_BATCH.get(device)
+    if gen is None:
+        from .batch import BatchedTrajectoryGenerator
+        gen = _ROUTE_BATCH[device] = BatchedTrajectoryGenerator(device, "f64")
+    return gen
+
+
 class DeviceRoute:
-    """One general route (any node / action-point attributes) on the GPU: vap_route_* of include/vap.h."""
+    """One general route (any node / action-point attributes) on the GPU: vap_route_* of include/vap.h.
+
+    ``use_batch_kernels`` (class or instance attribute, default False): True runs forward_backward (velocity only) and
+    motion_profile on the batch kernels with B = 1 — 0.7 ms instead of 3.2 ms for config 1.  The default stays on the
+    one-lane statement-by-statement vap_route_* layer because it keeps the reference's own operation order: against the
+    oracle on 14 000 random routes and robots it is at 1.4e-9 / 3e-8 (velocity / time rows) at worst, where the batch
+    kernels' reordered arithmetic, amplified by the recurrence, reaches 1.2e-7 / 7.5e-6 on 28 000 (profiles/r04_fuzz.txt)
+    — inside north_star's 1e-5, but a drop-in is judged on fidelity first."""
+    use_batch_kernels = False
 
     def __init__(self, points, nodes, action_points, device=0):
         if not torch.cuda.is_available():
@@ -186,6 +206,10 @@ class DeviceRoute:
             "apw": dcol([a.wait_time for a in action_points]), "apv": dcol([a.max_velocity for a in action_points]),
             "apa": dcol([a.max_acceleration for a in action_points]),
         }
+        self._keep = keep
+        self._nodes_have_limits = bool(keep["stop"].any() or (keep["maxv"] > 0).any() or (keep["maxa"] > 0).any() or M > 0)
+        self._aps = [{"t": float(a.t), "max_velocity": float(a.max_velocity), "max_acceleration": float(a.max_acceleration),
+                      "stop": bool(a.stop), "wait_time": float(a.wait_time)} for a in action_points]
         d = _lib.RouteDesc()
         d.n_nodes, d.n_actions = W, M
         d.waypoints = keep["wp"].ctypes.data_as(dp)
@@ -252,6 +276,46 @@ class DeviceRoute:
             self.total = tot.value
             self._fetch_tables()
 
+    def _try_batched(self, call):
+        """call(batch generator), or None for a route the batched entry points refuse (VAP_ERR_UNSUPPORTED: more nodes
+        than their tables hold) — the one-lane vap_route_* layer takes those."""
+        try:
+            return call(_route_batch(self.ctx.device))
+        except _lib.VapError as e:
+            if e.status == _lib.VAP_ERR_UNSUPPORTED:
+                return None
+            raise
+
+    def _batched_motion_profile(self, constraints, dt, dd):
+        """(rows, nodes_map, actions_map) through the batch kernels, or None when the one-lane layer has to take the call
+        (a route the batch refuses, or marks degenerate / not converged); IndexError where the reference raises."""
+        k = self._keep
+        res = self._try_batched(lambda g: self._batched_distance_domain(g, constraints, dd, 0.01, 0.01,
+                                                                         ("curvature", "velocity")))   # MPG:408
+        if res is None:
+            return None
+        gen = _route_batch(self.ctx.device)
+        # a time step advances at least 0.1 * dt (MPG:581-582): rows <= total / (0.1 * dt); twice that, plus slack
+        cap = int(self.total / (0.05 * float(dt))) + 4096
+        for _ in range(3):
+            tp = gen.time_profile(res, constraints, dt=dt, capacity_rows=cap, node_reverse=k["rev"][None])
+            out = gen.insert_waits(res, tp, node_wait_time=k["wait"][None], action_points=[self._aps] if self.M else None,
+                                   dt=dt, node_turn=k["turn"][None], node_reverse=k["rev"][None], constraints=constraints)
+            head = torch.cat([out["counts"][0], res["flags"][:1]]).cpu().numpy()      # one small copy, the call's sync
+            T, nn, na, flags = (int(v) for v in head)
+            if flags & _lib.FLAG_BAD_ROUTE:
+                raise IndexError("turn / wait before any profile row exists: the reference raises IndexError "
+                                 "(motion_profile_generator.py:440,499)")
+            if flags & _lib.FLAG_TRUNCATED:
+                cap *= 4
+                res["flags"].zero_()
+                continue
+            if flags:
+                return None
+            return (out["rows"][0, :T].cpu().numpy(), out["nodes_map"][0, :nn].cpu().numpy().astype(np.int64),
+                    out["actions_map"][0, :na].cpu().numpy().astype(np.int64))
+        return None
+
     def close(self):
         if getattr(self, "handle", None):
             self._L.vap_route_destroy(self.handle)
@@ -279,10 +343,44 @@ class DeviceRoute:
                                             out.ctypes.data_as(dp)), "vap_route_lookup")
         return out
 
-    def forward_backward(self, constraints, dd, start_vel, end_vel, want=("velocity",)):
+    # -- the batch kernels with B = 1 ------------------------------------------------------------------------------
+    # The route's sampling, limits, velocity pass, time-domain resample and event insertion are what the batched entry
+    # points do for B routes (vap_profile_routes -> vap_route_limits + vap_velocity_pass_limits -> vap_time_profile_routes
+    # -> vap_time_insert_events; the same goldens of the real reference pin both, tests/test_gpu_routes_batch.py): a
+    # single GUI route runs them as a batch of one — 0.65 ms for config 1 where the one-lane vap_route_* kernels
+    # (statement-by-statement, the in-library reference) take 3.2 ms.  Routes whose tables have other sizes than the
+    # reference's defaults (set_table_sizes) and callers that want the per-sample parameter row stay on vap_route_*.
+    def _default_tables(self):
+        return self.use_batch_kernels and (self.lut_samples, self.samples_per_node) == (_lib.LUT_SAMPLES, _lib.LUT_SAMPLES)
+
+    def _sample_count(self, dd):
         n = C.c_int()
         _lib.check(self._L.vap_route_sample_count(self.handle, float(dd), C.byref(n)), "vap_route_sample_count")
-        N = n.value
+        return n.value
+
+    def _batched_distance_domain(self, gen, constraints, dd, start_vel, end_vel, want):
+        k, W = self._keep, self.W
+        wp = torch.tensor(k["wp"][None], dtype=torch.float64, device=gen.device)
+        has_tan = bool(np.isfinite(k["tan"]).any())
+        res = gen.profile_routes(wp, node_reverse=k["rev"][None], node_turn=k["turn"][None],
+                                 node_tangent=k["tan"][None] if has_tan else None,
+                                 node_magnitudes=k["mag"][None] if has_tan else None, constraints=constraints, dd=float(dd),
+                                 start_vel=start_vel, end_vel=end_vel, want=want, capacity=self._sample_count(dd) + 9)
+        if self._nodes_have_limits:
+            gen.apply_node_limits(res, constraints, node_max_velocity=k["maxv"][None], node_stop=k["stop"][None],
+                                  node_max_acceleration=k["maxa"][None], action_points=[self._aps] if self.M else None,
+                                  start_vel=start_vel, end_vel=end_vel)
+        return res
+
+    def forward_backward(self, constraints, dd, start_vel, end_vel, want=("velocity",)):
+        if tuple(want) == ("velocity",) and self._default_tables():
+            res = self._try_batched(lambda gen: self._batched_distance_domain(gen, constraints, dd, start_vel, end_vel,
+                                                                                ("curvature", "velocity")))
+            if res is not None and int(res["flags"][0].item()) == 0:
+                N = int(res["meta"][0, 3].item())
+                return {"velocity": res["velocity"][0, :N].cpu().numpy()}, N
+        N = self._sample_count(dd)
+        n = C.c_int()
         dp = C.POINTER(C.c_double)
         names = ("t", "x", "y", "heading", "curvature", "velocity")
         bufs = {k: (np.empty(N) if k in want else None) for k in names}
@@ -293,6 +391,10 @@ class DeviceRoute:
         return {k: v for k, v in bufs.items() if v is not None}, N
 
     def motion_profile(self, constraints, dt, dd):
+        if self._default_tables():
+            got = self._batched_motion_profile(constraints, dt, dd)
+            if got is not None:
+                return got
         c = _lib.make_constraints(constraints)
         cap = int(self.total / 0.0005) + 4096
         dp, lp = C.POINTER(C.c_double), C.POINTER(C.c_long)

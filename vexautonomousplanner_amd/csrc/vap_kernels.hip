@@ -1021,39 +1021,60 @@ __global__ __launch_bounds__(64) void k_velocity_seq(int B, int S, VelConsts<R> 
             dup |= fast_gq(fast_gg(fc, DT[i]), kabs * kabs) < (R)0;
         }
     }
+    // Both sweeps read the rows of step i + 1 while step i is computed (a lane waits a memory round trip per step
+    // otherwise: the chain of a step is a few hundred cycles, a load from L2 about as long again).
     // forward, MPG:188-249
     R u = start_u, wprev = (R)0;   // FAST: wprev carries the previous squared velocity instead
     V[0] = u;
+    auto load_fwd = [&](int j, R &k, R &dt, R &cap, R &a) {      // what forward step j reads
+        k = K[j];
+        dt = DT[j];
+        cap = vcap ? (R)vcap[row + j + 1] : (R)0;
+        a = acc.fwd ? (R)acc.fwd[row + j] : c.amax;
+    };
+    R k1 = (R)0, d1 = (R)0, c1 = (R)0, a1 = c.amax, kprev = (R)0;
+    if (N > 1) load_fwd(0, k1, d1, c1, a1);
     for (int i = 0; i < N - 1; i++) {
-        const R un = (i + 1 == N - 1) ? end_u : (vcap ? (R)vcap[row + i + 1] * (R)vcap[row + i + 1] : vmax2);
-        // MPG:194-196: max_acc = max_dec = the value in force from the last boundary at or before sample i
-        const R cur = acc.fwd ? (R)acc.fwd[row + i] : c.amax;
+        const R k0 = k1, d0 = d1, c0 = c1, cur = a1;
+        load_fwd(i + 1 < N - 1 ? i + 1 : i, k1, d1, c1, a1);
+        const R un = (i + 1 == N - 1) ? end_u : (vcap ? c0 * c0 : vmax2);
+        // MPG:194-196: max_acc = max_dec = the value in force from the last boundary at or before sample i (`cur`)
         if constexpr (FAST) {
             R rho, gq, A, cap;
             const R amaxp = acc.fwd ? twodd * cur : fc.amaxp;
-            fast_derive(fc, (R)fabs(K[i]), i > 0 ? (R)fabs(K[i - 1]) : (R)0, DT[i], amaxp, rho, gq, A, cap);
-            if (acc.fwd) A = fast_cap_A(fc, (R)fabs(K[i]), A);
+            fast_derive(fc, (R)fabs(k0), i > 0 ? (R)fabs(kprev) : (R)0, d0, amaxp, rho, gq, A, cap);
+            if (acc.fwd) A = fast_cap_A(fc, (R)fabs(k0), A);
             R am, g;
             fast_scale(amaxp, gq, A, am, g);
             u = fast_forward_a(am, rho, g, A, cap, u, wprev, un);
         } else {
-            const SampleLimits<R> L = sample_limits(c, (R)fabs(K[i]), cur, acc.fwd ? cur : c.adec);
-            u = forward_step(c, L, cur, twodd, u, wprev, DT[i], un);
+            const SampleLimits<R> L = sample_limits(c, (R)fabs(k0), cur, acc.fwd ? cur : c.adec);
+            u = forward_step(c, L, cur, twodd, u, wprev, d0, un);
         }
+        kprev = k0;
         V[i + 1] = u;
     }
     // backward, MPG:251-311
     u = end_u;
     wprev = (R)0;
+    // MPG:256-257: max_acc as the backward sweep finds it at sample i; max_dec is what the forward sweep left
+    const R cur_dec = acc.dec ? (R)acc.dec[b] : c.adec;
+    auto load_bwd = [&](int j, R &k, R &dt, R &vf, R &a) {      // what backward step j (>= 1) reads
+        k = K[j];
+        dt = DT[j - 1];
+        vf = V[j - 1];
+        a = acc.bwd ? (R)acc.bwd[row + j] : c.amax;
+    };
+    R v1 = (R)0, knext = (R)0;
+    if (N > 1) load_bwd(N - 1, k1, d1, v1, a1);
     for (int i = N - 1; i > 0; i--) {
         R up;
-        // MPG:256-257: max_acc as the backward sweep finds it at sample i; max_dec is what the forward sweep left
-        const R cur_acc = acc.bwd ? (R)acc.bwd[row + i] : c.amax;
-        const R cur_dec = acc.dec ? (R)acc.dec[b] : c.adec;
+        const R k0 = k1, d0 = d1, vf = v1, cur_acc = a1;
+        load_bwd(i - 1 > 0 ? i - 1 : i, k1, d1, v1, a1);
         if constexpr (FAST) {
             R rho, gq, A, cap;
-            const R kabs = (R)fabs(K[i]);
-            fast_derive(fc, kabs, i + 1 <= N - 1 ? (R)fabs(K[i + 1]) : (R)0, DT[i - 1], acc.bwd ? twodd * cur_dec : fc.adecp, rho, gq, A, cap);
+            const R kabs = (R)fabs(k0);
+            fast_derive(fc, kabs, i + 1 <= N - 1 ? (R)fabs(knext) : (R)0, d0, acc.bwd ? twodd * cur_dec : fc.adecp, rho, gq, A, cap);
             if (acc.bwd) A = fast_cap_A(fc, kabs, A);
             // a straight sample is limited by max_dec alone (MPG:270-272), and so is a sample with a zero heading
             // difference whose angular velocity does not rise (the wheel limit is then +inf, MPG:52-59)
@@ -1061,12 +1082,13 @@ __global__ __launch_bounds__(64) void k_velocity_seq(int B, int S, VelConsts<R> 
             const R amaxp = acc.bwd ? ((kabs < (R)1e-6 || gq < (R)0) ? A : twodd * cur_acc) : fc.amaxp;
             R am, g;
             fast_scale(amaxp, gq, A, am, g);
-            up = dup ? fast_backward_a<true>(am, rho, g, A, cap, u, wprev, V[i - 1])
-                     : fast_backward_a<false>(am, rho, g, A, cap, u, wprev, V[i - 1]);
+            up = dup ? fast_backward_a<true>(am, rho, g, A, cap, u, wprev, vf)
+                     : fast_backward_a<false>(am, rho, g, A, cap, u, wprev, vf);
         } else {
-            const SampleLimits<R> L = sample_limits(c, (R)fabs(K[i]), cur_acc, cur_dec);
-            up = backward_step(c, L, cur_acc, twodd, u, wprev, DT[i - 1], V[i - 1]);
+            const SampleLimits<R> L = sample_limits(c, (R)fabs(k0), cur_acc, cur_dec);
+            up = backward_step(c, L, cur_acc, twodd, u, wprev, d0, vf);
         }
+        knext = k0;
         // (R != IO: V[i] — the scratch row, the forward value of sample i — is dead from here on and receives the
         // velocity in the arithmetic type: the fp64 row the time-domain resample integrates behind fp32 rows)
         const R vv = vel_sqrt(u);
