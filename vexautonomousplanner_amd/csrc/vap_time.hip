@@ -243,7 +243,7 @@ __global__ __launch_bounds__(64) void k_time_integrate_quad(int B, int S, const 
     const double *m = meta + (size_t)b * kMetaStride;
     const double total = m[1], dd = m[2], inv_dd = 1.0 / dd;
     const int N = (int)m[3];
-    const uint32_t row0 = (uint32_t)b * (uint32_t)S;        // (the launcher keeps B * S under 2^30)
+    const uint32_t row0 = (uint32_t)b * (uint32_t)S;        // (the launcher keeps B * S * sizeof(R) under 2^32)
     auto at = [&](int i) {
         const uint32_t o = row0 + (uint32_t)i;
         if constexpr (RES) return (double)vel[o] + (double)vres[o];
@@ -479,7 +479,8 @@ hipError_t launch_time_profile(hipStream_t st, bool f64, int B, int W, int S, co
     const int nblk = (B + 63) / 64;
     // four lanes per path while that still leaves at most one wavefront per SIMD (k_time_integrate_quad)
     // (time_kernel: VAP_OPT_TIME_KERNEL — 0 by batch size, 1 lane per path, 2 four lanes per path wherever the row offsets fit)
-    const bool quad = (size_t)B * (size_t)S < ((size_t)1 << 30) && (time_kernel == 2 || (time_kernel == 0 && B <= 16384));
+    // (the quad kernel addresses the velocity rows by 32-bit BYTE offsets from their bases)
+    const bool quad = (size_t)B * (size_t)S * (f64 ? 8 : 4) < ((size_t)1 << 32) && (time_kernel == 2 || (time_kernel == 0 && B <= 16384));
     const int nq = (B + 15) / 16;
     if (quad && f64)
         hipLaunchKernelGGL((k_time_integrate_quad<double, false>), dim3(nq), dim3(64), 0, st, B, S, meta, (const double *)vel,
