@@ -258,21 +258,21 @@ __global__ __launch_bounds__(64) void k_time_integrate_quad(int B, int S, const 
         double rdt = __builtin_amdgcn_rcp(dt);
         rdt = fma(fma(-dt, rdt, 1.0), rdt, rdt);
         rdt = fma(fma(-dt, rdt, 1.0), rdt, rdt);
-        const double n1 = (double)(N - 1);
         double sa = 0, sb = 0;          // this lane's piece of the row of the step before
         uint32_t touch0 = 0, touch1 = 0;   // where the touches land: live across the loop, since they arrive a step later
-        while (total > 0 && N > 1 && current_pos < total) {   // MPG:523
-            if (T >= cap) { full = true; break; }
+        const bool walk = total > 0 && N > 1;        // (`total > 0` also keeps degenerate paths — NaN / zero length — out)
+        bool bail = false;
+        while (walk & (current_pos < total) & (T < cap)) {   // MPG:523, and the row capacity
             const double x = hi ? current_pos + dd : current_pos;
-            double e = floor(x * inv_dd);
-            e = !(e >= -1.0) ? -1.0 : e;
-            e = e > n1 ? n1 : e;
-            int g = (int)e;
+            // a first guess of the grid index by truncation (the conversion saturates, NaN gives 0); the step up / step
+            // down below and the `ok` test decide — the i with i*dd <= x < (i+1)*dd is unique, whatever the guess was
+            int g = (int)(x * inv_dd);
+            g = g < -1 ? -1 : (g > N - 1 ? N - 1 : g);
             g += ((g + 1 < N) & ((double)(g + 1) * dd <= x)) ? 1 : 0;
             g -= ((g >= 0) & !((double)g * dd <= x)) ? 1 : 0;
             const double x0 = (double)g * dd, x1 = (double)(g + 1) * dd;
             const int ok = (((g + 1 >= N) | !(x1 <= x)) & ((g < 0) | (x0 <= x))) ? 1 : 0;
-            if (__builtin_expect(!(ok & __builtin_amdgcn_mov_dpp(ok, kQuad2301, 0xF, 0xF, true)), 0)) break;   // (state untouched)
+            if (__builtin_expect(!(ok & __builtin_amdgcn_mov_dpp(ok, kQuad2301, 0xF, 0xF, true)), 0)) { bail = true; break; }   // (state untouched)
             // The step's memory operations, by hand (quad_step_memory): this lane's sample (row and residual), THEN the row
             // of the step before, THEN a touch of the velocity rows kPrefetchBytes further on — and a wait that leaves
             // the store and the touches in flight.  A step moves up to ~20 samples, each of a wavefront's 16 paths
@@ -303,6 +303,7 @@ __global__ __launch_bounds__(64) void k_time_integrate_quad(int B, int S, const 
             T += 1;
             current_time += dt;
         }
+        full = !bail & walk & (current_pos < total) & (T >= cap);
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(touch0), "+v"(touch1) : : "memory");   // (the last touches have landed)
         if (T > 0) *reinterpret_cast<double2 *>(q) = make_double2(sa, sb);
         q += T > 0 ? kRowWidth : 0;           // row T again
