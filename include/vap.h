@@ -127,8 +127,11 @@ enum { VAP_RECURRENCE_F64 = 0, VAP_RECURRENCE_F32 = 1 };
 /* VAP_OPT_TIME_KERNEL: the kinematic recurrence of vap_time_profile[_routes] (MPG:566-584).  LANE walks a path with one
  * lane; QUAD with four (one grid index, one velocity sample and one interpolation per lane instead of two, four and two,
  * the 64-byte row stored as four 16-byte pieces) — the same rows bit for bit, a shorter step.  AUTO (default) takes
- * QUAD while four lanes per path still leave at most one wavefront per SIMD (B <= 16384) and LANE above that. */
-enum { VAP_TIME_KERNEL_AUTO = 0, VAP_TIME_KERNEL_LANE = 1, VAP_TIME_KERNEL_QUAD = 2 };
+ * QUAD while four lanes per path still leave at most one wavefront per SIMD (B <= 16384) and LANE above that.
+ * FUSED: QUAD's recurrence and the geometry of the rows behind it in one workgroup of 16 plain paths (the geometry runs in
+ * the shadow of the recurrence); AUTO takes it while that is at most one workgroup per CU (B <= 16 x CUs), and batches of
+ * routes (vap_time_profile_routes) never do. */
+enum { VAP_TIME_KERNEL_AUTO = 0, VAP_TIME_KERNEL_LANE = 1, VAP_TIME_KERNEL_QUAD = 2, VAP_TIME_KERNEL_FUSED = 3 };
 int vap_ctx_set_option(vap_ctx *ctx, int option, int value);
 /* Enable/disable per-stage hipEvent timing (replaces the reference's time.time() log lines,
  * SM:587-594, MPG:398-411).  Off by default. */

@@ -981,8 +981,9 @@ def test_time_profile_integrates_the_row_as_the_caller_left_it(torch_mod, B):
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype,resid", [("f32", True), ("f32", False), ("f64", False)])
 def test_time_profile_quad_kernel_is_bit_identical(torch_mod, dtype, resid):
-    """VAP_OPT_TIME_KERNEL: four lanes per path (what AUTO takes up to 16384 paths) and one lane per path walk the same
-    recurrence (MPG:566-584) — same counts, maps and row bits, for batch sizes that leave quads and wavefronts partly
+    """VAP_OPT_TIME_KERNEL: four lanes per path (what AUTO takes up to 16384 paths), the same with the geometry in the
+    workgroup (FUSED: AUTO's choice up to 16 paths per CU) and one lane per path walk the same recurrence (MPG:566-584) and
+    fill the same geometry columns — same counts, maps and row bits, for batch sizes that leave quads and wavefronts partly
     empty, a capacity that truncates, and a batch above AUTO's switch."""
     from vexautonomousplanner_amd.batch import BatchedTrajectoryGenerator
     from vexautonomousplanner_amd.synth import DEFAULT_CONSTRAINTS, make_waypoints
@@ -993,7 +994,7 @@ def test_time_profile_quad_kernel_is_bit_identical(torch_mod, dtype, resid):
         wp = torch.tensor(make_waypoints(B, W, 77 + B), device="cuda:0", dtype=td)
         res = gen.profile(wp, DEFAULT_CONSTRAINTS, samples=S)
         got = {}
-        for k in ("lane", "quad", "auto"):
+        for k in ("lane", "quad", "fused", "auto"):
             gen.set_time_kernel(k)
             got[k] = {n: v.clone() for n, v in gen.time_profile(res, DEFAULT_CONSTRAINTS, capacity_rows=cap).items()}
         torch.cuda.synchronize()
@@ -1001,7 +1002,7 @@ def test_time_profile_quad_kernel_is_bit_identical(torch_mod, dtype, resid):
         assert counts[:, 0].min() >= 60
         if cap == 60:
             assert (counts[:, 0] == 60).all()
-        for k in ("quad", "auto"):
+        for k in ("quad", "fused", "auto"):
             assert torch.equal(got[k]["counts"], got["lane"]["counts"]), (B, k)
             rows_a, rows_b = got["lane"]["rows"].cpu().numpy(), got[k]["rows"].cpu().numpy()
             nm_a, nm_b = got["lane"]["nodes_map"].cpu().numpy(), got[k]["nodes_map"].cpu().numpy()

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Developer tool (GPU box): k_time_integrate_quad (four lanes per path, VAP_TIME_KERNEL_QUAD) against the lane-per-path
+"""Developer tool (GPU box): k_time_integrate_quad (four lanes per path, VAP_TIME_KERNEL_QUAD) and k_time_fused (the same with the geometry in
+the workgroup, VAP_TIME_KERNEL_FUSED) against the lane-per-path
 kernel (VAP_TIME_KERNEL_LANE) — random batches through both; rows, counts and maps must be the same bits; then the
 config-3 timing of each.
   python tools/ab_time_quad.py [cases]"""
@@ -44,17 +45,17 @@ for dtype, resid in (("f32", True), ("f32", False), ("f64", False)):
         res = gen.profile(wp, cons, dd=dd, capacity=int(64 / dd))
         cap = 300 if case % 8 == 0 else 8192     # (300: truncated paths)
         out = {}
-        for k in ("lane", "quad"):
+        for k in ("lane", "quad", "fused"):
             gen.set_time_kernel(k)
             out[k] = gen.time_profile(res, cons, dt=dt, capacity_rows=cap)
         n += 1
-        if not same(out["lane"], out["quad"]):
+        if not (same(out["lane"], out["quad"]) and same(out["lane"], out["fused"])):
             bad += 1
             print("DIFFER", dtype, resid, case, B, W, dt, dd, flush=True)
     wp = torch.tensor(make_waypoints(4096, 32, 3), device="cuda:0", dtype=td)
     res = gen.profile(wp, DEFAULT_CONSTRAINTS, samples=10000)
     out = {}
-    for k in ("lane", "quad", "lane", "quad"):
+    for k in ("lane", "quad", "fused", "lane", "quad", "fused"):
         gen.set_time_kernel(k)
         tp = gen.time_profile(res, DEFAULT_CONSTRAINTS, capacity_rows=2048)
         torch.cuda.synchronize()
@@ -67,7 +68,7 @@ for dtype, resid in (("f32", True), ("f32", False), ("f64", False)):
         out[k] = tp
         print(f"config 3 {dtype} residual={resid} {k}: {ev[0].elapsed_time(ev[1]) / 5:.3f} ms", flush=True)
     n += 1
-    if not same(out["lane"], out["quad"]):
+    if not (same(out["lane"], out["quad"]) and same(out["lane"], out["fused"])):
         bad += 1
         print("DIFFER config 3", dtype, resid, flush=True)
 print(f"{n} batches, {bad} differ")

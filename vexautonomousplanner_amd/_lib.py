@@ -28,7 +28,7 @@ OPT_VELOCITY_KERNEL = 0
 OPT_TIME_DOMAIN_RESIDUAL = 3
 OPT_F32_RECURRENCE = 1
 OPT_TIME_KERNEL = 4
-TIME_KERNEL_AUTO, TIME_KERNEL_LANE, TIME_KERNEL_QUAD = 0, 1, 2
+TIME_KERNEL_AUTO, TIME_KERNEL_LANE, TIME_KERNEL_QUAD, TIME_KERNEL_FUSED = 0, 1, 2, 3
 RECURRENCE_F64, RECURRENCE_F32 = 0, 1
 VELOCITY_AUTO, VELOCITY_SEQ_LITERAL, VELOCITY_SEQ_FAST, VELOCITY_RELAX = 0, 1, 2, 3
 VELOCITY_RELAX_BLOCK, VELOCITY_RELAX_WAVE = 4, 5

@@ -61,9 +61,10 @@ class BatchedTrajectoryGenerator:
                             _lib.RECURRENCE_F64 if self.recurrence == "f64" else _lib.RECURRENCE_F32)
 
     def set_time_kernel(self, which):
-        """"auto" | "lane" | "quad" (VAP_OPT_TIME_KERNEL): lanes per path in the time domain's kinematic recurrence."""
+        """"auto" | "lane" | "quad" | "fused" (VAP_OPT_TIME_KERNEL): lanes per path in the time domain's kinematic
+        recurrence; "fused": the quad recurrence with the geometry in the same workgroup."""
         self.ctx.set_option(_lib.OPT_TIME_KERNEL, {"auto": _lib.TIME_KERNEL_AUTO, "lane": _lib.TIME_KERNEL_LANE,
-                                                   "quad": _lib.TIME_KERNEL_QUAD}[which])
+                                                   "quad": _lib.TIME_KERNEL_QUAD, "fused": _lib.TIME_KERNEL_FUSED}[which])
 
     def set_velocity_kernel(self, which):
         """"auto" | "seq_literal" | "seq_fast" | "relax" | "relax_block" | "relax_wave" | "lanes" | "lanes16" | "lanes32" |

@@ -291,7 +291,7 @@ int vap_ctx_set_option(vap_ctx *ctx, int option, int value)
         ctx->vres_for = nullptr;
         return VAP_OK;
     }
-    if (option == VAP_OPT_TIME_KERNEL && value >= VAP_TIME_KERNEL_AUTO && value <= VAP_TIME_KERNEL_QUAD) {
+    if (option == VAP_OPT_TIME_KERNEL && value >= VAP_TIME_KERNEL_AUTO && value <= VAP_TIME_KERNEL_FUSED) {
         ctx->time_kernel = value;
         return VAP_OK;
     }

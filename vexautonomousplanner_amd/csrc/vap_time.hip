@@ -14,6 +14,7 @@
 //                      sign / wrap of MPG:559-563, angular velocity (MPG:575), and the ordered list
 //                      of node crossings (nodes_map, MPG:420, 527-529).
 // All arithmetic is fp64 in the reference's order; only the velocity row is read in the batch dtype.
+#include <mutex>
 #include "vap_device.h"
 #include "vap_kernels.h"
 
@@ -230,16 +231,15 @@ __device__ __forceinline__ double quad_step_memory(const R *__restrict__ vel, co
 // k_time_geometry overwrites — heading, x, y — are scratch until then).  Sixteen paths per wavefront: 256 workgroups
 // at config 3, each on its own CU, and a wavefront's loads touch 16 rows instead of 64.  Bit-identical to the
 // lane-per-path kernel (tools/fuzz_time_profile.py runs both).
-template <typename R, bool RES>
-__global__ __launch_bounds__(64) void k_time_integrate_quad(int B, int S, const double *__restrict__ meta,
-                                                            const R *__restrict__ vel, const float *__restrict__ vres,
-                                                            double max_acc, double max_dec, double dt, int cap,
-                                                            double *__restrict__ rows, int *__restrict__ counts,
-                                                            uint32_t *__restrict__ flags)
+// PUBLISH (the fused kernel below): the quad tells the workgroup's geometry wavefronts, through two LDS words of its
+// path, how many of its rows are complete in memory (`done`) and, at the end, the row count (`fin`, -1 until then).
+template <typename R, bool RES, bool PUBLISH>
+__device__ __forceinline__ void quad_integrate_path(int b, int r, int S, const double *__restrict__ meta,
+                                                    const R *__restrict__ vel, const float *__restrict__ vres,
+                                                    double max_acc, double max_dec, double dt, int cap,
+                                                    double *__restrict__ rows, int *__restrict__ counts,
+                                                    uint32_t *__restrict__ flags, int *done, int *fin)
 {
-    const int r = threadIdx.x & 3;
-    const int b = blockIdx.x * 16 + (threadIdx.x >> 2);
-    if (b >= B) return;                        // (whole quads)
     const double *m = meta + (size_t)b * kMetaStride;
     const double total = m[1], dd = m[2], inv_dd = 1.0 / dd;
     const int N = (int)m[3];
@@ -252,6 +252,9 @@ __global__ __launch_bounds__(64) void k_time_integrate_quad(int B, int S, const 
     const bool odd = (r & 1) != 0, hi = (r & 2) != 0;
     double *q = rows + (size_t)b * cap * kRowWidth + 2 * r;   // this lane's 16 bytes of the row
     double current_time = 0, current_pos = 0, current_vel = N > 0 ? at(0) : 0.0;   // MPG:413-418
+    // (the first velocity is waited for HERE: left to the compiler, its wait can land at the first use inside the loop,
+    // where it would also wait, every step, for the store and the touches the loop means to leave in flight)
+    asm volatile("" : "+v"(current_vel));
     int T = 0;
     bool full = false;
     {
@@ -282,6 +285,9 @@ __global__ __launch_bounds__(64) void k_time_integrate_quad(int B, int S, const 
             const uint32_t o = (row0 + (uint32_t)clamp_index(gi, N)) * (uint32_t)sizeof(R);
             const uint32_t o_next = (row0 + (uint32_t)min(gi + kPrefetchBytes / (int)sizeof(R), N - 1)) * (uint32_t)sizeof(R);
             const double y = quad_step_memory<R, RES>(vel, vres, o, o_next, q, sa, sb, touch0, touch1);
+            // (the wait inside leaves this step's store and touches in flight: the rows before the one just stored — rows
+            // 0 .. T - 2 — are complete)
+            if constexpr (PUBLISH) *done = T > 1 ? T - 1 : 0;
             const double xm = odd ? x1 : x0;
             const double yn = quad_perm_f64<kQuad1133>(y), xn = quad_perm_f64<kQuad1133>(xm);   // even lanes: the odd neighbour's
             // MPG:349-386 lerp on the even lanes (the odd lanes' quotient is 0/0 and goes nowhere)
@@ -340,6 +346,24 @@ __global__ __launch_bounds__(64) void k_time_integrate_quad(int B, int S, const 
         counts[2 * b] = T;
         if (full && flags) atomicOr(&flags[b], VAP_FLAG_TRUNCATED_BIT);
     }
+    if constexpr (PUBLISH) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every row of the path is in memory
+        *done = T;
+        *fin = T;
+    }
+}
+
+template <typename R, bool RES>
+__global__ __launch_bounds__(64) void k_time_integrate_quad(int B, int S, const double *__restrict__ meta,
+                                                            const R *__restrict__ vel, const float *__restrict__ vres,
+                                                            double max_acc, double max_dec, double dt, int cap,
+                                                            double *__restrict__ rows, int *__restrict__ counts,
+                                                            uint32_t *__restrict__ flags)
+{
+    const int r = threadIdx.x & 3;
+    const int b = blockIdx.x * 16 + (threadIdx.x >> 2);
+    if (b >= B) return;                        // (whole quads)
+    quad_integrate_path<R, RES, false>(b, r, S, meta, vel, vres, max_acc, max_dec, dt, cap, rows, counts, flags, nullptr, nullptr);
 }
 
 // point / derivative / second derivative on ONE segment at its local parameter (the sum of QHS:221-251 / 473-504)
@@ -472,6 +496,165 @@ __global__ __launch_bounds__(256) void k_time_geometry(int W, int cap, const dou
     if (tid == 0) counts[2 * b + 1] = s_base < W ? s_base : W;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The recurrence and the geometry of 16 plain paths in ONE workgroup (VAP_TIME_KERNEL_FUSED): wavefront 0 walks the
+// recurrence exactly as k_time_integrate_quad does — it never waits for anybody — and six more wavefronts, two on each
+// of the other SIMDs, do k_time_geometry's work on the rows behind it, 64 rows of one path at a time, as soon as the recurrence
+// says they are complete in memory (two LDS words per path: rows done, final count).  The geometry of a batch, a fifth
+// of the two-kernel time, then runs in the shadow of the recurrence's dependent chain instead of after it.
+//   LDS: the 16 distance tables (128 KB: a binary search per row) + per-path bookkeeping; one workgroup per CU, so the
+//        launcher takes this kernel for batches of at most 16 paths per CU (config 3 exactly).  Segments stay in global
+//        memory (consecutive rows evaluate the same segment: L1).
+//   Rows are read back by the geometry wavefronts with device-scope loads (the recurrence's stores are in L2 when it
+//   reports them; the CU's L1 may hold a neighbouring row's stale line).  A geometry wavefront that finds nothing to do
+//   sleeps; a bounded count of sleeps (seconds) ends it with VAP_FLAG_NOCONVERGE instead of a hang.
+// Same bits as the two kernels (tools/ab_time_quad.py, test_time_profile_quad_kernel_is_bit_identical).
+// ------------------------------------------------------------------------------------------------
+constexpr int kFusedPaths = 16, kFusedThreads = 512, kFusedConsumers = 6;
+constexpr size_t kFusedLds = sizeof(double) * kFusedPaths * kLutN;
+
+__device__ __forceinline__ double load_row_f64(const double *p)
+{
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+                                                              __HIP_MEMORY_SCOPE_AGENT));
+}
+
+template <typename R, bool RES>
+__global__ __launch_bounds__(kFusedThreads) void k_time_fused(int B, int W, int S, const double *__restrict__ segments,
+                                                    const double *__restrict__ lut, const double *__restrict__ meta,
+                                                    const R *__restrict__ vel, const float *__restrict__ vres, double max_acc,
+                                                    double max_dec, double dt, int cap, double *__restrict__ rows,
+                                                    int *__restrict__ counts, int *__restrict__ nodes_map,
+                                                    uint32_t *__restrict__ flags)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_tab[];      // [16][kLutN]
+    __shared__ int s_done[kFusedPaths], s_fin[kFusedPaths], s_cur[kFusedPaths], s_nbase[kFusedPaths];
+    __shared__ double s_tc[kFusedPaths];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int b_first = blockIdx.x * kFusedPaths;
+    if (tid < kFusedPaths) {
+        s_done[tid] = 0;
+        s_fin[tid] = b_first + tid < B ? -1 : 0;      // (paths past the batch: nothing to do)
+        s_cur[tid] = b_first + tid < B ? 0 : -1;      // -1: closed
+        s_nbase[tid] = 1;
+        s_tc[tid] = 0.0;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int r = lane & 3, p = lane >> 2, b = b_first + p;
+        if (b >= B) return;
+        __builtin_amdgcn_s_setprio(3);
+        quad_integrate_path<R, RES, true>(b, r, S, meta, vel, vres, max_acc, max_dec, dt, cap, rows, counts, flags, &s_done[p],
+                                          &s_fin[p]);
+        return;
+    }
+    // ---- geometry wavefronts: two on each of the SIMDs the recurrence is not on (a workgroup's wavefronts go round the four
+    // SIMDs: wavefront 4 would share the recurrence's and leaves); consumer ci owns paths ci, ci + 6, ci + 12
+    if (wave == 4) return;
+    const int ci = wave < 4 ? wave - 1 : wave - 2;
+    const int G = W - 1;
+    const double end_param = (double)(W - 1);
+    const int tab_n = W * kSamplesPerNode;
+    for (int p = ci; p < kFusedPaths; p += kFusedConsumers) {
+        const int b = b_first + p;
+        if (b >= B) continue;
+        const double *src = lut + (size_t)b * kLutN;
+        for (int i = lane; i < kLutN; i += 64) s_tab[p * kLutN + i] = src[i];
+        if (lane == 0) nodes_map[(size_t)b * W] = 0;   // MPG:420: the first node maps to row 0
+    }
+    volatile int *v_done = s_done, *v_fin = s_fin, *v_cur = s_cur, *v_nbase = s_nbase;
+    volatile double *v_tc = s_tc;
+    int idle = 0;
+    for (;;) {
+        bool open = false, did = false;
+        for (int p = ci; p < kFusedPaths; p += kFusedConsumers) {
+            const int c = __builtin_amdgcn_readfirstlane(v_cur[p]);
+            if (c < 0) continue;
+            open = true;
+            const int fin = __builtin_amdgcn_readfirstlane(v_fin[p]);
+            const int lim = fin >= 0 ? fin : __builtin_amdgcn_readfirstlane(v_done[p]);
+            int n = lim - c;
+            const int b = b_first + p;
+            if (n >= 64 || (fin >= 0 && n > 0)) {
+                n = n < 64 ? n : 64;
+                did = true;
+                // ---- rows [c, c + n) of path b: k_time_geometry's body for one wavefront
+                const double *m = meta + (size_t)b * kMetaStride;
+                const double t_max = m[0], total = m[1];
+                const double *seg = segments + (size_t)b * G * 12;
+                const double *sD = s_tab + p * kLutN;
+                double *out = rows + (size_t)b * cap * kRowWidth;
+                const int i = c + lane;
+                const bool live = lane < n;
+                double t = 0.0;
+                if (live) {
+                    const double pos = i == 0 ? 0.0 : load_row_f64(out + (size_t)(i - 1) * kRowWidth + 1);
+                    t = distance_to_time(sD, total, t_max, end_param, pos);                        // MPG:525
+                }
+                double prev_t = __shfl_up(t, 1);
+                if (lane == 0) prev_t = v_tc[p];
+                if (i == 0) prev_t = 0.0;                                                          // MPG:521
+                const bool crossing = live && mod1(t) < mod1(prev_t) && t < end_param;            // MPG:527
+                const unsigned long long bal = __ballot(crossing);
+                const int base = __builtin_amdgcn_readfirstlane(v_nbase[p]);
+                const int k_self = base + __popcll(bal & ((1ull << lane) - 1ull));
+                if (crossing && k_self < W) nodes_map[(size_t)b * W + k_self] = i;                 // MPG:528-529
+                if (live) {
+                    double *q = out + (size_t)i * kRowWidth;
+                    const int jj = table_index(t, tab_n, end_param);                               // SM:332-346, 550-580
+                    const double tp = linspace_at(end_param, tab_n, jj);
+                    double d1x, d1y, d2x, d2y, px, py;
+                    hermite_eval_ref(seg, t_max, G, 1, tp, d1x, d1y);
+                    hermite_eval_ref(seg, t_max, G, 2, tp, d2x, d2y);
+                    const double ss = d1x * d1x + d1y * d1y;
+                    const double num = d1x * d2y - d1y * d2x;
+                    const double curvature = (ss >= 1e-10) ? num / (ss * sqrt(ss)) : 0.0;         // SM:517-527
+                    double heading = atan2(d1y, d1x);                                              // SM:536
+                    heading = py_mod(heading + M_PI, 2 * M_PI) - M_PI;                             // MPG:559-563
+                    heading *= -1;
+                    hermite_eval_ref(seg, t_max, G, 0, t, px, py);                                 // MPG:565
+                    const double target_vel = load_row_f64(q + 5);
+                    *reinterpret_cast<double2 *>(q + 4) = make_double2(heading, target_vel * curvature * -1);   // MPG:575
+                    *reinterpret_cast<double2 *>(q + 6) = make_double2(px, py);
+                }
+                // (this wavefront alone reads and writes its paths' bookkeeping; every lane writes the same values)
+                v_tc[p] = __shfl(t, n - 1);
+                v_nbase[p] = base + __popcll(bal);
+                v_cur[p] = c + n;
+            }
+            if (fin >= 0 && __builtin_amdgcn_readfirstlane(v_cur[p]) >= fin) {          // the path is through: close it
+                const int nb = __builtin_amdgcn_readfirstlane(v_nbase[p]);
+                if (lane == 0) counts[2 * b + 1] = nb < W ? nb : W;
+                v_cur[p] = -1;
+            }
+        }
+        if (!open) break;
+        if (did) { idle = 0; continue; }
+        __builtin_amdgcn_s_sleep(32);
+        if (++idle > (1 << 24)) {                        // (seconds: a recurrence that never reports)
+            if (lane == 0 && flags)
+                for (int p = ci; p < kFusedPaths; p += kFusedConsumers)
+                    if (v_cur[p] >= 0 && b_first + p < B) atomicOr(&flags[b_first + p], VAP_FLAG_NOCONVERGE_BIT);
+            break;
+        }
+    }
+}
+
+// CUs of the current device (one k_time_fused workgroup each)
+static int fused_workgroups()
+{
+    static int n[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev = dev < 0 || dev >= 64 ? 0 : dev;
+    if (n[dev] == 0) {
+        int cu = 0;
+        if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) cu = 1;
+        n[dev] = cu;
+    }
+    return n[dev];
+}
+
 hipError_t launch_time_profile(hipStream_t st, bool f64, int B, int W, int S, const double *segments, const double *lut,
                                const double *meta, const void *vel, double max_acc, double max_dec, double dt, int cap,
                                double *rows, int *counts, int *nodes_map, uint32_t *flags, RouteTables rt, const int *node_reverse,
@@ -481,8 +664,33 @@ hipError_t launch_time_profile(hipStream_t st, bool f64, int B, int W, int S, co
     // four lanes per path while that still leaves at most one wavefront per SIMD (k_time_integrate_quad)
     // (time_kernel: VAP_OPT_TIME_KERNEL — 0 by batch size, 1 lane per path, 2 four lanes per path wherever the row offsets fit)
     // (the quad kernel addresses the velocity rows by 32-bit BYTE offsets from their bases)
-    const bool quad = (size_t)B * (size_t)S * (f64 ? 8 : 4) < ((size_t)1 << 32) && (time_kernel == 2 || (time_kernel == 0 && B <= 16384));
+    const bool fits32 = (size_t)B * (size_t)S * (f64 ? 8 : 4) < ((size_t)1 << 32);
+    const bool quad = fits32 && (time_kernel == 2 || (time_kernel == 0 && B <= 16384));
     const int nq = (B + 15) / 16;
+    // recurrence and geometry in one workgroup (k_time_fused): plain paths, and at most one workgroup of 16 paths per CU
+    // (VAP_TIME_KERNEL_FUSED = 3 asks for it at any size; routes and reversed rows stay on the two kernels)
+    if (fits32 && !rt.sptab && !node_reverse && (time_kernel == 3 || (time_kernel == 0 && nq <= fused_workgroups()))) {
+        hipError_t e = hipSuccess;
+#define VAP_FUSED(R_, RES_, VEL_, VRES_)                                                                                        \
+        do {                                                                                                                    \
+            auto kern = k_time_fused<R_, RES_>;                                                                                 \
+            static std::once_flag once[64];                                                                                     \
+            int dev = 0;                                                                                                        \
+            (void)hipGetDevice(&dev);                                                                                           \
+            std::call_once(once[dev < 0 || dev >= 64 ? 0 : dev], [&] {                                                          \
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds); \
+            });                                                                                                                 \
+            if (e == hipSuccess)                                                                                                \
+                hipLaunchKernelGGL(kern, dim3(nq), dim3(kFusedThreads), kFusedLds, st, B, W, S, segments, lut, meta, VEL_, VRES_, max_acc, \
+                                   max_dec, dt, cap, rows, counts, nodes_map, flags);                                           \
+        } while (0)
+        if (f64) VAP_FUSED(double, false, (const double *)vel, (const float *)nullptr);
+        else if (vres) VAP_FUSED(float, true, (const float *)vel, vres);
+        else VAP_FUSED(float, false, (const float *)vel, (const float *)nullptr);
+#undef VAP_FUSED
+        if (e == hipSuccess) return hipGetLastError();
+        (void)hipGetLastError();      // (the attribute could not be set: the two kernels take the call)
+    }
     if (quad && f64)
         hipLaunchKernelGGL((k_time_integrate_quad<double, false>), dim3(nq), dim3(64), 0, st, B, S, meta, (const double *)vel,
                            (const float *)nullptr, max_acc, max_dec, dt, cap, rows, counts, flags);
