@@ -14,7 +14,6 @@
 //                      sign / wrap of MPG:559-563, angular velocity (MPG:575), and the ordered list
 //                      of node crossings (nodes_map, MPG:420, 527-529).
 // All arithmetic is fp64 in the reference's order; only the velocity row is read in the batch dtype.
-#include <mutex>
 #include "vap_device.h"
 #include "vap_kernels.h"
 
@@ -674,22 +673,25 @@ hipError_t launch_time_profile(hipStream_t st, bool f64, int B, int W, int S, co
 #define VAP_FUSED(R_, RES_, VEL_, VRES_)                                                                                        \
         do {                                                                                                                    \
             auto kern = k_time_fused<R_, RES_>;                                                                                 \
-            static std::once_flag once[64];                                                                                     \
+            static int attr_state[64] = {};   /* per instantiation and device: 0 not asked yet, 1 granted, -1 refused */        \
             int dev = 0;                                                                                                        \
             (void)hipGetDevice(&dev);                                                                                           \
-            std::call_once(once[dev < 0 || dev >= 64 ? 0 : dev], [&] {                                                          \
-                e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds); \
-            });                                                                                                                 \
-            if (e == hipSuccess)                                                                                                \
+            dev = dev < 0 || dev >= 64 ? 0 : dev;                                                                               \
+            if (attr_state[dev] == 0)                                                                                           \
+                attr_state[dev] = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                      (int)kFusedLds) == hipSuccess ? 1 : -1;                                   \
+            if (attr_state[dev] == 1)                                                                                           \
                 hipLaunchKernelGGL(kern, dim3(nq), dim3(kFusedThreads), kFusedLds, st, B, W, S, segments, lut, meta, VEL_, VRES_, max_acc, \
                                    max_dec, dt, cap, rows, counts, nodes_map, flags);                                           \
+            else                                                                                                                \
+                e = hipErrorInvalidValue;                                                                                       \
         } while (0)
         if (f64) VAP_FUSED(double, false, (const double *)vel, (const float *)nullptr);
         else if (vres) VAP_FUSED(float, true, (const float *)vel, vres);
         else VAP_FUSED(float, false, (const float *)vel, (const float *)nullptr);
 #undef VAP_FUSED
         if (e == hipSuccess) return hipGetLastError();
-        (void)hipGetLastError();      // (the attribute could not be set: the two kernels take the call)
+        (void)hipGetLastError();      // (a device that does not grant 128 KB of LDS: the two kernels take the call)
     }
     if (quad && f64)
         hipLaunchKernelGGL((k_time_integrate_quad<double, false>), dim3(nq), dim3(64), 0, st, B, S, meta, (const double *)vel,
