@@ -169,8 +169,8 @@ class DeviceRoute:
     ``use_batch_kernels`` (class or instance attribute, default False): True runs forward_backward (velocity only) and
     motion_profile on the batch kernels with B = 1 — 0.7 ms instead of 3.2 ms for config 1.  The default stays on the
     one-lane statement-by-statement vap_route_* layer because it keeps the reference's own operation order: against the
-    oracle on 14 000 random routes and robots it is at 1.4e-9 / 3e-8 (velocity / time rows) at worst, where the batch
-    kernels' reordered arithmetic, amplified by the recurrence, reaches 1.2e-7 / 7.5e-6 on 28 000 (profiles/r04_fuzz.txt)
+    oracle on 21 000 random routes and robots it is at 3.3e-9 / 1.5e-7 (velocity / time rows) at worst, where the batch
+    kernels' reordered arithmetic, amplified by the recurrence, reaches 1.2e-7 / 7.5e-6 on 42 000 (profiles/r04_fuzz.txt)
     — inside north_star's 1e-5, but a drop-in is judged on fidelity first."""
     use_batch_kernels = False
 
