@@ -13,6 +13,12 @@
 //                      SM:332-346 curvature / heading step lookup, SM:204-215 point, the heading
 //                      sign / wrap of MPG:559-563, angular velocity (MPG:575), and the ordered list
 //                      of node crossings (nodes_map, MPG:420, 527-529).
+// The recurrence comes in three forms with the same rows bit for bit (VAP_OPT_TIME_KERNEL; launch_time_profile picks):
+//   k_time_integrate        a lane per path — batches of more than 16 384 paths (many wavefronts per SIMD);
+//   k_time_integrate_quad   four lanes per path with the step's memory operations ordered by hand — batches that
+//                           leave at most one wavefront per SIMD, where the time is one path's dependent chain;
+//   k_time_fused            the quad recurrence and k_time_geometry's work in one workgroup — plain paths, at most one
+//                           workgroup of 16 paths per CU: the geometry runs in the shadow of the recurrence.
 // All arithmetic is fp64 in the reference's order; only the velocity row is read in the batch dtype.
 #include "vap_device.h"
 #include "vap_kernels.h"
