@@ -137,18 +137,31 @@ __global__ void k_event_merge(int B, int W, int M, const LimitInputs in, const i
 //   backward (MPG:256-257)  at a boundary: max_acc = max_accels[boundary_map[i] + 1] — the NEXT list entry, i.e. the
 //                           event after the last one on the nearest boundary at or above i (max_acc past the end);
 //                           above every boundary: what the forward sweep left; max_dec: what the forward sweep left
-template <typename R>
+template <typename R, bool EV_LDS>
 __global__ void k_limit_fill(int B, int W, int S, int E, const double *__restrict__ meta, LimitInputs in,
                              const int *__restrict__ ev_k, const double *__restrict__ ev_mv,
                              const double *__restrict__ ev_ma, const int *__restrict__ ev_stop, R *__restrict__ vcap,
                              R *__restrict__ acc_fwd, R *__restrict__ acc_bwd, R *__restrict__ dec_bwd)
 {
+    // the path's event list in LDS (a few dozen entries): every sample searches it, and from global memory the five
+    // dependent probes of a search were most of the kernel (252 -> ~90 us for config 3's 4.1e7 samples)
+    extern __shared__ __attribute__((aligned(16))) double s_ev[];     // [E] max_velocity, [E] max_acceleration, then ints
     const int b = blockIdx.y;
     const int N = (int)meta[(size_t)b * kMetaStride + 3];
-    const int *K = ev_k + (size_t)b * E;
-    const double *MV = ev_mv + (size_t)b * E;
-    const double *MA = ev_ma + (size_t)b * E;
-    const int *ST = ev_stop + (size_t)b * E;
+    const double *MV = ev_mv + (size_t)b * E, *MA = ev_ma + (size_t)b * E;
+    const int *K = ev_k + (size_t)b * E, *ST = ev_stop + (size_t)b * E;
+    if constexpr (EV_LDS) {       // (lists too long for LDS — thousands of action points — are searched where they lie)
+        double *mv = s_ev, *ma = s_ev + E;
+        int *kk = reinterpret_cast<int *>(s_ev + 2 * E), *st = kk + E;
+        for (int e = threadIdx.x; e < E; e += blockDim.x) {
+            mv[e] = MV[e];
+            ma[e] = MA[e];
+            kk[e] = K[e];
+            st[e] = ST[e];
+        }
+        __syncthreads();
+        MV = mv; MA = ma; K = kk; ST = st;
+    }
     const double mv0 = in.node_mv ? in.node_mv[(size_t)b * W] : 0.0, ma0 = in.node_ma ? in.node_ma[(size_t)b * W] : 0.0;
     const double m0 = mv0 > 0.0 ? mv0 : in.max_vel;     // MPG:100-107: node 0
     const double a0 = ma0 > 0.0 ? ma0 : in.max_acc;
@@ -164,33 +177,54 @@ __global__ void k_limit_fill(int B, int W, int S, int E, const double *__restric
     const int reached = count_le(N - 2);
     const double left = reached == 0 ? a0 : acc_of(reached - 1);   // what the forward sweep leaves behind
     if (dec_bwd && blockIdx.x == 0 && threadIdx.x == 0) dec_bwd[b] = (R)left;
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < S; k += gridDim.x * blockDim.x) {
-        double v = 0.0, af = 0.0, ab = 0.0;
-        if (k < N - 1) {
-            const int before = count_le(k - 1);     // events that have switched the limit before this sample
-            v = before == 0 ? m0 : (MV[before - 1] > 0.0 ? MV[before - 1] : in.max_vel);
-            int upto = before;
-            for (; upto < E && K[upto] == k; upto++)
-                if (ST[upto]) v = 0.01;              // MPG:127, 153
-            if (acc_fwd) af = upto == 0 ? a0 : acc_of(upto - 1);
-        } else if (k == N - 1) {
-            v = in.end_vel;                          // MPG:172
-        }
-        if (acc_fwd && k <= N - 1 && k >= 1) {
-            // nearest boundary at or above k: the first event with sample >= k
-            const int first = count_le(k - 1);
-            if (first >= reached) {
-                ab = left;
-            } else {
-                const int last_there = count_le(K[first]) - 1;     // the last event on that sample
-                ab = last_there + 1 < reached ? acc_of(last_there + 1) : in.max_acc;
+    // four consecutive samples per thread: one search for the first, a walk along the (sparse) event list for the others,
+    // and the rows leave as 16- / 32-byte pieces
+    for (int k0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4; k0 < S; k0 += gridDim.x * blockDim.x * 4) {
+        R ov[4], oaf[4], oab[4];
+        int before = count_le(k0 - 1);                  // events that have switched the limit before sample k0
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = k0 + j;
+            if (j) while (before < E && K[before] <= k - 1) before++;
+            double v = 0.0, af = 0.0, ab = 0.0;
+            if (k < N - 1) {
+                v = before == 0 ? m0 : (MV[before - 1] > 0.0 ? MV[before - 1] : in.max_vel);
+                int upto = before;
+                for (; upto < E && K[upto] == k; upto++)
+                    if (ST[upto]) v = 0.01;              // MPG:127, 153
+                if (acc_fwd) af = upto == 0 ? a0 : acc_of(upto - 1);
+            } else if (k == N - 1) {
+                v = in.end_vel;                          // MPG:172
             }
+            if (acc_fwd && k <= N - 1 && k >= 1) {
+                // nearest boundary at or above k: the first event with sample >= k
+                const int first = before;
+                if (first >= reached) {
+                    ab = left;
+                } else {
+                    const int last_there = count_le(K[first]) - 1;     // the last event on that sample
+                    ab = last_there + 1 < reached ? acc_of(last_there + 1) : in.max_acc;
+                }
+            }
+            ov[j] = (R)v; oaf[j] = (R)af; oab[j] = (R)ab;
         }
-        const size_t o = (size_t)b * S + k;
-        vcap[o] = (R)v;
+        const size_t o = (size_t)b * S + k0;
+        auto put = [&](R *__restrict__ row, const R (&x)[4]) {
+            if (k0 + 3 < S && (o & 3) == 0) {
+                if constexpr (sizeof(R) == 8) {
+                    *reinterpret_cast<double2 *>(row + o) = make_double2(x[0], x[1]);
+                    *reinterpret_cast<double2 *>(row + o + 2) = make_double2(x[2], x[3]);
+                } else {
+                    *reinterpret_cast<float4 *>(row + o) = make_float4(x[0], x[1], x[2], x[3]);
+                }
+            } else {
+                for (int j = 0; j < 4 && k0 + j < S; j++) row[o + j] = x[j];
+            }
+        };
+        put(vcap, ov);
         if (acc_fwd) {
-            acc_fwd[o] = (R)af;
-            acc_bwd[o] = (R)ab;
+            put(acc_fwd, oaf);
+            put(acc_bwd, oab);
         }
     }
 }
@@ -204,13 +238,14 @@ hipError_t launch_route_limits(hipStream_t st, bool f64, int B, int W, int M, in
     const int per = W + M;
     hipLaunchKernelGGL(k_event_samples, dim3((B * per + 127) / 128), dim3(128), 0, st, B, W, M, lut, meta, aux, runs, rt, in.ap_t, node_k, ap_k);
     if (E > 0) hipLaunchKernelGGL(k_event_merge, dim3((B + 63) / 64), dim3(64), 0, st, B, W, M, in, node_k, ap_k, ev_k, ev_mv, ev_ma, ev_stop);
-    const dim3 grid((unsigned)((S + 255) / 256 < 64 ? (S + 255) / 256 : 64), (unsigned)B);
-    if (f64)
-        hipLaunchKernelGGL(k_limit_fill<double>, grid, dim3(256), 0, st, B, W, S, E, meta, in, ev_k, ev_mv, ev_ma, ev_stop, (double *)vcap,
-                           (double *)acc_fwd, (double *)acc_bwd, (double *)dec_bwd);
-    else
-        hipLaunchKernelGGL(k_limit_fill<float>, grid, dim3(256), 0, st, B, W, S, E, meta, in, ev_k, ev_mv, ev_ma, ev_stop, (float *)vcap,
-                           (float *)acc_fwd, (float *)acc_bwd, (float *)dec_bwd);
+    const dim3 grid((unsigned)((S + 1023) / 1024 < 64 ? (S + 1023) / 1024 : 64), (unsigned)B);
+    const size_t lds = (sizeof(double) * 2 + sizeof(int) * 2) * (size_t)E + 16;
+#define VAP_FILL(R_, LDS_)                                                                                                      \
+    hipLaunchKernelGGL((k_limit_fill<R_, LDS_>), grid, dim3(256), LDS_ ? lds : 0, st, B, W, S, E, meta, in, ev_k, ev_mv, ev_ma, ev_stop, \
+                       (R_ *)vcap, (R_ *)acc_fwd, (R_ *)acc_bwd, (R_ *)dec_bwd)
+    if (lds <= 48 * 1024) { if (f64) VAP_FILL(double, true); else VAP_FILL(float, true); }
+    else { if (f64) VAP_FILL(double, false); else VAP_FILL(float, false); }
+#undef VAP_FILL
     return hipGetLastError();
 }
 
