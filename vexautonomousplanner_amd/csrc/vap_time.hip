@@ -790,7 +790,7 @@ __global__ __launch_bounds__(256) void k_time_waits(int W, int M, int cap_in, in
                                                     int *__restrict__ counts_out, int *__restrict__ nodes_out,
                                                     int *__restrict__ actions_out, uint32_t *__restrict__ flags)
 {
-    extern __shared__ int s_ev[];            // [E][3]: row, steps, node (>= 0: an in-place turn at that node; -1: a wait)
+    extern __shared__ __attribute__((aligned(16))) int s_ev[];   // [E][3]: row, steps, node (>= 0: an in-place turn at that node; -1: a wait)
     __shared__ int s_n_ev;
     const int E = 2 * W + M;
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -803,7 +803,17 @@ __global__ __launch_bounds__(256) void k_time_waits(int W, int M, int cap_in, in
     double *out = rows_out + (size_t)b * cap_out * kRowWidth;
     const double *seg = segments + (size_t)b * G * 12;
     int *ev_row = s_ev, *ev_steps = s_ev + E, *ev_node = s_ev + 2 * E;
-    const double *ntu = ev.node_turn ? ev.node_turn + (size_t)b * W : nullptr;
+    // the per-node inputs thread 0 walks below, in LDS first (one round trip instead of one per node and array)
+    int *s_nodes = s_ev + 3 * E;                                            // [W] nodes_in
+    double *s_ntu = reinterpret_cast<double *>(s_ev + 3 * E + W + ((3 * E + W) & 1));   // [W] node_turn (0 without), 8-byte aligned
+    double *s_nw = s_ntu + W;                                               // [W] node_wait (0 without)
+    for (int i = tid; i < W; i += 256) {
+        s_nodes[i] = nodes_in[(size_t)b * W + i];
+        s_ntu[i] = ev.node_turn ? ev.node_turn[(size_t)b * W + i] : 0.0;
+        s_nw[i] = ev.node_wait ? ev.node_wait[(size_t)b * W + i] : 0.0;
+    }
+    __syncthreads();
+    const double *ntu = ev.node_turn ? s_ntu : nullptr;
     if (tid == 0) {
         const double plain_sp[kSplineStride] = {t_max, 0.0, 0.0, 0.0};
         LutView v;
@@ -813,7 +823,7 @@ __global__ __launch_bounds__(256) void k_time_waits(int W, int M, int cap_in, in
         v.total = total;
         v.end_param = end_param;
         auto t_of_row = [&](int i) { return lutv_distance_to_time(v, i == 0 ? 0.0 : in[(size_t)(i - 1) * kRowWidth + 1]); };
-        const double *nw = ev.node_wait ? ev.node_wait + (size_t)b * W : nullptr;
+        const double *nw = ev.node_wait ? s_nw : nullptr;
         int n_ev = 0, shift = 0, n_act = 0;
         auto steps_of = [&](double w) { return w > 0.0 ? (int)(w / dt) : 0; };   // int(wait_time / dt)
         auto push = [&](int row, int steps, int node) {
@@ -843,7 +853,7 @@ __global__ __launch_bounds__(256) void k_time_waits(int W, int M, int cap_in, in
         };
         find_action();
         while (node < n_nodes || next_act_row >= 0) {
-            const int rn = node < n_nodes ? nodes_in[(size_t)b * W + node] : 0x7fffffff;
+            const int rn = node < n_nodes ? s_nodes[node] : 0x7fffffff;
             const int ra = next_act_row >= 0 ? next_act_row : 0x7fffffff;
             if (rn <= ra) {             // node first on the same row (MPG:527 then 546)
                 nodes_out[(size_t)b * W + node] = rn + shift;
@@ -873,17 +883,17 @@ __global__ __launch_bounds__(256) void k_time_waits(int W, int M, int cap_in, in
     }
     __syncthreads();
     const int n_ev = s_n_ev;
-    // rows: row i moves behind every event at a row <= i
-    for (int i = tid; i < T; i += 256) {
+    // rows: row i moves behind every event at a row <= i (four threads per row, 16 bytes each: consecutive threads move
+    // consecutive pieces)
+    for (int idx = tid; idx < 4 * T; idx += 256) {
+        const int i = idx >> 2, piece = idx & 3;
         int shift = 0;
         for (int e = 0; e < n_ev && ev_row[e] <= i; e++) shift += ev_steps[e];
         const int o = i + shift;
         if (o >= cap_out) continue;
-        const double *q = in + (size_t)i * kRowWidth;
-        double *w = out + (size_t)o * kRowWidth;
-        w[0] = q[0] + (double)shift * dt;
-#pragma unroll
-        for (int c = 1; c < kRowWidth; c++) w[c] = q[c];
+        double2 v = *reinterpret_cast<const double2 *>(in + (size_t)i * kRowWidth + 2 * piece);
+        if (piece == 0) v.x = v.x + (double)shift * dt;
+        *reinterpret_cast<double2 *>(out + (size_t)o * kRowWidth + 2 * piece) = v;
     }
     __syncthreads();
     // inserted rows, event after event: each continues from the output row in front of it (headings[-1],
@@ -945,7 +955,8 @@ hipError_t launch_time_waits(hipStream_t st, int B, int W, int M, int cap_in, in
                              double *rows_out, int *counts_out, int *nodes_out, int *actions_out, uint32_t *flags, RouteTables rt,
                              const double *node_turn, const int *node_reverse, double max_vel, double max_acc, double track_width)
 {
-    const size_t lds = sizeof(int) * 3 * (size_t)(2 * W + M);
+    // events [E][3] ints, then the node arrays: W ints (+ one of padding) and 2 W doubles
+    const size_t lds = sizeof(int) * (3 * (size_t)(2 * W + M) + W + 2) + sizeof(double) * 2 * (size_t)W + 8;
     TimeEventInputs ev;
     ev.node_wait = node_wait;
     ev.node_turn = node_turn;
