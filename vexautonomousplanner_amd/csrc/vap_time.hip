@@ -437,6 +437,23 @@ __global__ __launch_bounds__(256) void k_time_geometry(int W, int cap, const dou
         }
     };
     const int *rev = node_reverse ? node_reverse + (size_t)b * W : nullptr;
+    // reversed state behind node n = node 0's flag and every passed node's toggle it: the running XOR, once per workgroup
+    // (a row used to walk its passed nodes itself: up to W loads per row)
+    __shared__ unsigned char s_rev[kMaxWaypoints];
+    if (rev) {
+        if (tid < 64) {
+            int carry = 0;
+            for (int n0 = 0; n0 < W; n0 += 64) {
+                const int n = n0 + tid;
+                int x = (n < W && rev[n] != 0) ? 1 : 0;
+                for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o); if (tid >= o) x ^= y; }
+                x ^= carry;
+                if (n < W) s_rev[n] = (unsigned char)x;
+                carry = __shfl(x, 63);
+            }
+        }
+        __syncthreads();
+    }
     double *out = rows + (size_t)b * cap * kRowWidth;
     for (int r0 = 0; r0 < T; r0 += 256) {
         const int i = r0 + tid;
@@ -472,7 +489,7 @@ __global__ __launch_bounds__(256) void k_time_geometry(int W, int cap, const dou
             if (rev) {
                 int node_idx = k_self - 1 + (crossing ? 1 : 0);
                 node_idx = node_idx > W - 1 ? W - 1 : node_idx;
-                for (int n = 0; n <= node_idx; n++) reversed ^= rev[n] != 0;
+                reversed = node_idx >= 0 && s_rev[node_idx] != 0;
             }
             // SM:332-346, 550-580: step lookup into the (never materialised) property table
             const int jj = table_index(t, tab_n, end_param);
