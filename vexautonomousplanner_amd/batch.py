@@ -294,21 +294,26 @@ class BatchedTrajectoryGenerator:
         as2d = lambda a: np.zeros((B, W)) if a is None else np.asarray(a, dtype=np.float64).reshape(B, W)
         mv, ma = as2d(node_max_velocity), as2d(node_max_acceleration)
         stop = np.zeros((B, W), dtype=bool) if node_stop is None else np.asarray(node_stop).astype(bool).reshape(B, W)
-        aps = action_points if action_points is not None else [[] for _ in range(B)]
-        M = max((len(a) for a in aps), default=0)
-        ap_t = np.full((B, max(M, 1)), np.inf)
-        ap_mv, ap_ma = np.zeros((B, max(M, 1))), np.zeros((B, max(M, 1)))
-        ap_stop = np.zeros((B, max(M, 1)), dtype=np.int32)
-        for b, al in enumerate(aps):
-            for i, a in enumerate(al):
-                ap_t[b, i] = float(a["t"])
-                ap_mv[b, i] = float(a.get("max_velocity", 0.0))
-                ap_ma[b, i] = float(a.get("max_acceleration", 0.0))
-                ap_stop[b, i] = int(bool(a.get("stop", False)))
+        M = max((len(a) for a in action_points), default=0) if action_points is not None else 0
+        Mp = max(M, 1)
+        ap_t = np.full((B, Mp), np.inf)
+        ap_mv, ap_ma = np.zeros((B, Mp)), np.zeros((B, Mp))
+        ap_stop = np.zeros((B, Mp), dtype=np.int32)
+        if M:                                   # (no per-path Python loop for a batch without action points)
+            for b, al in enumerate(action_points):
+                for i, a in enumerate(al):
+                    ap_t[b, i] = float(a["t"])
+                    ap_mv[b, i] = float(a.get("max_velocity", 0.0))
+                    ap_ma[b, i] = float(a.get("max_acceleration", 0.0))
+                    ap_stop[b, i] = int(bool(a.get("stop", False)))
         with_acc = bool((ma > 0).any() or (ap_ma > 0).any())
         dev = self.device
-        d = {k: torch.tensor(v, device=dev) for k, v in dict(mv=mv, ma=ma, stop=stop.astype(np.int32), ap_t=ap_t, ap_mv=ap_mv,
-                                                               ap_ma=ap_ma, ap_stop=ap_stop).items()}
+        # two uploads (one per element type) instead of seven: the arrays one after the other, views of the device block
+        fl_dev = torch.tensor(np.concatenate([x.ravel() for x in (mv, ma, ap_t, ap_mv, ap_ma)]), device=dev)
+        it_dev = torch.tensor(np.concatenate([stop.astype(np.int32).ravel(), ap_stop.ravel()]), device=dev)
+        o = np.cumsum([0, B * W, B * W, B * Mp, B * Mp, B * Mp])
+        d = {"mv": fl_dev[o[0]:o[1]], "ma": fl_dev[o[1]:o[2]], "ap_t": fl_dev[o[2]:o[3]], "ap_mv": fl_dev[o[3]:o[4]],
+             "ap_ma": fl_dev[o[4]:o[5]], "stop": it_dev[:B * W], "ap_stop": it_dev[B * W:]}
         # the limit rows have the type of the recurrence they enter (vap_limit_rows_dtype): fp64 in the default mode — an
         # fp32-rounded limit (13.9 ft/s^2) is amplified by the recurrence past 1e-5
         ldt = torch.float64 if self._L.vap_limit_rows_dtype(self.ctx.handle, self.vdtype) == _lib.VAP_F64 else torch.float32
@@ -352,14 +357,14 @@ class BatchedTrajectoryGenerator:
         W = nodes_in.shape[1]
         dev = self.device
         wait = np.zeros((B, W)) if node_wait_time is None else np.asarray(node_wait_time, dtype=np.float64).reshape(B, W)
-        aps = action_points if action_points is not None else [[] for _ in range(B)]
-        M = max((len(a) for a in aps), default=0)
+        M = max((len(a) for a in action_points), default=0) if action_points is not None else 0
         ap_t = np.full((B, max(M, 1)), np.inf)
         ap_w = np.zeros((B, max(M, 1)))
-        for b, al in enumerate(aps):
-            for i, a in enumerate(al):
-                ap_t[b, i] = float(a["t"])
-                ap_w[b, i] = float(a.get("wait_time", 0.0))
+        if M:                                   # (no per-path Python loop for a batch without action points)
+            for b, al in enumerate(action_points):
+                for i, a in enumerate(al):
+                    ap_t[b, i] = float(a["t"])
+                    ap_w[b, i] = float(a.get("wait_time", 0.0))
         extra = int(np.max(np.floor(wait / dt).sum(axis=1) + np.floor(ap_w / dt).sum(axis=1))) + 1
         c = _lib.make_constraints(constraints)
         d_turn = d_rev = None
@@ -377,9 +382,9 @@ class BatchedTrajectoryGenerator:
                "counts": torch.zeros((B, 3), dtype=torch.int32, device=dev),
                "nodes_map": torch.zeros((B, W), dtype=torch.int32, device=dev),
                "actions_map": torch.zeros((B, max(M, 1)), dtype=torch.int32, device=dev)}
-        d_wait = torch.tensor(wait, device=dev)
-        d_apt = torch.tensor(ap_t, device=dev)
-        d_apw = torch.tensor(ap_w, device=dev)
+        # one upload for the three float arrays
+        fl_dev = torch.tensor(np.concatenate([wait.ravel(), ap_t.ravel(), ap_w.ravel()]), device=dev)
+        d_wait, d_apt, d_apw = fl_dev[:B * W], fl_dev[B * W:B * W + ap_t.size], fl_dev[B * W + ap_t.size:]
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         self.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(self._L.vap_time_insert_events(self.ctx.handle, B, W, M, cap_in, cap_out, float(dt), C.byref(c),
