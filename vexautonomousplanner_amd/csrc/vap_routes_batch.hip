@@ -13,6 +13,7 @@
 //       belonging to the earlier spline (SM:243-275)                                                -> k_sample_routes
 // The velocity pass is the plain one: forward_backward_pass does nothing special at a reverse or turn node
 // (MPG:112-176); those act in the time domain (MPG:435-476, 487-507).
+#include <type_traits>
 #include "vap_device.h"
 #include "vap_kernels.h"
 
@@ -370,14 +371,16 @@ __global__ __launch_bounds__(kRouteThreads) void k_sample_routes(int W, int NS, 
         s_dx[kRouteThreads] = nx.ex; s_dy[kRouteThreads] = nx.ey; s_j[kRouteThreads] = nx.jj; s_th[kRouteThreads] = nx.th;
     }
     __syncthreads();
+    // a thread's four consecutive samples leave as one 16-byte piece per fp32 row (two per fp64 row) where the row allows
+    OT vx[kRouteSPT], vy[kRouteSPT], vh[kRouteSPT], vk[kRouteSPT], vd[kRouteSPT];
+    double vk64[kRouteSPT], vd64[kRouteSPT];
 #pragma unroll
     for (int i = 0; i < kRouteSPT; i++) {
         const int k = kb + i;
-        if (k >= S) break;
         const Eval &me = ev[i];
         OT dth = (OT)0;
         double dth64 = 0.0;
-        if (k < N - 1) {
+        if (k < S && k < N - 1) {
             const double nx = i + 1 < kRouteSPT ? ev[(i + 1) % kRouteSPT].ex : s_dx[tid + 1];
             const double ny = i + 1 < kRouteSPT ? ev[(i + 1) % kRouteSPT].ey : s_dy[tid + 1];
             const OT nth = i + 1 < kRouteSPT ? ev[(i + 1) % kRouteSPT].th : s_th[tid + 1];
@@ -392,14 +395,38 @@ __global__ __launch_bounds__(kRouteThreads) void k_sample_routes(int W, int NS, 
             }
         }
         const bool in = k < N;
-        if (ox) ox[row + k] = in ? me.x : (OT)0;
-        if (oy) oy[row + k] = in ? me.y : (OT)0;
-        if (oh) oh[row + k] = in ? me.th : (OT)0;
-        if (ok) ok[row + k] = in ? (OT)me.kap : (OT)0;
-        if (odth) odth[row + k] = in ? dth : (OT)0;
+        vx[i] = in ? me.x : (OT)0;
+        vy[i] = in ? me.y : (OT)0;
+        vh[i] = in ? me.th : (OT)0;
+        vk[i] = in ? (OT)me.kap : (OT)0;
+        vd[i] = in ? dth : (OT)0;
+        vk64[i] = in ? me.kap : 0.0;
+        vd64[i] = in ? dth64 : 0.0;
+    }
+    if (kb < S) {
+        const size_t o = row + kb;
+        const bool whole = kb + kRouteSPT <= S && (o & 3) == 0;
+        auto put = [&](auto *__restrict__ dst, const auto (&x)[kRouteSPT]) {
+            using T = std::remove_reference_t<decltype(x[0])>;
+            if (whole) {
+                if constexpr (sizeof(T) == 4) {
+                    *reinterpret_cast<float4 *>(dst + o) = make_float4(x[0], x[1], x[2], x[3]);
+                } else {
+                    *reinterpret_cast<double2 *>(dst + o) = make_double2(x[0], x[1]);
+                    *reinterpret_cast<double2 *>(dst + o + 2) = make_double2(x[2], x[3]);
+                }
+            } else {
+                for (int i = 0; i < kRouteSPT && kb + i < S; i++) dst[o + i] = x[i];
+            }
+        };
+        if (ox) put(ox, vx);
+        if (oy) put(oy, vy);
+        if (oh) put(oh, vh);
+        if (ok) put(ok, vk);
+        if (odth) put(odth, vd);
         if constexpr (HI) {
-            ok64[row + k] = in ? me.kap : 0.0;
-            odth64[row + k] = in ? dth64 : 0.0;
+            put(ok64, vk64);
+            put(odth64, vd64);
         }
     }
 }
