@@ -62,9 +62,19 @@ def cpu_baseline(wl, budget_s=12.0):
         elapsed += time.perf_counter() - t0
         done += per_batch
         k += 1
+    # the same restatement on ONE thread (single-threaded beside all cores), a few seconds of it
+    done1, elapsed1 = 0, 0.0
+    while elapsed1 < 2.5 and done1 < 4096:
+        wp = make_waypoints(4, W, wl["seed"] + 777 + done1).astype(np.float64)
+        t0 = time.perf_counter()
+        oracle.profile_batch(wp, S, DEFAULT_CONSTRAINTS, n_threads=1, want=("velocity",))
+        elapsed1 += time.perf_counter() - t0
+        done1 += 4
     return {"value": done * S / elapsed, "unit": "sample-points/s", "cores": cores, "kind": "port",
             "sample": f"{done} paths x {W} waypoints x {S} samples of the same generator in {k} batches, "
-                      f"{cores} threads, {elapsed:.1f}s of CPU work"}
+                      f"{cores} threads, {elapsed:.1f}s of CPU work",
+            "single_thread": {"value": done1 * S / elapsed1, "unit": "sample-points/s", "cores": 1,
+                              "sample": f"{done1} paths, {elapsed1:.1f}s"}}
 
 
 def parity_check(out, wp, S, constraints, n_paths, dtype):
